@@ -1,0 +1,478 @@
+"""Scenario compiler: turns a traffic scenario into the dense tables the HIP
+microsimulator, the CPU oracle and the host-side env mirror all consume.
+
+Only ``large_grid`` is generated from first principles here; every rule is a
+restatement of the reference's own network generator and env class:
+
+* node grid / boundary nodes ........ large_grid/data/build_file.py:27-50
+* road types (2-lane 20 m/s streets, 1-lane 11 m/s avenues) ... :53-58
+* edges (200 m internal, 75 m boundary) ........................ :14-19,66-98
+* lane-to-lane connections (dedicated left lane on streets) .... :107-124
+* lane-area detectors ``pos=-50 endPos=-1`` on incoming lanes ... :360-391,445
+* demand (12 OD pairs, piece-wise constant vehsPerHour) ........ :268-326
+* phase set, neighbour map ........ envs/large_grid_env.py:38-42,73-101
+* agent order = sorted node ids, lanes = dedup of controlled lanes in link
+  order ........................................ envs/env.py:207-254
+* state/fingerprint dims ........................ envs/env.py:303-323
+* yellow-phase rule .............................. envs/env.py:128-152
+
+The SUMO-internal parts the reference does not contain (route choice, lane
+choice, junction right-of-way) are *defined* here and in DESIGN.md ("microsim
+spec"); they are this repo's spec, not SUMO's.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from fractions import Fraction
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+# --- microsim spec constants (DESIGN.md "microsim spec") -------------------
+VEH_LEN = 5.0        # vType length=5            (build_file.py:279)
+VEH_ACCEL = 5.0      # vType accel=5
+VEH_DECEL = 10.0     # vType decel=10
+MIN_GAP = 2.5        # SUMO default minGap (not in the reference tree)
+LANE_CAP = 28        # vehicle slots per lane: 200 m / 7.5 m = 26.7 -> 27 (+1)
+MAX_CROSS = 4        # vehicles that may leave one lane in one sim-step
+MAX_UP = 4           # upstream feeder lanes per lane
+DET_LEN = 50.0       # lane-area detector covers the last 50 m
+NO_LANE = -1
+
+
+@dataclass
+class Scenario:
+    name: str
+    agent: str                       # 'ma2c' | 'ia2c' | 'greedy' | ...
+    node_names: List[str]            # sorted TL ids == agent order
+    n_agent: int
+    # lanes
+    lane_names: List[str]
+    lane_len: np.ndarray             # f32 [NL]
+    lane_vmax: np.ndarray            # f32 [NL]
+    lane_node: np.ndarray            # i32 [NL] agent index of downstream TL node or -1 (sink)
+    lane_det_start: np.ndarray       # f32 [NL] detector start position (L-50, or 0 = whole lane)
+    lane_opp: np.ndarray             # i32 [NL] opposing approach lane (left-turn yield) or -1
+    lane_up: np.ndarray              # i32 [NL, MAX_UP] feeder lanes (ascending) or -1
+    # routes
+    n_route: int
+    mv_next: np.ndarray              # i32 [NL, NR] next lane, -1 = arrive at lane end, -2 = n/a
+    mv_link: np.ndarray              # i32 [NL, NR] link index at downstream node (3*approach+mv) or -1
+    route_entry_lane: np.ndarray     # i32 [NR]
+    route_names: List[Tuple[str, str]]
+    # signals
+    agent_lanes: np.ndarray          # i32 [A, LMAX] incoming lanes in ild order, -1 pad
+    agent_nlane: np.ndarray          # i32 [A]
+    agent_nlink: np.ndarray          # i32 [A]
+    agent_nphase: np.ndarray         # i32 [A]   (= n_a)
+    link_lane: np.ndarray            # i32 [A, KMAX] incoming lane of every signal link
+    phases: List[List[str]]          # per agent list of phase strings
+    green_tab: np.ndarray            # u8 [A, PMAX, KMAX]  chars of phase p
+    yellow_tab: np.ndarray           # u8 [A, PMAX, PMAX, KMAX] chars for prev->new during yellow
+    # neighbourhood
+    neighbors: List[List[int]]       # agent indices, neighbour-list order
+    n_s_ls: List[int]
+    n_w_ls: List[int]
+    n_f_ls: List[int]
+    n_a_ls: List[int]
+    obs_kind: np.ndarray             # i32 [A, SMAX] 0 pad,1 wave,2 wave*coop,3 wait,4 fingerprint
+    obs_src: np.ndarray              # i32 [A, SMAX] lane id (1,2,3) or agent*AMAX+k (4)
+    # demand
+    flows: np.ndarray                # i32 [NF, 4] begin,end,vph,route
+    # env constants (ENV_CONFIG)
+    control_interval_sec: int = 5
+    yellow_interval_sec: int = 2
+    episode_length_sec: int = 3600
+    coop_gamma: float = 0.9
+    norm_wave: float = 5.0
+    norm_wait: float = 100.0
+    clip_wave: float = 2.0
+    clip_wait: float = 2.0
+    coef_wait: float = 0.2
+    objective: str = 'hybrid'
+    has_wait_state: bool = True
+    queue_cap: int = -1              # real_net: min(10, halting)   (env.py:332-333)
+    reward_scale_realnet: bool = False
+    teleport_sec: int = 600          # --time-to-teleport (env.py:281-284)
+    extra: Dict = field(default_factory=dict)
+
+    @property
+    def n_lane(self) -> int:
+        return len(self.lane_names)
+
+    @property
+    def s_max(self) -> int:
+        return int(self.obs_kind.shape[1])
+
+    @property
+    def a_max(self) -> int:
+        return int(max(self.n_a_ls))
+
+
+# ---------------------------------------------------------------------------
+# reference rules restated
+# ---------------------------------------------------------------------------
+def yellow_phase(prev_phase: str, cur_phase: str) -> str:
+    """Link states shown during the yellow interval when switching
+    prev_phase -> cur_phase (envs/env.py:137-152)."""
+    switch_reds, switch_greens = [], []
+    for i, (p0, p1) in enumerate(zip(prev_phase, cur_phase)):
+        if (p0 in 'Gg') and (p1 == 'r'):
+            switch_reds.append(i)
+        elif (p0 in 'r') and (p1 in 'Gg'):
+            switch_greens.append(i)
+    if not switch_reds:
+        return cur_phase
+    y = list(cur_phase)
+    for i in switch_reds:
+        y[i] = 'y'
+    for i in switch_greens:
+        y[i] = 'r'
+    return ''.join(y)
+
+
+LARGE_GRID_PHASES = ['GGgrrrGGgrrr', 'rrrGrGrrrGrG', 'rrrGGrrrrGGr',
+                     'rrrGGGrrrrrr', 'rrrrrrrrrGGG']   # envs/large_grid_env.py:40-41
+
+
+def large_grid_demand(peak_flow1: int, peak_flow2: int):
+    """(from_edge, to_edge, begin, end, vph) for the 84 flow elements, in file
+    order (large_grid/data/build_file.py:284-324).  vph keeps the reference's
+    ``%d`` truncation (e.g. 1100*0.6*0.7 -> 461)."""
+    edge_maps = [0, 1, 2, 3, 4, 5, 5, 10, 15, 20, 25,
+                 25, 24, 23, 22, 21, 21, 16, 11, 6, 1]
+
+    def ext(out_edges, dest=True):
+        res = []
+        for o in out_edges:
+            nt, npn = 'nt%d' % edge_maps[o], 'np%d' % o
+            res.append('%s_%s' % ((nt, npn) if dest else (npn, nt)))
+        return res
+
+    srcs = [ext([12, 13, 14], False), ext([16, 18, 20], False),
+            ext([2, 3, 4], False), ext([6, 8, 10], False)]
+    sinks = [ext([2, 3, 4]), ext([6, 8, 10]), ext([14, 13, 12]), ext([20, 18, 16])]
+    ratios1 = np.array([0.4, 0.7, 0.9, 1.0, 0.75, 0.5, 0.25])
+    ratios2 = np.array([0.3, 0.8, 0.9, 1.0, 0.8, 0.6, 0.2])
+    flows = [peak_flow1 * 0.6 * ratios1, peak_flow1 * ratios1,
+             peak_flow2 * 0.6 * ratios2, peak_flow2 * ratios2]
+    times = np.arange(0, 3001, 300)
+    id1 = len(ratios1)
+    id2 = len(times) - 1 - id1
+    out = []
+    for i in range(len(times) - 1):
+        tb, te = int(times[i]), int(times[i + 1])
+        if i < id1:
+            for j in (0, 1):
+                for e1, e2 in zip(srcs[j], sinks[j]):
+                    out.append((e1, e2, tb, te, int(flows[j][i])))
+        if i >= id2:
+            for j in (2, 3):
+                for e1, e2 in zip(srcs[j], sinks[j]):
+                    out.append((e1, e2, tb, te, int(flows[j][i - id2])))
+    return out
+
+
+def large_grid_neighbor_map() -> Dict[str, List[str]]:
+    """envs/large_grid_env.py:73-101 (internal nodes list N,E,S,W)."""
+    m = {'nt1': ['nt6', 'nt2'], 'nt5': ['nt10', 'nt4'],
+         'nt21': ['nt22', 'nt16'], 'nt25': ['nt20', 'nt24'],
+         'nt2': ['nt7', 'nt3', 'nt1'], 'nt3': ['nt8', 'nt4', 'nt2'],
+         'nt4': ['nt9', 'nt5', 'nt3'], 'nt22': ['nt23', 'nt17', 'nt21'],
+         'nt23': ['nt24', 'nt18', 'nt22'], 'nt24': ['nt25', 'nt19', 'nt23'],
+         'nt10': ['nt15', 'nt5', 'nt9'], 'nt15': ['nt20', 'nt10', 'nt14'],
+         'nt20': ['nt25', 'nt15', 'nt19'], 'nt6': ['nt11', 'nt7', 'nt1'],
+         'nt11': ['nt16', 'nt12', 'nt6'], 'nt16': ['nt21', 'nt17', 'nt11']}
+    for i in (7, 8, 9, 12, 13, 14, 17, 18, 19):
+        m['nt%d' % i] = ['nt%d' % (i + 5), 'nt%d' % (i + 1), 'nt%d' % (i - 5), 'nt%d' % (i - 1)]
+    return m
+
+
+# ---------------------------------------------------------------------------
+# generic helpers
+# ---------------------------------------------------------------------------
+def _state_dims(agent, n_lane_ls, n_a_ls, neighbors, has_wait):
+    """envs/env.py:303-323."""
+    n_s, n_w, n_f = [], [], []
+    for a, nl in enumerate(n_lane_ls):
+        num_wave, num_fp = nl, 0
+        for j in neighbors[a]:
+            if agent not in ('a2c', 'greedy'):
+                num_wave += n_lane_ls[j]
+            if agent == 'ma2c':
+                num_fp += n_a_ls[j] - 1
+        num_wait = nl if has_wait else 0
+        n_s.append(num_wave + num_wait + num_fp)
+        n_w.append(num_wait)
+        n_f.append(num_fp)
+    return n_s, n_w, n_f
+
+
+def _obs_table(agent, agent_lanes, agent_nlane, n_a_ls, neighbors, has_wait, a_max):
+    """Gather table for envs/env.py:163-205: [own wave ; neighbour waves
+    (*coop_gamma for ma2c) ; own wait ; neighbour fingerprints (ma2c)]."""
+    rows = []
+    for a in range(len(agent_nlane)):
+        row = [(1, int(agent_lanes[a, k])) for k in range(agent_nlane[a])]
+        if agent != 'greedy':
+            if agent != 'a2c':
+                for j in neighbors[a]:
+                    kind = 2 if agent == 'ma2c' else 1
+                    row += [(kind, int(agent_lanes[j, k])) for k in range(agent_nlane[j])]
+            if has_wait:
+                row += [(3, int(agent_lanes[a, k])) for k in range(agent_nlane[a])]
+            if agent == 'ma2c':
+                for j in neighbors[a]:
+                    row += [(4, j * a_max + k) for k in range(n_a_ls[j] - 1)]
+        rows.append(row)
+    smax = max(len(r) for r in rows)
+    smax = (smax + 3) // 4 * 4
+    kind = np.zeros((len(rows), smax), np.int32)
+    src = np.zeros((len(rows), smax), np.int32)
+    for a, r in enumerate(rows):
+        for j, (k, s) in enumerate(r):
+            kind[a, j], src[a, j] = k, s
+    return kind, src, [len(r) for r in rows]
+
+
+def _signal_tables(phases_per_agent, kmax):
+    A = len(phases_per_agent)
+    pmax = max(len(p) for p in phases_per_agent)
+    green = np.full((A, pmax, kmax), ord('r'), np.uint8)
+    yellow = np.full((A, pmax, pmax, kmax), ord('r'), np.uint8)
+    for a, ph in enumerate(phases_per_agent):
+        for p, s in enumerate(ph):
+            green[a, p, :len(s)] = np.frombuffer(s.encode(), np.uint8)
+            for q, s0 in enumerate(ph):
+                # yellow_tab[a, prev=q, new=p]
+                y = s if q == p else yellow_phase(s0, s)
+                yellow[a, q, p, :len(y)] = np.frombuffer(y.encode(), np.uint8)
+    return green, yellow
+
+
+# ---------------------------------------------------------------------------
+# large_grid
+# ---------------------------------------------------------------------------
+_APPROACH = ('N', 'E', 'S', 'W')          # SUMO link order: incoming edges clockwise from north
+_RIGHT, _THROUGH, _LEFT = 0, 1, 2
+
+
+def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: int = 925,
+                     **env_kw) -> Scenario:
+    L0, L0_END, N = 200.0, 75.0, 5
+    pos: Dict[str, Tuple[float, float]] = {}
+    for r in range(N):
+        for c in range(N):
+            pos['nt%d' % (1 + N * r + c)] = (L0 * c, L0 * r)
+    for c in range(N):
+        pos['np%d' % (1 + c)] = (L0 * c, -L0_END)
+        pos['np%d' % (11 + (4 - c))] = (L0 * c, L0 * 4 + L0_END)
+    for r in range(N):
+        pos['np%d' % (6 + r)] = (L0 * 4 + L0_END, L0 * r)
+        pos['np%d' % (16 + (4 - r))] = (-L0_END, L0 * r)
+
+    def nbr(node, d):
+        i = int(node[2:]) - 1
+        r, c = divmod(i, N)
+        if d == 'N':
+            return 'nt%d' % (i + 1 + N) if r < N - 1 else 'np%d' % (11 + (4 - c))
+        if d == 'S':
+            return 'nt%d' % (i + 1 - N) if r > 0 else 'np%d' % (1 + c)
+        if d == 'E':
+            return 'nt%d' % (i + 2) if c < N - 1 else 'np%d' % (6 + r)
+        return 'nt%d' % i if c > 0 else 'np%d' % (16 + (4 - r))
+
+    tl_nodes = ['nt%d' % i for i in range(1, N * N + 1)]
+    node_names = sorted(tl_nodes)                       # envs/env.py:232
+    aidx = {n: i for i, n in enumerate(node_names)}
+
+    # edges: id -> (from, to, nlanes, speed, length)
+    edges: Dict[str, Tuple[str, str, int, float, float]] = {}
+    for n in tl_nodes:
+        for d in _APPROACH:
+            o = nbr(n, d)
+            street = d in ('E', 'W')
+            nl, sp = (2, 20.0) if street else (1, 11.0)
+            ln = L0 if o.startswith('nt') else L0_END
+            edges['%s_%s' % (o, n)] = (o, n, nl, sp, ln)
+            edges['%s_%s' % (n, o)] = (n, o, nl, sp, ln)
+
+    # movement geometry at a TL node: approach a (edge arriving FROM direction a)
+    # right/through/left -> leaving TOWARDS direction
+    out_dir = {'N': ('W', 'S', 'E'), 'E': ('N', 'W', 'S'),
+               'S': ('E', 'N', 'W'), 'W': ('S', 'E', 'N')}
+
+    def in_edge(n, a):
+        return '%s_%s' % (nbr(n, a), n)
+
+    def out_edge(n, a, mv):
+        return '%s_%s' % (n, nbr(n, out_dir[a][mv]))
+
+    def approach_of(edge):
+        fr, to = edges[edge][0], edges[edge][1]
+        for a in _APPROACH:
+            if nbr(to, a) == fr:
+                return a
+        raise KeyError(edge)
+
+    # ---- routing: lexicographic (free-flow time, #turns), tie -> through, right, left
+    demand = large_grid_demand(peak_flow1, peak_flow2)
+    route_names: List[Tuple[str, str]] = []
+    for e1, e2, *_ in demand:
+        if (e1, e2) not in route_names:
+            route_names.append((e1, e2))
+    NR = len(route_names)
+    tcost = {e: Fraction(int(v[4] * 1000), int(v[3] * 1000)) for e, v in edges.items()}
+    next_mv: Dict[Tuple[str, int], int] = {}
+    for r, (_, dst) in enumerate(route_names):
+        INF = (Fraction(10 ** 9), 10 ** 9)
+        dist = {e: INF for e in edges}
+        dist[dst] = (Fraction(0), 0)
+        changed = True
+        while changed:                                   # Bellman-Ford on 140 edges
+            changed = False
+            for e, v in edges.items():
+                if e == dst or not v[1].startswith('nt'):
+                    continue
+                a = approach_of(e)
+                best = dist[e]
+                for mv in (_THROUGH, _RIGHT, _LEFT):
+                    e2 = out_edge(v[1], a, mv)
+                    d2 = dist[e2]
+                    if d2 == INF:
+                        continue
+                    cand = (d2[0] + tcost[e2], d2[1] + (0 if mv == _THROUGH else 1))
+                    if cand < best:
+                        best = cand
+                if best < dist[e]:
+                    dist[e] = best
+                    changed = True
+        for e, v in edges.items():
+            if e == dst or not v[1].startswith('nt') or dist[e] == INF:
+                continue
+            a = approach_of(e)
+            for mv in (_THROUGH, _RIGHT, _LEFT):         # tie-break order
+                e2 = out_edge(v[1], a, mv)
+                if dist[e2] == INF:
+                    continue
+                if (dist[e2][0] + tcost[e2], dist[e2][1] + (0 if mv == _THROUGH else 1)) == dist[e]:
+                    next_mv[(e, r)] = mv
+                    break
+
+    # ---- lanes: 6 incoming per agent in ild order [N_0,E_0,E_1,S_0,W_0,W_1], then exit lanes
+    lane_names: List[str] = []
+    lane_id: Dict[str, int] = {}
+    agent_lanes = np.full((N * N, 6), -1, np.int32)
+    link_lane = np.full((N * N, 12), -1, np.int32)
+    for a_i, n in enumerate(node_names):
+        k = 0
+        for ai, a in enumerate(_APPROACH):
+            e = in_edge(n, a)
+            for ln in range(edges[e][2]):
+                nm = '%s_%d' % (e, ln)
+                lane_id[nm] = len(lane_names)
+                lane_names.append(nm)
+                agent_lanes[a_i, k] = lane_id[nm]
+                k += 1
+            # SUMO link order inside an approach: right, through (lane 0), left (leftmost lane)
+            link_lane[a_i, 3 * ai + _RIGHT] = lane_id['%s_0' % e]
+            link_lane[a_i, 3 * ai + _THROUGH] = lane_id['%s_0' % e]
+            link_lane[a_i, 3 * ai + _LEFT] = lane_id['%s_%d' % (e, edges[e][2] - 1)]
+    for e, v in edges.items():
+        if v[1].startswith('np'):
+            for ln in range(v[2]):
+                nm = '%s_%d' % (e, ln)
+                lane_id[nm] = len(lane_names)
+                lane_names.append(nm)
+    NL = len(lane_names)
+    lane_edge = [nm.rsplit('_', 1)[0] for nm in lane_names]
+    lane_k = [int(nm.rsplit('_', 1)[1]) for nm in lane_names]
+    lane_len = np.array([edges[e][4] for e in lane_edge], np.float32)
+    lane_vmax = np.array([edges[e][3] for e in lane_edge], np.float32)
+    lane_node = np.array([aidx.get(edges[e][1], -1) for e in lane_edge], np.int32)
+    lane_det = np.where(lane_node >= 0, lane_len - DET_LEN, 0).astype(np.float32)
+
+    def lane_choice(edge, r, via_mv, from_street):
+        """Lane a vehicle of route r takes when it enters `edge` (DESIGN.md
+        'lane choice at edge entry').  On the arrival edge the lane follows the
+        reference's connection table (build_file.py:107-124)."""
+        if edges[edge][2] == 1:
+            return 0
+        m = next_mv.get((edge, r))
+        if m is None:                                   # arrival edge
+            return 1 if (via_mv == _LEFT and not from_street) else 0
+        return 1 if m == _LEFT else 0
+
+    mv_next = np.full((NL, NR), -2, np.int32)
+    mv_link = np.full((NL, NR), -1, np.int32)
+    for l in range(NL):
+        e = lane_edge[l]
+        fr, to, nl, _, _ = edges[e]
+        for r, (_, dst) in enumerate(route_names):
+            if e == dst:
+                mv_next[l, r] = -1
+                continue
+            m = next_mv.get((e, r))
+            if m is None or not to.startswith('nt'):
+                continue
+            if nl == 2 and ((m == _LEFT) != (lane_k[l] == 1)):
+                continue                                # lane does not serve that movement
+            a = approach_of(e)
+            e2 = out_edge(to, a, m)
+            k2 = lane_choice(e2, r, m, nl == 2)
+            mv_next[l, r] = lane_id['%s_%d' % (e2, k2)]
+            mv_link[l, r] = 3 * _APPROACH.index(a) + m
+    route_entry = np.array([lane_id['%s_%d' % (src, lane_choice(src, r, None, False))]
+                            for r, (src, _) in enumerate(route_names)], np.int32)
+
+    lane_up = np.full((NL, MAX_UP), -1, np.int32)
+    for l2 in range(NL):
+        ups = sorted({l for l in range(NL) if (mv_next[l] == l2).any()})
+        assert len(ups) <= MAX_UP
+        lane_up[l2, :len(ups)] = ups
+
+    opp = {'N': 'S', 'S': 'N', 'E': 'W', 'W': 'E'}
+    lane_opp = np.full(NL, -1, np.int32)
+    for l in range(NL):
+        e = lane_edge[l]
+        if lane_node[l] < 0:
+            continue
+        to = edges[e][1]
+        serves_left = edges[e][2] == 1 or lane_k[l] == 1
+        if serves_left:
+            lane_opp[l] = lane_id['%s_0' % in_edge(to, opp[approach_of(e)])]
+
+    nmap = large_grid_neighbor_map()
+    neighbors = [[aidx[j] for j in nmap[n]] for n in node_names]
+    n_a_ls = [len(LARGE_GRID_PHASES)] * (N * N)
+    nlane = [6] * (N * N)
+    n_s, n_w, n_f = _state_dims(agent, nlane, n_a_ls, neighbors, True)
+    obs_kind, obs_src, lens = _obs_table(agent, agent_lanes, nlane, n_a_ls, neighbors, True, 5)
+    if agent not in ('greedy', 'a2c'):
+        assert lens == n_s
+    green, yellow = _signal_tables([LARGE_GRID_PHASES] * (N * N), 12)
+
+    rid = {rn: i for i, rn in enumerate(route_names)}
+    flows = np.array([[tb, te, vph, rid[(e1, e2)]] for e1, e2, tb, te, vph in demand], np.int32)
+
+    return Scenario(
+        name='large_grid', agent=agent, node_names=node_names, n_agent=N * N,
+        lane_names=lane_names, lane_len=lane_len, lane_vmax=lane_vmax, lane_node=lane_node,
+        lane_det_start=lane_det, lane_opp=lane_opp, lane_up=lane_up,
+        n_route=NR, mv_next=mv_next, mv_link=mv_link, route_entry_lane=route_entry,
+        route_names=route_names,
+        agent_lanes=agent_lanes, agent_nlane=np.array(nlane, np.int32),
+        agent_nlink=np.full(N * N, 12, np.int32), agent_nphase=np.array(n_a_ls, np.int32),
+        link_lane=link_lane, phases=[LARGE_GRID_PHASES] * (N * N),
+        green_tab=green, yellow_tab=yellow,
+        neighbors=neighbors, n_s_ls=n_s, n_w_ls=n_w, n_f_ls=n_f, n_a_ls=n_a_ls,
+        obs_kind=obs_kind, obs_src=obs_src, flows=flows,
+        extra={'peak_flow1': peak_flow1, 'peak_flow2': peak_flow2, 'demand': demand},
+        **env_kw)
+
+
+def build_scenario(name: str, agent: str = 'ma2c', **kw) -> Scenario:
+    if name == 'large_grid':
+        return build_large_grid(agent, **kw)
+    raise ValueError('unknown scenario %r (large_grid is built in; real_net comes from '
+                     'tools/compile_real_net.py tables)' % name)

@@ -1,0 +1,222 @@
+"""Fake TraCI backend over the CPU microsim -- TEST INFRASTRUCTURE ONLY.
+
+Purpose: run the reference's env classes (envs/env.py, envs/large_grid_env.py)
+UNMODIFIED so that everything the reference itself computes on top of the
+simulator -- phase/yellow FSM (env.py:128-152), detector read-out and
+normalisation (:369-407,:439-442), observation assembly (:163-205), reward
+(:325-367) and reward shaping (:590-631) -- is pinned by the reference's own
+code.  The vehicle dynamics underneath are oracle/microsim.c (our spec, SUMO is
+not available: see the header of that file).
+
+The complete TraCI surface the reference touches is listed in SURVEY.md §8b;
+each method below cites its call site in envs/env.py.
+
+Usage (only works where /root/reference exists, i.e. in the build container):
+
+    from oracle.fake_traci import ref_env
+    env = ref_env('large_grid', 'ma2c')     # a real envs.large_grid_env.LargeGridEnv
+"""
+import configparser
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+from oracle.microsim import MicroSim
+
+REFERENCE_ROOT = '/root/reference'
+_PENDING = {}          # port -> dict(seed=..)  filled by the fake subprocess.Popen
+
+
+class _TrafficLight:
+    def __init__(self, c):
+        self.c = c
+
+    def getIDList(self):                               # env.py:209
+        return list(self.c.tl_ids)
+
+    def getControlledLanes(self, node):                # env.py:219
+        a = self.c.aidx[node]
+        scn = self.c.scn
+        return [scn.lane_names[l] for l in scn.link_lane[a, :scn.agent_nlink[a]]]
+
+    def setRedYellowGreenState(self, node, phase):     # env.py:458
+        self.c.ms.set_links(self.c.aidx[node], phase)
+        self.c.phase_log.append((self.c.ms.time, node, phase))
+
+    def setPhaseDuration(self, node, dur):             # env.py:459
+        pass
+
+    def getRedYellowGreenState(self, node):            # env.py:115
+        return self.c.last_phase.get(node, '')
+
+
+class _Detector:
+    """lanearea.* (grids: detector = last 50 m) and lane.* (whole lane)."""
+
+    def __init__(self, c, whole_lane):
+        self.c = c
+        self.whole = whole_lane
+
+    def _start(self, lane):
+        return 0.0 if self.whole else float(self.c.scn.lane_len[lane] - 50.0)
+
+    def getLastStepVehicleNumber(self, ild):           # env.py:377,379
+        l = self.c.lidx[ild]
+        return self.c.ms.lane_stats(l, self._start(l))[0]
+
+    def getLastStepHaltingNumber(self, ild):           # env.py:333,335,425
+        l = self.c.lidx[ild]
+        return self.c.ms.lane_stats(l, self._start(l))[1]
+
+    def getLastStepVehicleIDs(self, ild):              # env.py:341,343,388,390
+        l = self.c.lidx[ild]
+        d = self.c.ms.lane_vehicles(l)
+        return ['%d:%d' % (l, i) for i in range(d['n']) if d['x'][i] >= np.float32(self._start(l))]
+
+    def getLength(self, ild):
+        return float(self.c.scn.lane_len[self.c.lidx[ild]])
+
+
+class _Vehicle:
+    def __init__(self, c):
+        self.c = c
+
+    def _get(self, vid):
+        l, i = (int(t) for t in vid.split(':'))
+        return self.c.ms.lane_vehicles(l), i
+
+    def getLanePosition(self, vid):                    # env.py:345,392
+        d, i = self._get(vid)
+        return float(d['x'][i])
+
+    def getWaitingTime(self, vid):                     # env.py:348,395,415
+        d, i = self._get(vid)
+        return float(d['w'][i])
+
+    def getSpeed(self, vid):                           # env.py:416
+        d, i = self._get(vid)
+        return float(d['v'][i])
+
+    def getIDList(self):                               # env.py:410
+        out = []
+        for l in range(self.c.scn.n_lane):
+            out += ['%d:%d' % (l, i) for i in range(self.c.ms.lane_vehicles(l)['n'])]
+        return out
+
+
+class _Simulation:
+    def __init__(self, c):
+        self.c = c
+
+    def getDepartedNumber(self):                       # env.py:412
+        return self.c.ms.totals()['step_departed']
+
+    def getArrivedNumber(self):                        # env.py:413
+        return self.c.ms.totals()['step_arrived']
+
+
+class Connection:
+    def __init__(self, scn, seed):
+        self.scn = scn
+        self.ms = MicroSim(scn)
+        self.ms.reset(seed)
+        self.tl_ids = list(scn.node_names)
+        self.aidx = {n: i for i, n in enumerate(scn.node_names)}
+        self.lidx = {n: i for i, n in enumerate(scn.lane_names)}
+        self.phase_log = []
+        self.last_phase = {}
+        self.trafficlight = _TrafficLight(self)
+        self.lanearea = _Detector(self, False)
+        self.lane = _Detector(self, True)
+        self.vehicle = _Vehicle(self)
+        self.simulation = _Simulation(self)
+
+    def simulationStep(self):                          # env.py:464
+        self.ms.step()
+
+    def close(self):                                   # env.py:564
+        pass
+
+
+_SCN_FOR_CONNECT = {}
+
+
+def install(scn):
+    """Install stub modules so the reference imports resolve, and route
+    traci.connect() to a Connection over `scn`."""
+    traci = types.ModuleType('traci')
+
+    def connect(port=0, **_kw):
+        seed = _PENDING.pop(port, {}).get('seed', 0)
+        c = Connection(_SCN_FOR_CONNECT['scn'], seed)
+        _SCN_FOR_CONNECT['last'] = c
+        return c
+    traci.connect = connect
+    sumolib = types.ModuleType('sumolib')
+    sumolib.checkBinary = lambda app: '/bin/true'
+    seaborn = types.ModuleType('seaborn')
+    seaborn.set_color_codes = lambda *a, **k: None
+    tf = types.ModuleType('tensorflow')
+    tf.nn = types.SimpleNamespace(relu=None, softmax=None, sigmoid=None)
+    tf.tanh = None
+    sys.modules.setdefault('traci', traci)
+    sys.modules['traci'].connect = connect
+    sys.modules.setdefault('sumolib', sumolib)
+    sys.modules.setdefault('seaborn', seaborn)
+    sys.modules.setdefault('tensorflow', tf)
+    _SCN_FOR_CONNECT['scn'] = scn
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    # env.py:291-293: Popen(sumo ...) + sleep(2) -> record --seed / --remote-port instead
+    import subprocess
+    import time
+    import envs.env as ref_env_mod
+
+    class _FakePopen:
+        def __init__(self, cmd, *a, **k):
+            port = int(cmd[cmd.index('--remote-port') + 1])
+            _PENDING[port] = {'seed': int(cmd[cmd.index('--seed') + 1])}
+    ref_env_mod.subprocess = types.SimpleNamespace(Popen=_FakePopen, check_call=subprocess.check_call)
+    ref_env_mod.time = types.SimpleNamespace(sleep=lambda s: None, time=time.time)
+    if not hasattr(np, 'bool'):
+        np.bool = bool                                  # agents/utils.py:226 uses np.bool
+    return ref_env_mod
+
+
+def ref_config(scenario, agent, config_name=None):
+    """The reference's own INI for (scenario, agent), data_path redirected to a tmp dir."""
+    name = config_name or {('large_grid', 'ma2c'): 'config_ma2c_large.ini',
+                           ('large_grid', 'ia2c'): 'config_ia2c_large.ini',
+                           ('large_grid', 'greedy'): 'config_test_large.ini',
+                           ('large_grid', 'iqll'): 'config_iqll_large.ini',
+                           ('real_net', 'ma2c'): 'config_ma2c_real.ini',
+                           ('real_net', 'ia2c'): 'config_ia2c_real.ini'}[(scenario, agent)]
+    cfg = configparser.ConfigParser()
+    cfg.read(os.path.join(REFERENCE_ROOT, 'config', name))
+    tmp = tempfile.mkdtemp(prefix='tsc_ref_') + '/'
+    if scenario == 'real_net':
+        os.makedirs(tmp + 'in', exist_ok=True)
+    cfg['ENV_CONFIG']['data_path'] = tmp
+    return cfg
+
+
+def ref_env(scenario, agent, scn=None, config=None):
+    """Construct the reference's env class (unmodified) over the fake backend."""
+    from deeprl_signal_control_amd.scenario import build_scenario
+    cfg = config or ref_config(scenario, agent)
+    if scn is None:
+        scn = build_scenario(scenario, agent)
+    install(scn)
+    if scenario == 'large_grid':
+        from envs.large_grid_env import LargeGridEnv
+        env = LargeGridEnv(cfg['ENV_CONFIG'])
+    elif scenario == 'real_net':
+        from envs.real_net_env import RealNetEnv
+        env = RealNetEnv(cfg['ENV_CONFIG'])
+    else:
+        raise ValueError(scenario)
+    env._tsc_cfg = cfg
+    return env

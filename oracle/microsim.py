@@ -1,0 +1,130 @@
+"""ctypes binding of oracle/libmicrosim.so (the CPU restatement of the microsim
+spec, oracle/microsim.c).  TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, 'libmicrosim.so')
+    src = os.path.join(_HERE, 'microsim.c')
+    if force or not os.path.exists(so) or (os.path.exists(src) and
+                                           os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(['make', '-C', _HERE, '-B', 'libmicrosim.so'],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        L.ms_create.restype = C.c_void_p
+        L.ms_create.argtypes = [C.c_int] * 7 + [fp, fp, ip, ip, ip, ip, ip, ip, ip]
+        L.ms_destroy.argtypes = [C.c_void_p]
+        L.ms_reset.argtypes = [C.c_void_p, C.c_uint32]
+        L.ms_set_links.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
+        L.ms_step.argtypes = [C.c_void_p]
+        L.ms_run.argtypes = [C.c_void_p, C.c_int]
+        L.ms_lane_stats.argtypes = [C.c_void_p, C.c_int, C.c_float, ip, ip, ip]
+        L.ms_lane_count.argtypes = [C.c_void_p, C.c_int]
+        L.ms_lane_vehicles.argtypes = [C.c_void_p, C.c_int, fp, fp, ip, ip, ip, fp]
+        L.ms_time.argtypes = [C.c_void_p]
+        L.ms_totals.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.ms_check.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _f(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, np.int32)
+
+
+class MicroSim:
+    """One env instance of the CPU microsim over a compiled Scenario."""
+
+    def __init__(self, scn, cap=None):
+        from deeprl_signal_control_amd.scenario import LANE_CAP
+        self.scn = scn
+        self.cap = cap or LANE_CAP
+        L = lib()
+        self._keep = [_f(scn.lane_len), _f(scn.lane_vmax), _i(scn.lane_node), _i(scn.lane_opp),
+                      _i(scn.lane_up), _i(scn.mv_next), _i(scn.mv_link), _i(scn.route_entry_lane),
+                      _i(scn.flows)]
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        ptrs = [a.ctypes.data_as(fp if a.dtype == np.float32 else ip) for a in self._keep]
+        self.kmax = int(scn.green_tab.shape[2])
+        self.h = L.ms_create(scn.n_lane, scn.n_route, scn.n_agent, self.kmax, self.cap,
+                             len(scn.flows), scn.teleport_sec, *ptrs)
+        self.L = L
+
+    def __del__(self):
+        if getattr(self, 'h', None):
+            self.L.ms_destroy(self.h)
+            self.h = None
+
+    def reset(self, seed):
+        self.L.ms_reset(self.h, int(seed) & 0xFFFFFFFF)
+
+    def set_links(self, agent, chars):
+        if isinstance(chars, str):
+            chars = chars.encode()
+        self.L.ms_set_links(self.h, agent, bytes(chars), len(chars))
+
+    def step(self, n=1):
+        self.L.ms_run(self.h, n)
+
+    def lane_stats(self, lane, det_start=None):
+        if det_start is None:
+            det_start = float(self.scn.lane_det_start[lane])
+        w, h, hw = C.c_int32(), C.c_int32(), C.c_int32()
+        self.L.ms_lane_stats(self.h, lane, det_start, C.byref(w), C.byref(h), C.byref(hw))
+        return w.value, h.value, hw.value
+
+    def lane_vehicles(self, lane):
+        n = self.L.ms_lane_count(self.h, lane)
+        x = np.zeros(self.cap, np.float32); v = np.zeros(self.cap, np.float32)
+        sf = np.zeros(self.cap, np.float32)
+        w = np.zeros(self.cap, np.int32); r = np.zeros(self.cap, np.int32); i = np.zeros(self.cap, np.int32)
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        self.L.ms_lane_vehicles(self.h, lane, x.ctypes.data_as(fp), v.ctypes.data_as(fp),
+                                w.ctypes.data_as(ip), r.ctypes.data_as(ip), i.ctypes.data_as(ip),
+                                sf.ctypes.data_as(fp))
+        return dict(n=n, x=x[:n], v=v[:n], w=w[:n], r=r[:n], id=i[:n], sf=sf[:n])
+
+    def snapshot(self):
+        """Dense [NL, CAP] arrays (x, v, sf, w, r) + counts, for state-level parity checks."""
+        NL, CAP = self.scn.n_lane, self.cap
+        out = dict(n=np.zeros(NL, np.int32), x=np.zeros((NL, CAP), np.float32),
+                   v=np.zeros((NL, CAP), np.float32), sf=np.zeros((NL, CAP), np.float32),
+                   w=np.zeros((NL, CAP), np.int32), r=np.zeros((NL, CAP), np.int32))
+        for l in range(NL):
+            d = self.lane_vehicles(l)
+            k = d['n']
+            out['n'][l] = k
+            for key in ('x', 'v', 'sf', 'w', 'r'):
+                out[key][l, :k] = d[key]
+        return out
+
+    @property
+    def time(self):
+        return self.L.ms_time(self.h)
+
+    def totals(self):
+        out = (C.c_int64 * 8)()
+        self.L.ms_totals(self.h, out)
+        return dict(live=out[0], departed=out[1], arrived=out[2], sum_trip=out[3], pending=out[4],
+                    step_departed=out[5], step_arrived=out[6])
+
+    def check(self):
+        return self.L.ms_check(self.h)

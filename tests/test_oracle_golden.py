@@ -1,0 +1,100 @@
+"""Pin the oracle restatement (oracle/env_oracle.py + oracle/microsim.c) against
+fixtures recorded from the REFERENCE's own env classes (tools/make_golden.py ran
+/root/reference/envs/large_grid_env.py unmodified over oracle/fake_traci.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from deeprl_signal_control_amd.scenario import build_large_grid, yellow_phase, LARGE_GRID_PHASES
+from oracle.env_oracle import OracleEnv, numpy_pairwise_sum
+
+
+def _replay(env, g, prefix='', test_ind=None):
+    acts, pols = g[prefix + 'actions'], g[prefix + 'policies']
+    ob = env.reset() if test_ind is None else env.reset(test_ind=test_ind)
+    np.testing.assert_array_equal(np.concatenate(ob), g[prefix + 'obs'][0])
+    for t in range(len(acts)):
+        if env.agent == 'ma2c':
+            env.update_fingerprint(list(pols[t]))
+        ob, r, done, gr = env.step(list(acts[t]))
+        np.testing.assert_array_equal(np.concatenate(ob), g[prefix + 'obs'][t + 1], err_msg='obs t=%d' % t)
+        np.testing.assert_array_equal(np.asarray(r, np.float64), g[prefix + 'reward'][t], err_msg='reward t=%d' % t)
+        assert gr == g[prefix + 'global_reward'][t]
+        assert bool(done) == bool(g[prefix + 'done'][t])
+
+
+def test_static_tables(golden_dir):
+    st = json.load(open(os.path.join(golden_dir, 'large_grid_static.json')))
+    scn = build_large_grid('ma2c')
+    assert scn.node_names == st['node_names']
+    assert scn.n_s_ls == st['n_s_ls'] and scn.n_a_ls == st['n_a_ls']
+    assert scn.n_w_ls == st['n_w_ls'] and scn.n_f_ls == st['n_f_ls']
+    assert build_large_grid('ia2c').n_s_ls == st['ia2c_n_s_ls']
+    for a, n in enumerate(scn.node_names):
+        assert [scn.node_names[j] for j in scn.neighbors[a]] == st['neighbors'][n]
+        assert [scn.lane_names[l] for l in scn.agent_lanes[a]] == st['ilds_in'][n]
+        assert [scn.lane_names[l] for l in scn.link_lane[a]] == st['lanes_in'][n]
+    for p in range(5):
+        assert bytes(scn.green_tab[0, p]).decode() == st['green'][p]
+        for q in range(5):
+            assert bytes(scn.yellow_tab[0, p, q]).decode() == st['yellow']['%d->%d' % (p, q)]
+            if p != q:
+                assert yellow_phase(LARGE_GRID_PHASES[p], LARGE_GRID_PHASES[q]) == st['yellow']['%d->%d' % (p, q)]
+    flows = [[e1, e2, b, e, v] for (e1, e2, b, e, v) in scn.extra['demand']]
+    assert flows == st['flows']                       # 84 elements incl. the %d truncation (461)
+    assert len(flows) == 84
+
+
+def test_ma2c_full_episode_and_reseed(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'large_grid_ma2c.npz'))
+    env = OracleEnv(build_large_grid('ma2c'), seed=12)
+    _replay(env, g, 'ep1_')
+    assert g['ep1_done'][-1] and len(g['ep1_done']) == 720
+    _replay(env, g, 'ep2_')                            # second reset: seed 13 (env.py:560)
+
+
+def test_ia2c_global_reward_broadcast(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'large_grid_ia2c.npz'))
+    _replay(OracleEnv(build_large_grid('ia2c'), seed=12), g)
+
+
+def test_ma2c_test_mode_local_rewards(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'large_grid_ma2c_test.npz'))
+    env = OracleEnv(build_large_grid('ma2c'), seed=12, test_seeds=(10000, 20000), train_mode=False)
+    _replay(env, g, test_ind=1)
+
+
+def test_greedy_state(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'large_grid_greedy.npz'))
+    scn = build_large_grid('greedy', norm_wave=1.0, norm_wait=1.0, clip_wave=1000.0, clip_wait=1000.0,
+                           coop_gamma=0.75)
+    env = OracleEnv(scn, seed=42, test_seeds=(10000, 20000, 30000), train_mode=False)
+    _replay(env, g, test_ind=0)
+
+
+def test_numpy_sum_order():
+    rng = np.random.RandomState(0)
+    for n in (2, 6, 25, 28):
+        for _ in range(300):
+            a = -(rng.randint(0, 40, n) + 0.2 * rng.randint(0, 300, n)).astype(np.float64)
+            assert numpy_pairwise_sum(a) == np.sum(a)
+
+
+def test_microsim_invariants():
+    """Spacing >= vehicle length, positions inside the lane, conservation of vehicles."""
+    from oracle.microsim import MicroSim
+    scn = build_large_grid('ma2c')
+    m = MicroSim(scn)
+    m.reset(3)
+    rng = np.random.RandomState(0)
+    for t in range(1500):
+        if t % 5 == 0:
+            for a in range(25):
+                m.set_links(a, scn.phases[a][rng.randint(5)])
+        m.step()
+        assert m.check() == 0
+    tot = m.totals()
+    assert tot['departed'] == tot['arrived'] + tot['live']
+    assert tot['live'] > 100
