@@ -1,0 +1,110 @@
+"""ctypes loader for the C-ABI library (include/tsc.h).  There is no CPU fallback: if
+libtsc.so is missing or fails to load, importing the product path raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libtsc.so')
+
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+_bp = C.POINTER(C.c_uint8)
+
+
+class TscScenario(C.Structure):
+    _fields_ = [
+        ('n_lane', C.c_int32), ('n_route', C.c_int32), ('n_agent', C.c_int32), ('n_flow', C.c_int32),
+        ('k_max', C.c_int32), ('p_max', C.c_int32), ('l_max', C.c_int32), ('s_max', C.c_int32),
+        ('nbr_max', C.c_int32),
+        ('lane_len', _fp), ('lane_vmax', _fp), ('lane_det_start', _fp),
+        ('lane_node', _ip), ('lane_opp', _ip), ('lane_up', _ip),
+        ('mv_next', _ip), ('mv_link', _ip), ('route_entry', _ip), ('flows', _ip),
+        ('agent_lanes', _ip), ('agent_nlane', _ip), ('agent_nlink', _ip), ('agent_nphase', _ip),
+        ('green_tab', _bp), ('yellow_tab', _bp),
+        ('nbr', _ip), ('obs_kind', _ip), ('obs_src', _ip),
+        ('control_interval_sec', C.c_int32), ('yellow_interval_sec', C.c_int32),
+        ('episode_length_sec', C.c_int32), ('teleport_sec', C.c_int32),
+        ('queue_cap', C.c_int32), ('objective', C.c_int32), ('agent_kind', C.c_int32),
+        ('realnet_scale', C.c_int32),
+        ('coop_gamma', C.c_double), ('norm_wave', C.c_double), ('norm_wait', C.c_double),
+        ('clip_wave', C.c_double), ('clip_wait', C.c_double), ('coef_wait', C.c_double),
+    ]
+
+
+_LIB = None
+
+# every symbol include/tsc.h declares (tests/test_abi.py checks the header against this list)
+SYMBOLS = ['tsc_last_error', 'tsc_version', 'tsc_env_create', 'tsc_env_destroy', 'tsc_env_set_stream',
+           'tsc_env_reset', 'tsc_env_set_fingerprint', 'tsc_env_step', 'tsc_env_get_state',
+           'tsc_env_live_vehicles']
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('deeprl_signal_control_amd: %s not built -- run `python -c "import __graft_entry__ as g; '
+                           'g.build()"` (hipcc, gfx950). There is no CPU fallback.' % LIB_PATH)
+    # torch ships its own HIP runtime (torch/lib/libamdhip64.so, same soname as /opt/rocm's); it must be
+    # the one in the process, so load it first and let libtsc.so bind to it.
+    import torch  # noqa: F401
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.tsc_last_error.restype = C.c_char_p
+    L.tsc_env_create.argtypes = [C.POINTER(TscScenario), C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.tsc_env_destroy.argtypes = [vp]
+    L.tsc_env_set_stream.argtypes = [vp, vp]
+    L.tsc_env_reset.argtypes = [vp, C.POINTER(C.c_uint32), vp]
+    L.tsc_env_set_fingerprint.argtypes = [vp, vp]
+    L.tsc_env_step.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int32]
+    L.tsc_env_get_state.argtypes = [vp, C.c_int32, _ip, _fp, _fp, _fp, _ip, _ip, _ip, _ip, _ip]
+    L.tsc_env_live_vehicles.argtypes = [vp, C.POINTER(C.c_double)]
+    _LIB = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError('libtsc: ' + lib().tsc_last_error().decode())
+
+
+def scenario_struct(scn):
+    """Pack a scenario.Scenario into the C struct; returns (struct, keepalive list)."""
+    keep = []
+
+    def arr(a, dt, ptr):
+        a = np.ascontiguousarray(a, dt)
+        keep.append(a)
+        return a.ctypes.data_as(ptr)
+
+    A = scn.n_agent
+    nbr_max = max(1, max(len(n) for n in scn.neighbors))
+    nbr = np.full((A, nbr_max), -1, np.int32)
+    for a, ns in enumerate(scn.neighbors):
+        nbr[a, :len(ns)] = ns
+    agent_kind = {'greedy': 0, 'a2c': 0, 'ma2c': 2}.get(scn.agent, 1)
+    s = TscScenario(
+        n_lane=scn.n_lane, n_route=scn.n_route, n_agent=A, n_flow=len(scn.flows),
+        k_max=scn.green_tab.shape[2], p_max=scn.green_tab.shape[1], l_max=scn.agent_lanes.shape[1],
+        s_max=scn.s_max, nbr_max=nbr_max,
+        lane_len=arr(scn.lane_len, np.float32, _fp), lane_vmax=arr(scn.lane_vmax, np.float32, _fp),
+        lane_det_start=arr(scn.lane_det_start, np.float32, _fp),
+        lane_node=arr(scn.lane_node, np.int32, _ip), lane_opp=arr(scn.lane_opp, np.int32, _ip),
+        lane_up=arr(scn.lane_up, np.int32, _ip), mv_next=arr(scn.mv_next, np.int32, _ip),
+        mv_link=arr(scn.mv_link, np.int32, _ip), route_entry=arr(scn.route_entry_lane, np.int32, _ip),
+        flows=arr(scn.flows, np.int32, _ip), agent_lanes=arr(scn.agent_lanes, np.int32, _ip),
+        agent_nlane=arr(scn.agent_nlane, np.int32, _ip), agent_nlink=arr(scn.agent_nlink, np.int32, _ip),
+        agent_nphase=arr(scn.agent_nphase, np.int32, _ip),
+        green_tab=arr(scn.green_tab, np.uint8, _bp), yellow_tab=arr(scn.yellow_tab, np.uint8, _bp),
+        nbr=arr(nbr, np.int32, _ip), obs_kind=arr(scn.obs_kind, np.int32, _ip),
+        obs_src=arr(scn.obs_src, np.int32, _ip),
+        control_interval_sec=scn.control_interval_sec, yellow_interval_sec=scn.yellow_interval_sec,
+        episode_length_sec=scn.episode_length_sec, teleport_sec=scn.teleport_sec,
+        queue_cap=scn.queue_cap, objective={'queue': 0, 'wait': 1, 'hybrid': 2}[scn.objective],
+        agent_kind=agent_kind, realnet_scale=int(scn.reward_scale_realnet),
+        coop_gamma=scn.coop_gamma, norm_wave=scn.norm_wave, norm_wait=scn.norm_wait,
+        clip_wave=scn.clip_wave, clip_wait=scn.clip_wait, coef_wait=scn.coef_wait)
+    return s, keep

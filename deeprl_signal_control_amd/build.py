@@ -1,0 +1,42 @@
+"""Builds the C-ABI library (deeprl_signal_control_amd/libtsc.so) with hipcc for gfx950.
+
+In-tree on purpose: the built .so is git-ignored but travels to the GPU box with the repo
+snapshot.  -ffp-contract=off keeps one rounding per fp32 operation in the microsimulator
+(bit-exact vehicle state vs the CPU oracle); the MFMA kernels do not depend on contraction."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libtsc.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-ffp-contract=off',
+         '-fno-fast-math', '-Wall', '-Wno-unused-function']
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, '..', 'include', 'tsc.h')]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not stale():
+        return LIB
+    cmd = [HIPCC] + FLAGS + ['-I', os.path.join(HERE, '..', 'include'), '-o', LIB] + sources()
+    if verbose:
+        print(' '.join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv, verbose=True)
+    print(LIB)

@@ -1,0 +1,626 @@
+// tsc_env.hip -- batched traffic microsimulator + reference env semantics on gfx950.
+//
+// Replaces, for E parallel env instances, the reference's TrafficSimulator.step/reset
+// (envs/env.py:544-631) *including* the SUMO process behind its TraCI socket:
+//   K1 signal FSM ............ envs/env.py:128-152,455-459 (tables from scenario.py)
+//   K2 vehicle update ........ DESIGN.md "microsim spec" (IDM + safe-speed clamp, lane queues)
+//   K3 hand-off / insertion .. DESIGN.md "microsim spec" (feeder gather, vehsPerHour flows)
+//   K4 detectors ............. envs/env.py:325-407 (wave / halting / head-vehicle wait)
+//   K5 observation gather .... envs/env.py:163-205,439-442 (float64 arithmetic, cast to f32)
+//   K6 reward + shaping ...... envs/env.py:356-367,580,590-631 (float64, numpy sum order)
+//
+// Mapping: one workgroup per env instance, one thread per lane (lanes padded to a multiple of
+// 64 = NLP).  Vehicles live in HBM as slot-major SoA  X/V/SF/M[E][CAP][NLP]: slot i of all lanes
+// of one env is contiguous, so the per-lane front-to-back walk issues fully coalesced loads.
+// Everything lanes need from *other* lanes (tail/head summaries, signal states, the per-step
+// hand-off outbox, the route tables) is staged in LDS; one control step (2 yellow + 3 green
+// simulated seconds, detectors, obs, reward) is a single launch with 2 barriers per second.
+//
+// Arithmetic is fp32 with one rounding per operation (-ffp-contract=off, IEEE div/sqrt) so the
+// vehicle state is bit-identical to the CPU oracle; obs/reward are computed in float64 exactly
+// like the reference's NumPy code.
+#include "tsc_common.h"
+#include "../../include/tsc.h"
+
+#include <cmath>
+#include <vector>
+
+namespace {
+
+constexpr float kLen = 5.0f, kS0 = 2.5f, kAcc = 5.0f, kDec = 10.0f, kTHead = 1.5f;
+constexpr float kCab = 14.142136f, kHalt = 0.1f, kYieldT = 3.0f, kYieldD = 10.0f;
+constexpr int kCap = TSC_LANE_CAP, kMaxCross = TSC_MAX_CROSS, kMaxUp = TSC_MAX_UP;
+
+struct EnvDev {
+    int NL, NLP, NR, A, NF, KMAX, PMAX, LMAX, SMAX, NBR, E;
+    const float *lane_len, *lane_vmax, *lane_det;
+    const int *lane_node, *lane_opp, *lane_up;
+    const int *mv;                 // [NL*NR] packed: low16 = next lane (int16), high16 = link (int16)
+    const int *route_entry;        // [NR]
+    const int *flow_ptr;           // [NR+1] CSR over flows sorted by route
+    const int *flows;              // [NF*4] begin,end,vph,route (sorted by route, stable)
+    const int *agent_lanes, *agent_nlane, *agent_nlink, *agent_nphase;
+    const uint8_t *green_tab, *yellow_tab;
+    const int *nbr, *obs_kind, *obs_src;
+    int ctrl, yellow, episode, teleport, queue_cap, objective, agent_kind, realnet_scale;
+    double coop_gamma, norm_wave, norm_wait, clip_wave, clip_wait, coef_wait;
+    float *X, *V, *SF;
+    uint32_t *M;                   // w | route << 16
+    int *N;                        // [E][NLP]
+    int *pending, *serial;         // [E][NR]
+    int *tsec;
+    uint32_t *seed;
+    int *prev_action;              // [E][A]
+    float *fp;                     // [E][A][PMAX]
+    unsigned long long *arrived;   // [E]
+};
+
+__device__ __forceinline__ uint32_t hash32(uint32_t seed, uint32_t route, uint32_t serial, uint32_t stream) {
+    uint32_t h = seed * 0x9E3779B1u + route * 0x85EBCA77u + serial * 0xC2B2AE3Du + stream * 0x27D4EB2Fu;
+    h ^= h >> 16; h *= 0x85EBCA6Bu;
+    h ^= h >> 13; h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ float u01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
+
+// one car-following evaluation against one leader (DESIGN.md "follow")
+__device__ __forceinline__ float follow(float v, float v0, bool has_lead, float g, float vl, float s0gap) {
+    float ratio = v / v0;
+    float r2 = ratio * ratio;
+    float acc = kAcc * (1.0f - r2 * r2);
+    float vsafe = INFINITY;
+    if (has_lead) {
+        float sstar = (kS0 + v * kTHead) + (v * (v - vl)) / kCab;
+        if (sstar < kS0) sstar = kS0;
+        float s = g < 0.5f ? 0.5f : g;
+        float q = sstar / s;
+        acc = acc - kAcc * (q * q);
+        float gs = g - s0gap;
+        if (gs < 0.0f) gs = 0.0f;
+        vsafe = sqrtf((kDec * kDec + vl * vl) + (2.0f * kDec) * gs) - kDec;
+    }
+    if (acc < -kDec) acc = -kDec;
+    float vn = v + acc;
+    if (vn > vsafe) vn = vsafe;
+    if (vn > v0 && v <= v0) vn = v0;
+    if (vn < 0.0f) vn = 0.0f;
+    return vn;
+}
+
+__device__ __forceinline__ bool sig_open(int tl, int k, int a, int w, float x, float v, float L,
+                                         const uint8_t *link, int KMAX, int teleport) {
+    if (tl == -1) return true;
+    if (a < 0 || k < 0) return false;
+    if (w >= teleport) return true;
+    uint8_t st = link[a * KMAX + k];
+    if (st == 'G' || st == 'g') return true;
+    if (st == 'y') {
+        float need = (v * v) / (2.0f * kDec);
+        return (L - x) < need;
+    }
+    return false;
+}
+
+struct Smem {
+    int *mv;                                   // [NL*NR]
+    int *n; float *tx, *tv, *hx, *hv; uint32_t *hm;   // lane summaries [NLP]
+    float *ox, *ov, *osf; uint32_t *om; int *oto;     // outbox [kMaxCross*NLP]
+    int *nout;                                  // [NLP]
+    int *wave, *halt, *hwait;                   // detectors [NLP]
+    double *r;                                  // local rewards [A] (+1 for global)
+    uint8_t *link_y, *link_g;                   // [A*KMAX]
+};
+
+__device__ __forceinline__ Smem carve(char *base, const EnvDev &P) {
+    Smem s;
+    char *p = base;
+    auto take = [&](size_t bytes) { char *q = p; p += (bytes + 15) & ~size_t(15); return q; };
+    s.r = (double *)take(sizeof(double) * (P.A + 1));
+    s.mv = (int *)take(sizeof(int) * P.NL * P.NR);
+    s.n = (int *)take(4 * P.NLP); s.tx = (float *)take(4 * P.NLP); s.tv = (float *)take(4 * P.NLP);
+    s.hx = (float *)take(4 * P.NLP); s.hv = (float *)take(4 * P.NLP); s.hm = (uint32_t *)take(4 * P.NLP);
+    s.ox = (float *)take(4 * kMaxCross * P.NLP); s.ov = (float *)take(4 * kMaxCross * P.NLP);
+    s.osf = (float *)take(4 * kMaxCross * P.NLP); s.om = (uint32_t *)take(4 * kMaxCross * P.NLP);
+    s.oto = (int *)take(4 * kMaxCross * P.NLP);
+    s.nout = (int *)take(4 * P.NLP);
+    s.wave = (int *)take(4 * P.NLP); s.halt = (int *)take(4 * P.NLP); s.hwait = (int *)take(4 * P.NLP);
+    s.link_y = (uint8_t *)take(P.A * P.KMAX); s.link_g = (uint8_t *)take(P.A * P.KMAX);
+    return s;
+}
+
+size_t smem_bytes(const EnvDev &P) {
+    auto r16 = [](size_t b) { return (b + 15) & ~size_t(15); };
+    size_t t = r16(sizeof(double) * (P.A + 1)) + r16(sizeof(int) * P.NL * P.NR) + 6 * r16(4 * P.NLP) +
+               5 * r16(4 * kMaxCross * P.NLP) + 4 * r16(4 * P.NLP) + 2 * r16(P.A * P.KMAX);
+    return t;
+}
+
+// numpy's float64 pairwise sum for n <= 128 (np.sum at envs/env.py:580)
+__device__ double np_sum(const double *a, int n) {
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    double r[8];
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+
+__device__ __forceinline__ double norm_clip(double x, double norm, double clip) {
+    x = x / norm;                                   // envs/env.py:439-442
+    if (clip < 0) return x;
+    return fmin(fmax(x, 0.0), clip);
+}
+
+// K5: float32(state) for every agent of env e (envs/env.py:163-205)
+__device__ void emit_obs(const EnvDev &P, const Smem &s, int e, float *obs) {
+    const int tot = P.A * P.SMAX;
+    for (int idx = threadIdx.x; idx < tot; idx += blockDim.x) {
+        int kind = P.obs_kind[idx], src = P.obs_src[idx];
+        float o = 0.0f;
+        if (kind == 1) o = (float)norm_clip((double)s.wave[src], P.norm_wave, P.clip_wave);
+        else if (kind == 2) o = (float)(norm_clip((double)s.wave[src], P.norm_wave, P.clip_wave) * P.coop_gamma);
+        else if (kind == 3) o = (float)norm_clip((double)s.hwait[src], P.norm_wait, P.clip_wait);
+        else if (kind == 4) o = P.fp[(size_t)e * P.A * P.PMAX + src];
+        obs[(size_t)e * tot + idx] = o;
+    }
+}
+
+__global__ void reset_kernel(EnvDev P, const uint32_t *seeds, float *obs) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Smem s = carve(smem_raw, P);
+    const int e = blockIdx.x, l = threadIdx.x;
+    if (l < P.NLP) { P.N[(size_t)e * P.NLP + l] = 0; s.wave[l] = 0; s.hwait[l] = 0; }
+    for (int r = l; r < P.NR; r += blockDim.x) {
+        P.pending[(size_t)e * P.NR + r] = 0;
+        P.serial[(size_t)e * P.NR + r] = 0;
+    }
+    for (int a = l; a < P.A; a += blockDim.x) {
+        P.prev_action[(size_t)e * P.A + a] = 0;                    // envs/env.py:448
+        int na = P.agent_nphase[a];
+        float p = (float)(1.0 / (double)na);                       // envs/env.py:263-269
+        for (int k = 0; k < P.PMAX; ++k) P.fp[((size_t)e * P.A + a) * P.PMAX + k] = k < na - 1 ? p : 0.0f;
+    }
+    if (l == 0) { P.tsec[e] = 0; P.seed[e] = seeds[e]; P.arrived[e] = 0ull; }
+    __syncthreads();
+    emit_obs(P, s, e, obs);
+}
+
+__global__ void fingerprint_kernel(EnvDev P, const float *pi) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t tot = (size_t)P.E * P.A * P.PMAX;
+    if (i < tot) P.fp[i] = pi[i];                                  // pi[:-1] is applied at gather time
+}
+
+__global__ void __launch_bounds__(1024)
+step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, double *__restrict__ reward,
+            double *__restrict__ greward, uint8_t *__restrict__ done, int train_mode) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    Smem s = carve(smem_raw, P);
+    const int e = blockIdx.x, l = threadIdx.x, NLP = P.NLP, NR = P.NR;
+    const bool lane = l < P.NL;
+    float *X = P.X + (size_t)e * kCap * NLP, *V = P.V + (size_t)e * kCap * NLP, *SF = P.SF + (size_t)e * kCap * NLP;
+    uint32_t *M = P.M + (size_t)e * kCap * NLP;
+
+    // ---- K1: signal FSM (envs/env.py:128-152) -> link chars for the yellow and the green interval
+    for (int a = l; a < P.A; a += blockDim.x) {
+        int act = action[(size_t)e * P.A + a];
+        int prev = P.prev_action[(size_t)e * P.A + a];
+        P.prev_action[(size_t)e * P.A + a] = act;
+        const uint8_t *g = P.green_tab + ((size_t)a * P.PMAX + act) * P.KMAX;
+        const uint8_t *y = (prev < 0 || prev == act) ? g : P.yellow_tab + (((size_t)a * P.PMAX + prev) * P.PMAX + act) * P.KMAX;
+        for (int k = 0; k < P.KMAX; ++k) { s.link_y[a * P.KMAX + k] = y[k]; s.link_g[a * P.KMAX + k] = g[k]; }
+    }
+    for (int i = l; i < P.NL * NR; i += blockDim.x) s.mv[i] = P.mv[i];
+
+    // ---- per-lane constants and the initial lane summary
+    int n = 0, my_node = -1, my_opp = -1;
+    float L = 1.0f, vmax = 1.0f, det = 0.0f;
+    float hx = 0, hv = 0, tx = 0, tv = 0; uint32_t hm = 0;
+    if (lane) {
+        n = P.N[(size_t)e * NLP + l];
+        L = P.lane_len[l]; vmax = P.lane_vmax[l]; det = P.lane_det[l];
+        my_node = P.lane_node[l]; my_opp = P.lane_opp[l];
+        if (n > 0) { hx = X[l]; hv = V[l]; hm = M[l]; tx = X[(n - 1) * NLP + l]; tv = V[(n - 1) * NLP + l]; }
+    }
+    if (l < NLP) { s.n[l] = n; s.hx[l] = hx; s.hv[l] = hv; s.hm[l] = hm; s.tx[l] = tx; s.tv[l] = tv; }
+    int t = P.tsec[e];
+    const uint32_t seed = P.seed[e];
+    unsigned arrived = 0;
+    __syncthreads();
+
+    for (int sub = 0; sub < P.ctrl; ++sub, ++t) {
+        const uint8_t *link = sub < P.yellow ? s.link_y : s.link_g;
+        // ================= phase A (K2): advance own vehicles from the OLD state =================
+        int kept = 0, nsent = 0;
+        if (lane) {
+            int ncross = 0;
+            bool all_crossed = true;
+            float pnx = INFINITY, pox = 0.0f, pov = 0.0f;
+            for (int i = 0; i < n; ++i) {
+                const float x = X[i * NLP + l], v = V[i * NLP + l], sf = SF[i * NLP + l];
+                const uint32_t meta = M[i * NLP + l];
+                int w = (int)(meta & 0xFFFFu);
+                const int r = (int)(meta >> 16);
+                const float v0 = vmax * sf;
+                const int mvp = s.mv[l * NR + r];
+                const int tl = (int)(short)(mvp & 0xFFFF), k = (int)(short)(mvp >> 16);
+                const bool sink = tl == -1;
+                const bool open = sig_open(tl, k, my_node, w, x, v, L, link, P.KMAX, P.teleport);
+                bool can_cross = false;
+                if (all_crossed) {
+                    can_cross = open;
+                    if (can_cross && k >= 0 && k % 3 == 2 && w < P.teleport && my_opp >= 0 && s.n[my_opp] > 0) {
+                        // left turns yield to the opposing head going right / through
+                        const uint32_t om = s.hm[my_opp];
+                        const int mo = s.mv[my_opp * NR + (int)(om >> 16)];
+                        const int tlo = (int)(short)(mo & 0xFFFF), ko = (int)(short)(mo >> 16);
+                        if (ko >= 0 && ko % 3 != 2) {
+                            const float xo = s.hx[my_opp], vo = s.hv[my_opp], Lo = P.lane_len[my_opp];
+                            if (sig_open(tlo, ko, P.lane_node[my_opp], (int)(om & 0xFFFFu), xo, vo, Lo, link, P.KMAX, P.teleport)) {
+                                const float d = Lo - xo;
+                                if (d < vo * kYieldT + kYieldD) can_cross = false;
+                            }
+                        }
+                    }
+                    if (can_cross && tl >= 0 && s.n[tl] + kMaxCross > kCap) can_cross = false;
+                    if (can_cross && ncross >= kMaxCross) can_cross = false;
+                    if (tl < -1) can_cross = false;
+                }
+                const bool line_block = all_crossed ? !can_cross : !open;
+                const bool tgt_lead = can_cross && !sink && s.n[tl] > 0;
+                float vn;
+                if (i > 0) vn = follow(v, v0, true, (pox - kLen) - x, pov, kS0);
+                else if (tgt_lead) vn = follow(v, v0, true, (L - x) + (s.tx[tl] - kLen), s.tv[tl], kS0);
+                else vn = follow(v, v0, false, 0.0f, 0.0f, 0.0f);
+                if (line_block) {
+                    const float v2 = follow(v, v0, true, L - x, 0.0f, 0.0f);
+                    if (v2 < vn) vn = v2;
+                }
+                float xn = x + vn;
+                bool clamped = false;
+                if (xn > pnx - kLen) { xn = pnx - kLen; clamped = true; }
+                if (tgt_lead) {
+                    const float lim = L + (s.tx[tl] - kLen);
+                    if (xn > lim) { xn = lim; clamped = true; }
+                }
+                if (!can_cross && xn > L) { xn = L; clamped = true; }
+                if (xn < x) { xn = x; clamped = true; }
+                if (clamped) vn = xn - x;
+                w = (vn < kHalt) ? w + 1 : 0;
+                pnx = xn; pox = x; pov = v;
+                const uint32_t nmeta = (uint32_t)w | ((uint32_t)r << 16);
+                if (can_cross && xn >= L) {
+                    if (!sink) {
+                        const int o = nsent * NLP + l;
+                        s.ox[o] = xn - L; s.ov[o] = vn; s.osf[o] = sf; s.om[o] = nmeta; s.oto[o] = tl;
+                        ++nsent;
+                    } else {
+                        ++arrived;
+                    }
+                    ++ncross;
+                } else {
+                    all_crossed = false;
+                    const int o = kept * NLP + l;
+                    X[o] = xn; V[o] = vn; SF[o] = sf; M[o] = nmeta;
+                    if (kept == 0) { hx = xn; hv = vn; hm = nmeta; }
+                    tx = xn; tv = vn;
+                    ++kept;
+                }
+            }
+            s.nout[l] = nsent;
+        }
+        __syncthreads();
+        // ================= phase B (K3): gather hand-offs from feeder lanes, then demand =========
+        if (lane) {
+            n = kept;
+            for (int u = 0; u < kMaxUp; ++u) {
+                const int src = P.lane_up[l * kMaxUp + u];
+                if (src < 0) continue;
+                const int cnt = s.nout[src];
+                for (int j = 0; j < cnt; ++j) {
+                    const int o = j * NLP + src;
+                    if (s.oto[o] == l && n < kCap) {
+                        const int d = n * NLP + l;
+                        const float ax = s.ox[o], av = s.ov[o];
+                        const uint32_t am = s.om[o];
+                        X[d] = ax; V[d] = av; SF[d] = s.osf[o]; M[d] = am;
+                        if (n == 0) { hx = ax; hv = av; hm = am; }
+                        tx = ax; tv = av;
+                        ++n;
+                    }
+                }
+            }
+            for (int r = 0; r < NR; ++r) {
+                if (P.route_entry[r] != l) continue;
+                int pend = P.pending[(size_t)e * NR + r];
+                for (int f = P.flow_ptr[r]; f < P.flow_ptr[r + 1]; ++f) {
+                    const int b = P.flows[f * 4], en = P.flows[f * 4 + 1];
+                    if (t >= b && t < en) {
+                        const long long tau = t - b, vph = P.flows[f * 4 + 2];
+                        pend += (int)((((tau + 1) * vph + 3599) / 3600) - ((tau * vph + 3599) / 3600));
+                    }
+                }
+                if (pend > 0 && n < kCap) {
+                    const float xt = n > 0 ? tx : (L + kLen) + kS0;
+                    const float xmax = (xt - kLen) - kS0;
+                    if (!(xmax < kLen)) {
+                        const uint32_t ser = (uint32_t)P.serial[(size_t)e * NR + r];
+                        const float u0 = u01(hash32(seed, (uint32_t)r, ser, 0));
+                        const float u1 = u01(hash32(seed, (uint32_t)r, ser, 1));
+                        const float u2 = u01(hash32(seed, (uint32_t)r, ser, 2));
+                        const float ax = kLen + u0 * (xmax - kLen);
+                        const float asf = 1.0f + 0.2f * ((u1 + u2) - 1.0f);
+                        const uint32_t am = (uint32_t)r << 16;
+                        const int d = n * NLP + l;
+                        X[d] = ax; V[d] = 0.0f; SF[d] = asf; M[d] = am;
+                        if (n == 0) { hx = ax; hv = 0.0f; hm = am; }
+                        tx = ax; tv = 0.0f;
+                        ++n;
+                        --pend;
+                        P.serial[(size_t)e * NR + r] = (int)ser + 1;
+                    }
+                }
+                P.pending[(size_t)e * NR + r] = pend;
+            }
+            s.n[l] = n; s.hx[l] = hx; s.hv[l] = hv; s.hm[l] = hm; s.tx[l] = tx; s.tv[l] = tv;
+        }
+        __syncthreads();
+    }
+
+    // ---- K4: detectors (envs/env.py:325-407): wave, halting, wait of the front-most vehicle
+    if (lane) {
+        P.N[(size_t)e * NLP + l] = n;
+        int wave = 0, halt = 0, hw = 0;
+        for (int i = 0; i < n; ++i) {
+            const float x = X[i * NLP + l];
+            if (x >= det) {
+                ++wave;
+                if (V[i * NLP + l] < kHalt) ++halt;
+                if (i == 0 && x > 0.0f) hw = (int)(M[l] & 0xFFFFu);
+            }
+        }
+        s.wave[l] = wave; s.halt[l] = halt; s.hwait[l] = hw;
+    }
+    if (arrived) atomicAdd(&P.arrived[e], (unsigned long long)arrived);
+    if (l == 0) { P.tsec[e] = t; done[e] = t >= P.episode ? 1 : 0; }
+    __syncthreads();
+
+    // ---- K5: observations
+    emit_obs(P, s, e, obs);
+
+    // ---- K6: reward (envs/env.py:356-367) and shaping (:580,:590-631), float64
+    for (int a = l; a < P.A; a += blockDim.x) {
+        long long queue = 0;
+        double wsum = 0.0;
+        for (int k = 0; k < P.agent_nlane[a]; ++k) {
+            const int ln = P.agent_lanes[a * P.LMAX + k];
+            int q = s.halt[ln];
+            if (P.queue_cap >= 0 && q > P.queue_cap) q = P.queue_cap;
+            queue += q;
+            wsum += (double)s.hwait[ln];
+        }
+        double r;
+        if (P.objective == TSC_OBJ_QUEUE) r = (double)(-queue);
+        else if (P.objective == TSC_OBJ_WAIT) r = -wsum;
+        else r = (double)(-queue) - P.coef_wait * wsum;
+        s.r[a] = r;
+    }
+    __syncthreads();
+    if (l == 0) { double g = np_sum(s.r, P.A); s.r[P.A] = g; greward[e] = g; }
+    __syncthreads();
+    for (int a = l; a < P.A; a += blockDim.x) {
+        const double g = s.r[P.A];
+        double out;
+        if (!train_mode) {
+            out = s.r[a];
+        } else if (P.agent_kind == TSC_AGENT_GREEDY) {
+            out = g;
+        } else if (P.agent_kind == TSC_AGENT_GLOBAL) {
+            out = P.realnet_scale ? g / (double)(P.A * 20) : g;
+        } else {
+            double cur = s.r[a];
+            int deg = 0;
+            for (int j = 0; j < P.NBR; ++j) {
+                const int nb = P.nbr[a * P.NBR + j];
+                if (nb < 0) break;
+                cur += P.coop_gamma * s.r[nb];
+                ++deg;
+            }
+            out = P.realnet_scale ? cur / (double)((1 + deg) * 20) : cur;
+        }
+        reward[(size_t)e * P.A + a] = out;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+struct tsc_env {
+    EnvDev P;
+    int device;
+    hipStream_t stream;
+    std::vector<void *> allocs;
+    size_t smem;
+    uint32_t *d_seeds;
+};
+
+extern "C" {
+
+const char *tsc_last_error(void) { return tsc::err_buf(); }
+int tsc_version(void) { return 100; }
+
+#define UP(field, T, src, count)                                                 \
+    do {                                                                         \
+        T *d_ = nullptr;                                                         \
+        TSC_HIP(tsc::upload<T>(&d_, (const T *)(src), (size_t)(count)));         \
+        h->allocs.push_back(d_);                                                 \
+        P.field = d_;                                                            \
+    } while (0)
+#define ALLOC(field, T, count)                                                   \
+    do {                                                                         \
+        T *d_ = nullptr;                                                         \
+        TSC_HIP(hipMalloc((void **)&d_, sizeof(T) * (size_t)(count)));           \
+        TSC_HIP(hipMemset(d_, 0, sizeof(T) * (size_t)(count)));                  \
+        h->allocs.push_back(d_);                                                 \
+        P.field = d_;                                                            \
+    } while (0)
+
+int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_env **out) {
+    if (!sc || !out || n_env <= 0) return tsc::fail("tsc_env_create: bad arguments");
+    if (sc->n_lane > 1024) return tsc::fail("tsc_env_create: n_lane %d > 1024 unsupported", sc->n_lane);
+    if (sc->n_route > 255) return tsc::fail("tsc_env_create: n_route %d > 255 unsupported", sc->n_route);
+    TSC_HIP(hipSetDevice(device));
+    tsc_env *h = new tsc_env();
+    h->device = device;
+    h->stream = nullptr;
+    EnvDev &P = h->P;
+    P.NL = sc->n_lane; P.NLP = (sc->n_lane + 63) / 64 * 64; P.NR = sc->n_route; P.A = sc->n_agent;
+    P.NF = sc->n_flow; P.KMAX = sc->k_max; P.PMAX = sc->p_max; P.LMAX = sc->l_max; P.SMAX = sc->s_max;
+    P.NBR = sc->nbr_max; P.E = n_env;
+    P.ctrl = sc->control_interval_sec; P.yellow = sc->yellow_interval_sec; P.episode = sc->episode_length_sec;
+    P.teleport = sc->teleport_sec; P.queue_cap = sc->queue_cap; P.objective = sc->objective;
+    P.agent_kind = sc->agent_kind; P.realnet_scale = sc->realnet_scale;
+    P.coop_gamma = sc->coop_gamma; P.norm_wave = sc->norm_wave; P.norm_wait = sc->norm_wait;
+    P.clip_wave = sc->clip_wave; P.clip_wait = sc->clip_wait; P.coef_wait = sc->coef_wait;
+
+    const int NL = P.NL, NR = P.NR, A = P.A;
+    UP(lane_len, float, sc->lane_len, NL); UP(lane_vmax, float, sc->lane_vmax, NL);
+    UP(lane_det, float, sc->lane_det_start, NL);
+    UP(lane_node, int, sc->lane_node, NL); UP(lane_opp, int, sc->lane_opp, NL);
+    UP(lane_up, int, sc->lane_up, NL * kMaxUp);
+    std::vector<int> mv((size_t)NL * NR);
+    for (int i = 0; i < NL * NR; ++i) {
+        int nx = sc->mv_next[i], lk = sc->mv_link[i];
+        if (nx > 32767 || lk > 32767) return tsc::fail("tsc_env_create: table overflow");
+        mv[i] = (int)(((uint32_t)(uint16_t)(int16_t)nx) | ((uint32_t)(uint16_t)(int16_t)lk << 16));
+    }
+    UP(mv, int, mv.data(), NL * NR);
+    UP(route_entry, int, sc->route_entry, NR);
+    // flows sorted by route (stable) + CSR
+    std::vector<int> fl; std::vector<int> ptr(NR + 1, 0);
+    for (int r = 0; r < NR; ++r) {
+        ptr[r] = (int)fl.size() / 4;
+        for (int f = 0; f < sc->n_flow; ++f)
+            if (sc->flows[f * 4 + 3] == r) fl.insert(fl.end(), sc->flows + f * 4, sc->flows + f * 4 + 4);
+    }
+    ptr[NR] = (int)fl.size() / 4;
+    UP(flows, int, fl.data(), fl.size());
+    UP(flow_ptr, int, ptr.data(), NR + 1);
+    UP(agent_lanes, int, sc->agent_lanes, A * P.LMAX);
+    UP(agent_nlane, int, sc->agent_nlane, A); UP(agent_nlink, int, sc->agent_nlink, A);
+    UP(agent_nphase, int, sc->agent_nphase, A);
+    UP(green_tab, uint8_t, sc->green_tab, (size_t)A * P.PMAX * P.KMAX);
+    UP(yellow_tab, uint8_t, sc->yellow_tab, (size_t)A * P.PMAX * P.PMAX * P.KMAX);
+    UP(nbr, int, sc->nbr, A * P.NBR);
+    UP(obs_kind, int, sc->obs_kind, A * P.SMAX); UP(obs_src, int, sc->obs_src, A * P.SMAX);
+
+    const size_t slots = (size_t)n_env * kCap * P.NLP;
+    ALLOC(X, float, slots); ALLOC(V, float, slots); ALLOC(SF, float, slots); ALLOC(M, uint32_t, slots);
+    ALLOC(N, int, (size_t)n_env * P.NLP);
+    ALLOC(pending, int, (size_t)n_env * NR); ALLOC(serial, int, (size_t)n_env * NR);
+    ALLOC(tsec, int, n_env); ALLOC(seed, uint32_t, n_env);
+    ALLOC(prev_action, int, (size_t)n_env * A);
+    ALLOC(fp, float, (size_t)n_env * A * P.PMAX);
+    ALLOC(arrived, unsigned long long, n_env);
+    TSC_HIP(hipMalloc((void **)&h->d_seeds, sizeof(uint32_t) * n_env));
+    h->allocs.push_back(h->d_seeds);
+    h->smem = smem_bytes(P);
+    if (h->smem > 160 * 1024) return tsc::fail("tsc_env_create: LDS need %zu B > 160 KiB", h->smem);
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    TSC_HIP(hipFuncSetAttribute((const void *)reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    *out = h;
+    return 0;
+}
+
+int tsc_env_destroy(tsc_env *h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    for (void *p : h->allocs) (void)hipFree(p);
+    delete h;
+    return 0;
+}
+
+int tsc_env_set_stream(tsc_env *h, void *hip_stream) {
+    if (!h) return tsc::fail("null handle");
+    h->stream = (hipStream_t)hip_stream;
+    return 0;
+}
+
+int tsc_env_reset(tsc_env *h, const uint32_t *seeds_host, float *obs_dev) {
+    if (!h || !seeds_host || !obs_dev) return tsc::fail("tsc_env_reset: bad arguments");
+    TSC_HIP(hipMemcpyAsync(h->d_seeds, seeds_host, sizeof(uint32_t) * h->P.E, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(reset_kernel, dim3(h->P.E), dim3(h->P.NLP), h->smem, h->stream, h->P, h->d_seeds, obs_dev);
+    TSC_HIP(hipGetLastError());
+    TSC_HIP(hipStreamSynchronize(h->stream));          // seeds_host may be reused by the caller
+    return 0;
+}
+
+int tsc_env_set_fingerprint(tsc_env *h, const float *pi_dev) {
+    if (!h || !pi_dev) return tsc::fail("tsc_env_set_fingerprint: bad arguments");
+    size_t tot = (size_t)h->P.E * h->P.A * h->P.PMAX;
+    hipLaunchKernelGGL(fingerprint_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->P, pi_dev);
+    TSC_HIP(hipGetLastError());
+    return 0;
+}
+
+int tsc_env_step(tsc_env *h, const int32_t *action_dev, float *obs_dev, double *reward_dev,
+                 double *global_reward_dev, uint8_t *done_dev, int32_t train_mode) {
+    if (!h || !action_dev || !obs_dev || !reward_dev || !global_reward_dev || !done_dev)
+        return tsc::fail("tsc_env_step: bad arguments");
+    hipLaunchKernelGGL(step_kernel, dim3(h->P.E), dim3(h->P.NLP), h->smem, h->stream, h->P, action_dev, obs_dev,
+                       reward_dev, global_reward_dev, done_dev, (int)train_mode);
+    TSC_HIP(hipGetLastError());
+    return 0;
+}
+
+int tsc_env_get_state(tsc_env *h, int32_t e, int32_t *n, float *x, float *v, float *sf, int32_t *w, int32_t *r,
+                      int32_t *pending, int32_t *serial, int32_t *time_sec) {
+    if (!h || e < 0 || e >= h->P.E) return tsc::fail("tsc_env_get_state: bad arguments");
+    const EnvDev &P = h->P;
+    TSC_HIP(hipStreamSynchronize(h->stream));
+    const size_t slab = (size_t)kCap * P.NLP;
+    std::vector<float> hx(slab), hv(slab), hs(slab);
+    std::vector<uint32_t> hm(slab);
+    std::vector<int> hn(P.NLP);
+    TSC_HIP(hipMemcpy(hx.data(), P.X + e * slab, slab * 4, hipMemcpyDeviceToHost));
+    TSC_HIP(hipMemcpy(hv.data(), P.V + e * slab, slab * 4, hipMemcpyDeviceToHost));
+    TSC_HIP(hipMemcpy(hs.data(), P.SF + e * slab, slab * 4, hipMemcpyDeviceToHost));
+    TSC_HIP(hipMemcpy(hm.data(), P.M + e * slab, slab * 4, hipMemcpyDeviceToHost));
+    TSC_HIP(hipMemcpy(hn.data(), P.N + (size_t)e * P.NLP, P.NLP * 4, hipMemcpyDeviceToHost));
+    for (int l = 0; l < P.NL; ++l) {
+        n[l] = hn[l];
+        for (int i = 0; i < kCap; ++i) {
+            const bool live = i < hn[l];
+            const size_t s = (size_t)i * P.NLP + l, d = (size_t)l * kCap + i;
+            x[d] = live ? hx[s] : 0.0f; v[d] = live ? hv[s] : 0.0f; sf[d] = live ? hs[s] : 0.0f;
+            w[d] = live ? (int)(hm[s] & 0xFFFFu) : 0; r[d] = live ? (int)(hm[s] >> 16) : 0;
+        }
+    }
+    if (pending) TSC_HIP(hipMemcpy(pending, P.pending + (size_t)e * P.NR, P.NR * 4, hipMemcpyDeviceToHost));
+    if (serial) TSC_HIP(hipMemcpy(serial, P.serial + (size_t)e * P.NR, P.NR * 4, hipMemcpyDeviceToHost));
+    if (time_sec) TSC_HIP(hipMemcpy(time_sec, P.tsec + e, 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tsc_env_live_vehicles(tsc_env *h, double *mean_live) {
+    if (!h || !mean_live) return tsc::fail("tsc_env_live_vehicles: bad arguments");
+    const EnvDev &P = h->P;
+    TSC_HIP(hipStreamSynchronize(h->stream));
+    std::vector<int> hn((size_t)P.E * P.NLP);
+    TSC_HIP(hipMemcpy(hn.data(), P.N, hn.size() * 4, hipMemcpyDeviceToHost));
+    double tot = 0;
+    for (int e = 0; e < P.E; ++e)
+        for (int l = 0; l < P.NL; ++l) tot += hn[(size_t)e * P.NLP + l];
+    *mean_live = tot / P.E;
+    return 0;
+}
+
+}  // extern "C"

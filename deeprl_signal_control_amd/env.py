@@ -1,0 +1,185 @@
+"""Host-side env mirror of the reference's TrafficSimulator (envs/env.py:82-635) over the
+HIP microsimulator (include/tsc.h, csrc/tsc_env.hip).
+
+* ``VecTrafficEnv`` -- E parallel env instances on one GPU, torch tensors in/out
+  (device memory only: no compute happens in torch).
+* ``TrafficEnv`` -- E = 1 adaptor with the reference's exact duck-type
+  (``reset/step/update_fingerprint/terminate`` and the attributes ``utils.Trainer`` and
+  ``main.train`` read), so parity tests read like the reference's own
+  scripts (envs/large_grid_env.py:261-286).
+
+There is no CPU path: construction fails if libtsc.so is missing or no GPU is present.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .scenario import LANE_CAP, Scenario, build_scenario
+
+
+class VecTrafficEnv:
+    """E instances of TrafficSimulator.  Seeds follow the reference's bookkeeping
+    (envs/env.py:547-560): instance e starts at ``seed + e`` and every ``reset()`` in train
+    mode advances its seed by ``seed_stride`` (1 for E = 1, like the reference)."""
+
+    def __init__(self, scn: Scenario, n_env: int, device=0, seed=12, test_seeds=(10000, 20000),
+                 seed_stride=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError('VecTrafficEnv needs a GPU (MI355X); there is no CPU fallback')
+        self.scn = scn
+        self.E = int(n_env)
+        self.device = torch.device('cuda', device) if not isinstance(device, torch.device) else device
+        self.agent = scn.agent
+        self.A, self.SMAX, self.AMAX = scn.n_agent, scn.s_max, int(scn.green_tab.shape[1])
+        self.n_s_ls, self.n_a_ls = list(scn.n_s_ls), list(scn.n_a_ls)
+        self.n_w_ls, self.n_f_ls = list(scn.n_w_ls), list(scn.n_f_ls)
+        self.n_s, self.n_a = int(np.sum(self.n_s_ls)), int(np.prod(np.array(self.n_a_ls, dtype=object)))
+        self.node_names = scn.node_names
+        self.T = np.ceil(scn.episode_length_sec / scn.control_interval_sec)      # envs/env.py:89
+        self.train_mode = True
+        self.test_seeds = list(test_seeds)
+        self.test_num = len(self.test_seeds)
+        self.seeds = np.array([seed + e for e in range(self.E)], np.int64)
+        self.seed_stride = self.E if seed_stride is None else seed_stride
+        self.cur_episode = 0
+        self.cur_sec = 0
+        L = _lib.lib()
+        self._L = L
+        sc, self._keep = _lib.scenario_struct(scn)
+        h = C.c_void_p()
+        _lib.check(L.tsc_env_create(C.byref(sc), self.E, self.device.index or 0, C.byref(h)))
+        self._h = h
+        with torch.cuda.device(self.device):
+            self.stream = torch.cuda.current_stream(self.device)
+            _lib.check(L.tsc_env_set_stream(h, C.c_void_p(self.stream.cuda_stream)))
+            d = self.device
+            self.obs = torch.zeros(self.E, self.A, self.SMAX, dtype=torch.float32, device=d)
+            self.reward = torch.zeros(self.E, self.A, dtype=torch.float64, device=d)
+            self.global_reward = torch.zeros(self.E, dtype=torch.float64, device=d)
+            self.done = torch.zeros(self.E, dtype=torch.uint8, device=d)
+
+    # -- lifecycle -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, '_h', None):
+            self._L.tsc_env_destroy(self._h)
+            self._h = None
+
+    terminate = close
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def use_stream(self, stream):
+        self.stream = stream
+        _lib.check(self._L.tsc_env_set_stream(self._h, C.c_void_p(stream.cuda_stream)))
+
+    # -- reference API, batched ------------------------------------------------------------
+    def reset(self, test_ind=0):
+        """envs/env.py:544-561 -> obs float32 [E, A, SMAX]."""
+        if self.train_mode:
+            seeds = self.seeds.copy()
+            self.seeds += self.seed_stride                      # `self.seed += 1`, env.py:560
+        else:
+            seeds = np.full(self.E, self.test_seeds[test_ind], np.int64)
+            self.seeds += self.seed_stride                      # the reference bumps it in test mode too
+        s32 = (seeds & 0xFFFFFFFF).astype(np.uint32)
+        _lib.check(self._L.tsc_env_reset(self._h, s32.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                         C.c_void_p(self.obs.data_ptr())))
+        self.cur_sec = 0
+        self.cur_episode += 1
+        return self.obs
+
+    def update_fingerprint(self, pi):
+        """envs/env.py:633-635; pi float32 [E, A, AMAX] on the device."""
+        assert pi.dtype == torch.float32 and pi.is_contiguous() and tuple(pi.shape) == (self.E, self.A, self.AMAX)
+        _lib.check(self._L.tsc_env_set_fingerprint(self._h, C.c_void_p(pi.data_ptr())))
+
+    def step(self, action):
+        """envs/env.py:566-631; action int32 [E, A] on the device.  Returns the env's own
+        output buffers (obs f32 [E,A,SMAX], reward f64 [E,A], done u8 [E], global f64 [E]),
+        overwritten by the next call."""
+        assert action.dtype == torch.int32 and action.is_contiguous() and tuple(action.shape) == (self.E, self.A)
+        _lib.check(self._L.tsc_env_step(self._h, C.c_void_p(action.data_ptr()), C.c_void_p(self.obs.data_ptr()),
+                                        C.c_void_p(self.reward.data_ptr()),
+                                        C.c_void_p(self.global_reward.data_ptr()),
+                                        C.c_void_p(self.done.data_ptr()), int(self.train_mode)))
+        self.cur_sec += self.scn.control_interval_sec
+        return self.obs, self.reward, self.done, self.global_reward
+
+    # -- debug / parity ---------------------------------------------------------------------
+    def get_state(self, e=0):
+        NL, NR = self.scn.n_lane, self.scn.n_route
+        out = dict(n=np.zeros(NL, np.int32), x=np.zeros((NL, LANE_CAP), np.float32),
+                   v=np.zeros((NL, LANE_CAP), np.float32), sf=np.zeros((NL, LANE_CAP), np.float32),
+                   w=np.zeros((NL, LANE_CAP), np.int32), r=np.zeros((NL, LANE_CAP), np.int32),
+                   pending=np.zeros(NR, np.int32), serial=np.zeros(NR, np.int32), t=np.zeros(1, np.int32))
+        fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
+        _lib.check(self._L.tsc_env_get_state(
+            self._h, e, out['n'].ctypes.data_as(ip), out['x'].ctypes.data_as(fp), out['v'].ctypes.data_as(fp),
+            out['sf'].ctypes.data_as(fp), out['w'].ctypes.data_as(ip), out['r'].ctypes.data_as(ip),
+            out['pending'].ctypes.data_as(ip), out['serial'].ctypes.data_as(ip), out['t'].ctypes.data_as(ip)))
+        return out
+
+    def mean_live_vehicles(self):
+        v = C.c_double()
+        _lib.check(self._L.tsc_env_live_vehicles(self._h, C.byref(v)))
+        return v.value
+
+
+class TrafficEnv:
+    """The reference's single-env duck-type (envs/env.py:544-635) on top of VecTrafficEnv(E=1):
+    ``reset() -> list[A] of 1-D float arrays``, ``step(list[A] of int) -> (obs, reward ndarray,
+    done bool, global_reward float)``.  Observations come back as float32 (the value the
+    reference feeds to its nets, agents/policies.py:82,130); rewards stay float64."""
+
+    def __init__(self, scn: Scenario, device=0, seed=12, test_seeds=(10000, 20000)):
+        self.vec = VecTrafficEnv(scn, 1, device=device, seed=seed, test_seeds=test_seeds, seed_stride=1)
+        self.scn = scn
+        for k in ('agent', 'n_s_ls', 'n_a_ls', 'n_w_ls', 'n_f_ls', 'n_s', 'n_a', 'node_names', 'T', 'test_num'):
+            setattr(self, k, getattr(self.vec, k))
+        self.name = scn.name
+
+    train_mode = property(lambda self: self.vec.train_mode,
+                          lambda self, v: setattr(self.vec, 'train_mode', v))
+    cur_episode = property(lambda self: self.vec.cur_episode)
+    cur_sec = property(lambda self: self.vec.cur_sec)
+    seed = property(lambda self: int(self.vec.seeds[0]))
+
+    def _split(self, obs):
+        o = obs[0].cpu().numpy()
+        return [o[a, :n].copy() for a, n in enumerate(self.scn.obs_len)]
+
+    def reset(self, gui=False, test_ind=0):
+        return self._split(self.vec.reset(test_ind=test_ind))
+
+    def update_fingerprint(self, policy):
+        pi = np.zeros((1, self.vec.A, self.vec.AMAX), np.float32)
+        for a, p in enumerate(policy):
+            pi[0, a, :len(p)] = np.asarray(p, np.float32)
+        self.vec.update_fingerprint(torch.from_numpy(pi).to(self.vec.device))
+
+    def step(self, action):
+        act = torch.tensor([[int(a) for a in action]], dtype=torch.int32, device=self.vec.device)
+        obs, reward, done, g = self.vec.step(act)
+        r = reward[0].cpu().numpy()
+        if self.agent in ('a2c', 'greedy') and self.train_mode:
+            r = float(r[0])                                    # scalar for greedy/a2c (envs/env.py:593-594)
+        return self._split(obs), r, bool(done[0].item()), float(g[0].item())
+
+    def terminate(self):
+        pass
+
+    def close(self):
+        self.vec.close()
+
+
+def make_env(scenario='large_grid', agent='ma2c', n_env=None, **kw):
+    """init_env (main.py:51-79) equivalent; n_env=None gives the reference's single-env type."""
+    scn_kw = {k: kw.pop(k) for k in list(kw) if k in Scenario.__dataclass_fields__}
+    scn = build_scenario(scenario, agent, **scn_kw)
+    return TrafficEnv(scn, **kw) if n_env is None else VecTrafficEnv(scn, n_env, **kw)

@@ -79,6 +79,7 @@ class Scenario:
     obs_src: np.ndarray              # i32 [A, SMAX] lane id (1,2,3) or agent*AMAX+k (4)
     # demand
     flows: np.ndarray                # i32 [NF, 4] begin,end,vph,route
+    obs_len: List[int] = field(default_factory=list)   # true obs length per agent (greedy: wave only)
     # env constants (ENV_CONFIG)
     control_interval_sec: int = 5
     yellow_interval_sec: int = 2
@@ -466,7 +467,7 @@ def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: in
         link_lane=link_lane, phases=[LARGE_GRID_PHASES] * (N * N),
         green_tab=green, yellow_tab=yellow,
         neighbors=neighbors, n_s_ls=n_s, n_w_ls=n_w, n_f_ls=n_f, n_a_ls=n_a_ls,
-        obs_kind=obs_kind, obs_src=obs_src, flows=flows,
+        obs_kind=obs_kind, obs_src=obs_src, flows=flows, obs_len=lens,
         extra={'peak_flow1': peak_flow1, 'peak_flow2': peak_flow2, 'demand': demand},
         **env_kw)
 
