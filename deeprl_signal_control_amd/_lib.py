@@ -38,7 +38,12 @@ _LIB = None
 # every symbol include/tsc.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = ['tsc_last_error', 'tsc_version', 'tsc_env_create', 'tsc_env_destroy', 'tsc_env_set_stream',
            'tsc_env_reset', 'tsc_env_set_fingerprint', 'tsc_env_step', 'tsc_env_get_state',
-           'tsc_env_live_vehicles']
+           'tsc_env_live_vehicles',
+           'tsc_model_create', 'tsc_model_destroy', 'tsc_model_set_stream', 'tsc_model_layout',
+           'tsc_model_set_params', 'tsc_model_get_params', 'tsc_model_get_opt_state', 'tsc_model_set_opt_state',
+           'tsc_model_reset', 'tsc_model_forward', 'tsc_model_sample', 'tsc_model_add_transition',
+           'tsc_model_compute_grads', 'tsc_model_grad_buffer', 'tsc_model_apply_grads', 'tsc_model_get_returns',
+           'tsc_gemm_grouped_f32']
 
 
 def lib():

@@ -1,0 +1,403 @@
+"""Host-side model mirror of the reference's IA2C / MA2C (agents/models.py:132-262) over the
+HIP nets (include/tsc.h tsc_model_*, csrc/tsc_model.hip).
+
+* ``VecA2C`` -- all agents x E env instances, torch tensors in/out (device memory only).
+* ``IA2C`` / ``MA2C`` -- the reference's duck-type for E = 1
+  (``forward/backward/add_transition/reset/save/load``, attrs ``n_step n_agent``), so a
+  ``utils.Trainer``-style loop can drive them unchanged.
+
+Weight init restates ``ortho_init`` (agents/utils.py:11-24, scale sqrt(2), biases 0); like the
+reference it draws from ``np.random`` -- pass ``seed`` to make it reproducible (the reference's
+is not).  Parity tests inject weights through ``set_agent_params``.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+
+A2C_DEFAULTS = dict(rmsp_alpha=0.99, rmsp_epsilon=1e-5, max_grad_norm=40.0, gamma=0.99, lr_init=5e-4,
+                    lr_decay='constant', entropy_coef_init=0.01, entropy_coef_min=0.01,
+                    entropy_decay='constant', entropy_ratio=0.5, value_coef=0.5, num_fw=128, num_ft=32,
+                    num_lstm=64, num_fp=64, batch_size=120, reward_norm=2000.0, reward_clip=2.0,
+                    lr_min=0.0)     # config/config_ma2c_large.ini [MODEL_CONFIG]
+
+
+class TscModelCfg(C.Structure):
+    _fields_ = [('n_agent', C.c_int32), ('s_max', C.c_int32), ('a_max', C.c_int32),
+                ('n_wave', C.POINTER(C.c_int32)), ('n_wait', C.POINTER(C.c_int32)),
+                ('n_fp', C.POINTER(C.c_int32)), ('n_act', C.POINTER(C.c_int32)),
+                ('n_fc_wave', C.c_int32), ('n_fc_wait', C.c_int32), ('n_fc_fp', C.c_int32),
+                ('n_lstm', C.c_int32), ('n_step', C.c_int32),
+                ('gamma', C.c_double), ('reward_norm', C.c_double), ('reward_clip', C.c_double),
+                ('value_coef', C.c_double), ('max_grad_norm', C.c_double), ('rmsp_alpha', C.c_double),
+                ('rmsp_epsilon', C.c_double)]
+
+
+class Scheduler:
+    """agents/utils.py:268-281."""
+
+    def __init__(self, val_init, val_min=0, total_step=0, decay='linear'):
+        self.val, self.N, self.val_min, self.decay, self.n = val_init, float(total_step), val_min, decay, 0
+
+    def get(self, n_step):
+        self.n += n_step
+        if self.decay == 'linear':
+            return max(self.val_min, self.val * (1 - self.n / self.N))
+        return self.val
+
+
+def ortho_init(shape, rng, scale=np.sqrt(2)):
+    """agents/utils.py:11-24 for 2-D shapes."""
+    a = rng.standard_normal(shape)
+    u, _, v = np.linalg.svd(a, full_matrices=False)
+    q = u if u.shape == tuple(shape) else v
+    return (scale * q.reshape(shape)).astype(np.float32)
+
+
+def _setup_lib(L):
+    if getattr(L, '_model_ready', False):
+        return
+    vp = C.c_void_p
+    L.tsc_model_create.argtypes = [C.POINTER(TscModelCfg), C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.tsc_model_destroy.argtypes = [vp]
+    L.tsc_model_set_stream.argtypes = [vp, vp]
+    L.tsc_model_layout.argtypes = [vp, C.POINTER(C.c_int64)]
+    for f in ('tsc_model_set_params', 'tsc_model_get_params', 'tsc_model_get_opt_state', 'tsc_model_set_opt_state'):
+        getattr(L, f).argtypes = [vp, vp]
+    L.tsc_model_reset.argtypes = [vp]
+    L.tsc_model_forward.argtypes = [vp, vp, vp, vp, vp, C.c_int32]
+    L.tsc_model_sample.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64]
+    L.tsc_model_add_transition.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp]
+    L.tsc_model_compute_grads.argtypes = [vp, vp, C.c_double]
+    L.tsc_model_grad_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
+    L.tsc_model_apply_grads.argtypes = [vp, C.c_double, C.c_double, vp]
+    L.tsc_model_get_returns.argtypes = [vp, vp, vp]
+    L.tsc_gemm_grouped_f32.argtypes = [C.c_int32] * 6 + [vp, C.c_int64, C.c_int32, vp, C.c_int64, C.c_int32,
+                                                        vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp]
+    L._model_ready = True
+
+
+class VecA2C:
+    """IA2C / MA2C for A agents x E env instances on one GPU."""
+
+    def __init__(self, n_s_ls, n_a_ls, n_w_ls, n_f_ls, n_env, s_max, a_max, model_config=None,
+                 total_step=0, device=0, seed=None, name='ma2c', process_group=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError('VecA2C needs a GPU (MI355X); there is no CPU fallback')
+        cfg = dict(A2C_DEFAULTS)
+        cfg.update(model_config or {})
+        self.cfg, self.name = cfg, name
+        self.n_agent, self.E = len(n_s_ls), int(n_env)
+        self.n_s_ls, self.n_a_ls, self.n_w_ls, self.n_f_ls = map(list, (n_s_ls, n_a_ls, n_w_ls, n_f_ls))
+        if name != 'ma2c':
+            self.n_f_ls = [0] * self.n_agent
+        self.n_wave_ls = [s - w - f for s, w, f in zip(self.n_s_ls, self.n_w_ls, self.n_f_ls)]
+        self.n_step = int(cfg['batch_size'])
+        self.s_max, self.a_max = int(s_max), int(a_max)
+        self.device = torch.device('cuda', device) if not isinstance(device, torch.device) else device
+        self.pg = process_group
+        self.total_step = total_step
+        self._init_scheduler()
+        L = _lib.lib()
+        _setup_lib(L)
+        self._L = L
+        ip = C.POINTER(C.c_int32)
+        self._arrs = [np.ascontiguousarray(x, np.int32) for x in (self.n_wave_ls, self.n_w_ls, self.n_f_ls, self.n_a_ls)]
+        n_fp = int(cfg['num_fp']) if name == 'ma2c' else 0
+        n_ft = int(cfg['num_ft']) if max(self.n_w_ls) > 0 else 0
+        mc = TscModelCfg(self.n_agent, self.s_max, self.a_max, *[a.ctypes.data_as(ip) for a in self._arrs],
+                         int(cfg['num_fw']), n_ft, n_fp, int(cfg['num_lstm']), self.n_step, float(cfg['gamma']),
+                         float(cfg['reward_norm']), float(cfg['reward_clip']), float(cfg['value_coef']),
+                         float(cfg['max_grad_norm']), float(cfg['rmsp_alpha']), float(cfg['rmsp_epsilon']))
+        self.n_fc = (int(cfg['num_fw']), n_fp, n_ft)
+        h = C.c_void_p()
+        _lib.check(L.tsc_model_create(C.byref(mc), self.E, self.device.index or 0, C.byref(h)))
+        self._h = h
+        lay = (C.c_int64 * 12)()
+        _lib.check(L.tsc_model_layout(h, lay))
+        (self.G, self.stride, self.H, self.Lh, self.oW1, self.ob1, self.oWx, self.oWh, self.obl, self.oWo,
+         self.obo, self.out_pad) = [int(x) for x in lay]
+        with torch.cuda.device(self.device):
+            self.stream = torch.cuda.current_stream(self.device)
+            _lib.check(L.tsc_model_set_stream(h, C.c_void_p(self.stream.cuda_stream)))
+            d = self.device
+            self.pi = torch.zeros(self.E, self.n_agent, self.a_max, dtype=torch.float32, device=d)
+            self.v = torch.zeros(self.E, self.n_agent, dtype=torch.float32, device=d)
+            self.v_boot = torch.zeros(self.E, self.n_agent, dtype=torch.float32, device=d)
+            self.action = torch.zeros(self.E, self.n_agent, dtype=torch.int32, device=d)
+            self._false = torch.zeros(self.E, dtype=torch.uint8, device=d)
+        gp, cnt = C.c_void_p(), C.c_int64()
+        _lib.check(L.tsc_model_grad_buffer(h, C.byref(gp), C.byref(cnt)))
+        self._grad_ptr, self.n_param = gp.value, int(cnt.value)
+        self.cur_t = 0
+        self.sample_step = 0
+        self.sample_seed = 0 if seed is None else int(seed)
+        self.init_params(seed)
+
+    # ---- parameters -----------------------------------------------------------------------
+    def _init_scheduler(self):
+        """agents/models.py:53-69."""
+        c = self.cfg
+        if c['lr_decay'] == 'constant':
+            self.lr_scheduler = Scheduler(c['lr_init'], decay='constant')
+        else:
+            self.lr_scheduler = Scheduler(c['lr_init'], c['lr_min'], self.total_step, decay=c['lr_decay'])
+        if c['entropy_decay'] == 'constant':
+            self.beta_scheduler = Scheduler(c['entropy_coef_init'], decay='constant')
+        else:
+            self.beta_scheduler = Scheduler(c['entropy_coef_init'], c['entropy_coef_min'],
+                                            self.total_step * c['entropy_ratio'], decay=c['entropy_decay'])
+
+    def agent_param_shapes(self, a):
+        """TF-variable-style shapes of one tower of agent a (agents/policies.py:99-118,191-211)."""
+        fw, fp, ft = self.n_fc
+        sh = {'fcw_w': (self.n_wave_ls[a], fw), 'fcw_b': (fw,)}
+        if fp:
+            sh.update({'fcf_w': (self.n_f_ls[a], fp), 'fcf_b': (fp,)})
+        if ft:
+            sh.update({'fct_w': (self.n_w_ls[a], ft), 'fct_b': (ft,)})
+        sh.update({'lstm_wx': (self.H, 4 * self.Lh), 'lstm_wh': (self.Lh, 4 * self.Lh), 'lstm_b': (4 * self.Lh,)})
+        return sh
+
+    def init_params(self, seed=None):
+        rng = np.random.RandomState(seed) if seed is not None else np.random
+        towers = []
+        for a in range(self.n_agent):
+            for tower in ('pi', 'v'):
+                p = {}
+                for k, sh in self.agent_param_shapes(a).items():
+                    p[k] = ortho_init(sh, rng) if len(sh) == 2 else np.zeros(sh, np.float32)
+                n_out = self.n_a_ls[a] if tower == 'pi' else 1
+                p['out_w'] = ortho_init((self.Lh, n_out), rng)
+                p['out_b'] = np.zeros(n_out, np.float32)
+                towers.append(p)
+        self.set_tower_params(towers)
+
+    def pack(self, towers):
+        """List of per-tower dicts (order: agent0 pi, agent0 v, agent1 pi, ...) -> flat [G*stride]."""
+        flat = np.zeros((self.G, self.stride), np.float32)
+        fw, fp, ft = self.n_fc
+        for g, p in enumerate(towers):
+            a = g // 2
+            nw, nt, nf = self.n_wave_ls[a], self.n_w_ls[a], self.n_f_ls[a]
+            W1 = np.zeros((self.s_max, self.H), np.float32)
+            b1 = np.zeros(self.H, np.float32)
+            W1[:nw, :fw] = p['fcw_w']; b1[:fw] = p['fcw_b']
+            if fp:
+                W1[nw + nt:nw + nt + nf, fw:fw + fp] = p['fcf_w']; b1[fw:fw + fp] = p['fcf_b']
+            if ft:
+                W1[nw:nw + nt, fw + fp:] = p['fct_w']; b1[fw + fp:] = p['fct_b']
+            Wo = np.zeros((self.Lh, self.out_pad), np.float32)
+            bo = np.zeros(self.out_pad, np.float32)
+            Wo[:, :p['out_w'].shape[1]] = p['out_w']; bo[:len(p['out_b'])] = p['out_b']
+            f = flat[g]
+            f[self.oW1:self.ob1] = W1.ravel(); f[self.ob1:self.oWx] = b1
+            f[self.oWx:self.oWh] = p['lstm_wx'].ravel(); f[self.oWh:self.obl] = p['lstm_wh'].ravel()
+            f[self.obl:self.oWo] = p['lstm_b']; f[self.oWo:self.obo] = Wo.ravel(); f[self.obo:] = bo
+        return flat.ravel()
+
+    def unpack(self, flat):
+        flat = np.asarray(flat, np.float32).reshape(self.G, self.stride)
+        fw, fp, ft = self.n_fc
+        towers = []
+        for g in range(self.G):
+            a = g // 2
+            nw, nt, nf = self.n_wave_ls[a], self.n_w_ls[a], self.n_f_ls[a]
+            f = flat[g]
+            W1 = f[self.oW1:self.ob1].reshape(self.s_max, self.H); b1 = f[self.ob1:self.oWx]
+            p = {'fcw_w': W1[:nw, :fw].copy(), 'fcw_b': b1[:fw].copy()}
+            if fp:
+                p['fcf_w'] = W1[nw + nt:nw + nt + nf, fw:fw + fp].copy(); p['fcf_b'] = b1[fw:fw + fp].copy()
+            if ft:
+                p['fct_w'] = W1[nw:nw + nt, fw + fp:].copy(); p['fct_b'] = b1[fw + fp:].copy()
+            p['lstm_wx'] = f[self.oWx:self.oWh].reshape(self.H, 4 * self.Lh).copy()
+            p['lstm_wh'] = f[self.oWh:self.obl].reshape(self.Lh, 4 * self.Lh).copy()
+            p['lstm_b'] = f[self.obl:self.oWo].copy()
+            n_out = self.n_a_ls[a] if g % 2 == 0 else 1
+            p['out_w'] = f[self.oWo:self.obo].reshape(self.Lh, self.out_pad)[:, :n_out].copy()
+            p['out_b'] = f[self.obo:self.obo + n_out].copy()
+            towers.append(p)
+        return towers
+
+    def set_tower_params(self, towers):
+        flat = np.ascontiguousarray(self.pack(towers))
+        _lib.check(self._L.tsc_model_set_params(self._h, flat.ctypes.data_as(C.c_void_p)))
+
+    def get_flat(self, what='params'):
+        out = np.zeros(self.n_param, np.float32)
+        fn = self._L.tsc_model_get_params if what == 'params' else self._L.tsc_model_get_opt_state
+        _lib.check(fn(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def get_tower_params(self):
+        return self.unpack(self.get_flat())
+
+    def grad_tensor(self):
+        """The contiguous fp32 gradient buffer as a torch tensor view (for RCCL all-reduce)."""
+        class _Holder:
+            pass
+        hold = _Holder()
+        hold.__cuda_array_interface__ = {'shape': (self.n_param,), 'typestr': '<f4', 'data': (self._grad_ptr, False),
+                                         'version': 3, 'strides': None}
+        return torch.as_tensor(hold, device=self.device)
+
+    # ---- reference API (batched) ------------------------------------------------------------
+    def reset(self):
+        """agents/models.py:218-220."""
+        _lib.check(self._L.tsc_model_reset(self._h))
+
+    def forward(self, obs, done, out_type='pv'):
+        """agents/models.py:185-200.  obs f32 [E,A,SMAX] (device), done u8 [E] or bool.
+        Returns tensors pi [E,A,AMAX], v [E,A] (or one of them for 'p' / 'v')."""
+        if not torch.is_tensor(done):
+            done = torch.full((self.E,), int(bool(done)), dtype=torch.uint8, device=self.device)
+        adv = 1 if 'p' in out_type else 0
+        v_out = self.v if adv else self.v_boot
+        _lib.check(self._L.tsc_model_forward(self._h, C.c_void_p(obs.data_ptr()), C.c_void_p(done.data_ptr()),
+                                             C.c_void_p(self.pi.data_ptr()), C.c_void_p(v_out.data_ptr()), adv))
+        if out_type == 'pv':
+            return self.pi, self.v
+        return self.pi if out_type == 'p' else v_out
+
+    def sample(self, pi=None):
+        """np.random.choice per agent (utils.py:155-157), counter-based RNG."""
+        pi = self.pi if pi is None else pi
+        _lib.check(self._L.tsc_model_sample(self._h, C.c_void_p(pi.data_ptr()), C.c_void_p(self.action.data_ptr()),
+                                            self.sample_seed, self.sample_step))
+        self.sample_step += 1
+        return self.action
+
+    def add_transition(self, obs, done_pre, actions, rewards, values, done_post):
+        """agents/models.py:222-229 (+ the pre-step done the LSTM saw, agents/utils.py:225-226)."""
+        if not torch.is_tensor(done_pre):
+            done_pre = torch.full((self.E,), int(bool(done_pre)), dtype=torch.uint8, device=self.device)
+        _lib.check(self._L.tsc_model_add_transition(
+            self._h, self.cur_t, C.c_void_p(obs.data_ptr()), C.c_void_p(done_pre.data_ptr()),
+            C.c_void_p(actions.data_ptr()), C.c_void_p(rewards.data_ptr()), C.c_void_p(values.data_ptr()),
+            C.c_void_p(done_post.data_ptr())))
+        self.cur_t += 1
+
+    def backward(self, R, summary_writer=None, global_step=None, want_stats=False):
+        """agents/models.py:174-183.  R: bootstrap values f32 [E,A] (zeros where terminal)."""
+        assert self.cur_t == self.n_step, 'backward() needs a full n_step buffer (T %% n_step == 0, utils.py:121)'
+        cur_lr = self.lr_scheduler.get(self.n_step)
+        cur_beta = self.beta_scheduler.get(self.n_step)
+        _lib.check(self._L.tsc_model_compute_grads(self._h, C.c_void_p(R.data_ptr()), float(cur_beta)))
+        scale = 1.0
+        if self.pg is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                   and torch.distributed.get_world_size() > 1):
+            g = self.grad_tensor()
+            torch.distributed.all_reduce(g, group=self.pg)       # RCCL over xGMI, one flat buffer
+            scale = 1.0 / torch.distributed.get_world_size(self.pg)
+        stats = np.zeros((self.n_agent, 4), np.float64) if want_stats else None
+        _lib.check(self._L.tsc_model_apply_grads(self._h, float(cur_lr), scale,
+                                                 stats.ctypes.data_as(C.c_void_p) if want_stats else None))
+        self.cur_t = 0
+        return stats
+
+    # ---- checkpoints (agents/models.py:83-108: `checkpoint-<step>`, highest step wins) -------
+    def save(self, model_dir, global_step):
+        os.makedirs(model_dir, exist_ok=True)
+        np.savez(os.path.join(model_dir, 'checkpoint-%d.npz' % int(global_step)), params=self.get_flat('params'),
+                 ms=self.get_flat('ms'), layout=np.array([self.G, self.stride, self.H, self.s_max]))
+
+    def load(self, model_dir, checkpoint=None):
+        save_file, save_step = None, 0
+        if os.path.exists(model_dir):
+            if checkpoint is None:
+                for f in os.listdir(model_dir):
+                    if f.startswith('checkpoint'):
+                        tokens = f.split('.')[0].split('-')
+                        if len(tokens) != 2:
+                            continue
+                        if int(tokens[1]) > save_step:
+                            save_file, save_step = f, int(tokens[1])
+            else:
+                save_file = 'checkpoint-%d.npz' % int(checkpoint)
+        if save_file is None or not os.path.exists(os.path.join(model_dir, save_file)):
+            return False
+        z = np.load(os.path.join(model_dir, save_file))
+        p = np.ascontiguousarray(z['params'], np.float32)
+        ms = np.ascontiguousarray(z['ms'], np.float32)
+        _lib.check(self._L.tsc_model_set_params(self._h, p.ctypes.data_as(C.c_void_p)))
+        _lib.check(self._L.tsc_model_set_opt_state(self._h, ms.ctypes.data_as(C.c_void_p)))
+        return True
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._L.tsc_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class IA2C:
+    """E = 1 duck-type of agents/models.py:132-229 (lists of per-agent arrays in and out)."""
+    _name = 'ia2c'
+
+    def __init__(self, n_s_ls, n_a_ls, n_w_ls, total_step, model_config, seed=0, device=0, n_f_ls=None):
+        n_f_ls = [0] * len(n_s_ls) if n_f_ls is None else n_f_ls
+        s_max = (max(n_s_ls) + 3) // 4 * 4
+        self.vec = VecA2C(n_s_ls, n_a_ls, n_w_ls, n_f_ls, 1, s_max, max(n_a_ls), model_config, total_step,
+                          device=device, seed=seed, name=self._name)
+        self.name, self.n_agent, self.n_step = self._name, len(n_s_ls), self.vec.n_step
+        self.n_s_ls, self.n_a_ls = list(n_s_ls), list(n_a_ls)
+        self.sess = None
+        self._last_done = False
+        d = self.vec.device
+        self._obs = torch.zeros(1, self.n_agent, s_max, dtype=torch.float32, device=d)
+
+    def _put_obs(self, obs):
+        o = np.zeros((1, self.n_agent, self.vec.s_max), np.float32)
+        for a, ob in enumerate(obs):
+            o[0, a, :len(ob)] = np.asarray(ob, np.float32)          # TF feed casts to float32
+        self._obs.copy_(torch.from_numpy(o))
+        return self._obs
+
+    def forward(self, obs, done, out_type='pv'):
+        out = self.vec.forward(self._put_obs(obs), done, out_type)
+        self._last_done = done
+        if out_type == 'pv':
+            pi, v = out[0][0].cpu().numpy(), out[1][0].cpu().numpy()
+            return [pi[a, :n].copy() for a, n in enumerate(self.n_a_ls)], [v[a] for a in range(self.n_agent)]
+        if out_type == 'p':
+            pi = out[0].cpu().numpy()
+            return [pi[a, :n].copy() for a, n in enumerate(self.n_a_ls)]
+        v = out[0].cpu().numpy()
+        return [v[a] for a in range(self.n_agent)]
+
+    def add_transition(self, obs, actions, rewards, values, done):
+        d = self.vec.device
+        self.vec.add_transition(self._put_obs(obs), self._last_done,
+                                torch.tensor([list(map(int, actions))], dtype=torch.int32, device=d),
+                                torch.tensor(np.asarray(rewards, np.float64).reshape(1, -1), device=d),
+                                torch.tensor(np.asarray(values, np.float32).reshape(1, -1), device=d),
+                                torch.tensor([int(bool(done))], dtype=torch.uint8, device=d))
+
+    def backward(self, R_ls, summary_writer=None, global_step=None):
+        R = torch.tensor(np.asarray(R_ls, np.float32).reshape(1, -1), device=self.vec.device)
+        return self.vec.backward(R, summary_writer, global_step)
+
+    def reset(self):
+        self.vec.reset()
+
+    def save(self, model_dir, global_step):
+        self.vec.save(model_dir, global_step)
+
+    def load(self, model_dir, checkpoint=None):
+        return self.vec.load(model_dir, checkpoint)
+
+
+class MA2C(IA2C):
+    """agents/models.py:232-261."""
+    _name = 'ma2c'
+
+    def __init__(self, n_s_ls, n_a_ls, n_w_ls, n_f_ls, total_step, model_config, seed=0, device=0):
+        super().__init__(n_s_ls, n_a_ls, n_w_ls, total_step, model_config, seed=seed, device=device, n_f_ls=n_f_ls)

@@ -1,0 +1,730 @@
+// tsc_model.hip -- per-intersection actor-critic nets + on-policy A2C update on gfx950.
+//
+// Replaces, for all agents of all env instances at once:
+//   K7 policy forward ........ IA2C/MA2C.forward (agents/models.py:185-200) -> LstmACPolicy /
+//                              FPLstmACPolicy._build_net (agents/policies.py:99-118,191-211),
+//                              fc / lstm (agents/utils.py:66-74,88-116)
+//   sampling ................. np.random.choice per agent (utils.py:155-157)
+//   K8 returns / advantages .. OnPolicyBuffer (agents/utils.py:182-228), reward norm/clip
+//                              (agents/models.py:222-229)
+//   K9 loss + BPTT + update .. ACPolicy.prepare_loss (agents/policies.py:41-61): A2C loss,
+//                              per-agent clip_by_global_norm, TF1 RMSProp
+//
+// Layout: agent-tower group g = 2*agent + tower (0 = pi, 1 = v).  All parameters live in one
+// flat fp32 buffer [G][stride] (W1 | b1 | Wx | Wh | bl | Wo | bo per group); gradients and the
+// RMSProp accumulator use the same layout, so the gradient buffer is one contiguous RCCL
+// all-reduce.  The three input FCs (wave / fingerprint / wait) are one block-diagonal
+// [SMAX x H] matrix with structural zeros (kept zero by a row-range mask on its gradient).
+// Dense contractions run on the fp32 MFMA grouped GEMM (tsc_gemm.h); the recurrent part is a
+// persistent per-(group, 64-env tile) kernel with Wh resident in LDS and c/h (forward) or
+// dc/dh (backward) resident in registers across the n_step time steps.
+#include "tsc_common.h"
+#include "tsc_gemm.h"
+#include "../../include/tsc.h"
+
+#include <vector>
+
+namespace {
+
+using tsc::f32x16;
+using tsc::GemmArgs;
+
+constexpr int kOut = 8;          // padded head width (n_a <= 8; v uses column 0)
+constexpr int kL = 64;           // num_lstm (fixed by the kernels' tiling)
+constexpr int kG4 = 4 * kL;      // gate columns i|f|o|u
+
+struct Layout {
+    int G, A, SMAX, AMAX, H;
+    long long stride, oW1, ob1, oWx, oWh, obl, oWo, obo;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------
+// LSTM forward (agents/utils.py:88-116), T steps, one workgroup per (group, 64-env tile).
+//   Z     [G][T*E][256]  in: x*Wx + b   out (if store): post-activation gates i|f|o|u
+//   state [G][E][128]    c | h   (read; written back if write_state)
+//   Hh,Cc [G][T*E][64]   h_t, c_t            (if store)
+//   Hp    [G][T*E][64]   masked h_{t-1} fed to step t   (if store)
+//   done  [T][E] u8      pre-step done (resets c, h)
+// Wave w owns env rows 32*(w&1).. and hidden units 32*(w>>1)..; its four 32x32 MFMA tiles are
+// the four gates of the same (env, unit) pairs, so the cell update needs no cross-lane traffic.
+// ------------------------------------------------------------------------------------------------
+constexpr int kWhLd = kG4 + 4;
+constexpr int kHsLd = 64 + 4;
+
+__global__ void __launch_bounds__(256) lstm_fwd_kernel(const float *__restrict__ params, Layout lay, float *Z,
+                                                      const float *state_in, float *state_out,
+                                                      float *Hh, float *Cc, float *Hp, const uint8_t *done,
+                                                      int T, int E, int store) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *Whs = (float *)smem_raw;                 // [64][kWhLd]
+    float *hs = Whs + 64 * kWhLd;                   // [64 k = unit][kHsLd m = env]
+    const int g = blockIdx.x, e0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = 32 * (wave & 1), j0 = 32 * (wave >> 1), li = lane & 31, kh = lane >> 5;
+    const float *Wh = params + (long long)g * lay.stride + lay.oWh;
+    for (int i = tid; i < 64 * kG4; i += 256) Whs[(i / kG4) * kWhLd + (i % kG4)] = Wh[i];
+    const long long N = (long long)T * E;
+    const int j = j0 + li;
+    float c[16];
+    int erow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        erow[r] = r0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int e = e0 + erow[r];
+        float c0 = 0.f, h0 = 0.f;
+        if (e < E) {
+            const float *s = state_in + ((long long)g * E + e) * 2 * kL;
+            c0 = s[j]; h0 = s[kL + j];
+            const float keep = 1.0f - (float)done[e];
+            c0 *= keep; h0 *= keep;
+        }
+        c[r] = c0;
+        hs[j * kHsLd + erow[r]] = h0;
+    }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int e = e0 + erow[r];
+                acc[q][r] = e < E ? Z[(((long long)g * N + (long long)t * E + e) * kG4) + 64 * q + j] : 0.f;
+            }
+        if (store) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int e = e0 + erow[r];
+                if (e < E) Hp[((long long)g * N + (long long)t * E + e) * kL + j] = hs[j * kHsLd + erow[r]];
+            }
+        }
+#pragma unroll 4
+        for (int kk = 0; kk < 64; kk += 2) {
+            const float a = hs[(kk + kh) * kHsLd + r0 + li];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float b = Whs[(kk + kh) * kWhLd + 64 * q + j];
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q], 0, 0, 0);
+            }
+        }
+        __syncthreads();                             // everyone is done reading hs
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int e = e0 + erow[r];
+            const float ig = sigmoidf_(acc[0][r]), fg = sigmoidf_(acc[1][r]);
+            const float og = sigmoidf_(acc[2][r]), ug = tanhf(acc[3][r]);
+            const float cn = fg * c[r] + ig * ug;
+            const float hn = og * tanhf(cn);
+            float keep = 1.0f;
+            if (e < E) {
+                const long long n = (long long)g * N + (long long)t * E + e;
+                if (store) {
+                    Z[n * kG4 + j] = ig; Z[n * kG4 + 64 + j] = fg; Z[n * kG4 + 128 + j] = og; Z[n * kG4 + 192 + j] = ug;
+                    Cc[n * kL + j] = cn;
+                }
+                Hh[n * kL + j] = hn;
+                if (t + 1 < T) keep = 1.0f - (float)done[(long long)(t + 1) * E + e];
+                if (t + 1 == T && state_out) {
+                    float *s = state_out + ((long long)g * E + e) * 2 * kL;
+                    s[j] = cn; s[kL + j] = hn;
+                }
+            }
+            c[r] = cn * keep;
+            hs[j * kHsLd + erow[r]] = hn * keep;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LSTM backward through time.  One workgroup per (group, 64-env tile); lanes keep dc and the
+// recurrent dh of their 16 (env, unit) pairs in registers over the whole sequence.
+//   Z   [G][N][256] in: gates i|f|o|u (post-activation)   out: dz (pre-activation gradients)
+//   Cc  [G][N][64]  c_t;  c_{t-1} = Cc[t-1] or state_bw, masked by done[t]
+//   dH  [G][N][64]  gradient arriving at h_t from the head
+// per step: dz -> LDS (k-major) -> dh_{t-1} = dz * Wh^T on the MFMA (K = 256).
+// ------------------------------------------------------------------------------------------------
+constexpr int kWtLd = 64 + 4;
+constexpr int kDzLd = 64 + 4;
+
+__global__ void __launch_bounds__(256) lstm_bwd_kernel(const float *__restrict__ params, Layout lay, float *Z,
+                                                      const float *Cc, const float *state_bw, const float *dH,
+                                                      const uint8_t *done, int T, int E) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *WhT = (float *)smem_raw;                 // [256 k = gate col][kWtLd n = unit]
+    float *dzs = WhT + kG4 * kWtLd;                 // [256 k][kDzLd m = env]
+    const int g = blockIdx.x, e0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = 32 * (wave & 1), j0 = 32 * (wave >> 1), li = lane & 31, kh = lane >> 5;
+    const float *Wh = params + (long long)g * lay.stride + lay.oWh;
+    for (int i = tid; i < 64 * kG4; i += 256) WhT[(i % kG4) * kWtLd + (i / kG4)] = Wh[i];
+    const long long N = (long long)T * E;
+    const int j = j0 + li;
+    float dh_rec[16], dc_rec[16];
+    int erow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        erow[r] = r0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        dh_rec[r] = 0.f; dc_rec[r] = 0.f;
+    }
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int e = e0 + erow[r];
+            float di = 0.f, df = 0.f, dog = 0.f, du = 0.f;
+            if (e < E) {
+                const long long n = (long long)g * N + (long long)t * E + e;
+                const float ig = Z[n * kG4 + j], fg = Z[n * kG4 + 64 + j], og = Z[n * kG4 + 128 + j], ug = Z[n * kG4 + 192 + j];
+                const float cn = Cc[n * kL + j];
+                const float keep = 1.0f - (float)done[(long long)t * E + e];
+                const float cp = (t > 0 ? Cc[(n - E) * kL + j] : state_bw[((long long)g * E + e) * 2 * kL + j]) * keep;
+                const float dh = dH[n * kL + j] + dh_rec[r];
+                const float tc = tanhf(cn);
+                dog = dh * tc * og * (1.0f - og);
+                const float dc = dh * og * (1.0f - tc * tc) + dc_rec[r];
+                di = dc * ug * ig * (1.0f - ig);
+                df = dc * cp * fg * (1.0f - fg);
+                du = dc * ig * (1.0f - ug * ug);
+                dc_rec[r] = dc * fg * keep;
+                Z[n * kG4 + j] = di; Z[n * kG4 + 64 + j] = df; Z[n * kG4 + 128 + j] = dog; Z[n * kG4 + 192 + j] = du;
+            }
+            dzs[(j) * kDzLd + erow[r]] = di;
+            dzs[(64 + j) * kDzLd + erow[r]] = df;
+            dzs[(128 + j) * kDzLd + erow[r]] = dog;
+            dzs[(192 + j) * kDzLd + erow[r]] = du;
+        }
+        __syncthreads();
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+        for (int kk = 0; kk < kG4; kk += 2) {
+            const float a = dzs[(kk + kh) * kDzLd + r0 + li];
+            const float b = WhT[(kk + kh) * kWtLd + j];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int e = e0 + erow[r];
+            const float keep = e < E ? 1.0f - (float)done[(long long)t * E + e] : 0.f;
+            dh_rec[r] = acc[r] * keep;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Heads.  pi = softmax(h_pi Wo + bo) over the agent's n_a actions, v = h_v Wv + bv
+// (agents/policies.py:20-26).  One thread per (sample, agent).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void head_eval(const float *__restrict__ params, const Layout &lay, int a, int na,
+                                          const float *hp, const float *hv, float *pi, float &v) {
+    const float *Wo = params + (long long)(2 * a) * lay.stride + lay.oWo;
+    const float *bo = params + (long long)(2 * a) * lay.stride + lay.obo;
+    const float *Wv = params + (long long)(2 * a + 1) * lay.stride + lay.oWo;
+    const float *bv = params + (long long)(2 * a + 1) * lay.stride + lay.obo;
+    float lg[kOut];
+#pragma unroll
+    for (int k = 0; k < kOut; ++k) lg[k] = 0.f;
+    float vv = 0.f;
+    for (int jj = 0; jj < kL; ++jj) {
+        const float h = hp[jj];
+#pragma unroll
+        for (int k = 0; k < kOut; ++k) lg[k] += h * Wo[jj * kOut + k];
+        vv += hv[jj] * Wv[jj * kOut];
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < kOut; ++k) { lg[k] += bo[k]; if (k < na && lg[k] > mx) mx = lg[k]; }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < kOut; ++k) { pi[k] = k < na ? expf(lg[k] - mx) : 0.f; sum += pi[k]; }
+#pragma unroll
+    for (int k = 0; k < kOut; ++k) pi[k] = pi[k] / sum;
+    v = vv + bv[0];
+}
+
+__global__ void head_fwd_kernel(const float *__restrict__ params, Layout lay, const int *n_act, const float *Hh,
+                                int E, float *pi_out, float *v_out) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)E * lay.A) return;
+    const int e = (int)(idx / lay.A), a = (int)(idx % lay.A);
+    float hp[kL], hv[kL];
+    const float *p0 = Hh + ((long long)(2 * a) * E + e) * kL, *p1 = Hh + ((long long)(2 * a + 1) * E + e) * kL;
+    for (int jj = 0; jj < kL; ++jj) { hp[jj] = p0[jj]; hv[jj] = p1[jj]; }
+    float pi[kOut], v;
+    head_eval(params, lay, a, n_act[a], hp, hv, pi, v);
+    for (int k = 0; k < lay.AMAX; ++k) pi_out[idx * lay.AMAX + k] = k < kOut ? pi[k] : 0.f;
+    v_out[idx] = v;
+}
+
+// Loss (agents/policies.py:41-52) and its gradient w.r.t. logits / v, then back through the head:
+//   L = -mean(log_pi[a] Adv) + 0.5 v_coef mean((R - v)^2) - beta mean(entropy), mean over the
+//   T*E samples of one agent.  Writes dL [G][N][8] (pi tower: dlogits, v tower: dv in col 0)
+//   and dH [G][N][64].
+__global__ void head_bwd_kernel(const float *__restrict__ params, Layout lay, const int *n_act, const float *Hh,
+                                const int *act, const float *Rs, const float *Advs, long long N,
+                                float v_coef, float beta, float *dL, float *dH, double *stats) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * lay.A) return;
+    const long long n = idx / lay.A;
+    const int a = (int)(idx % lay.A), na = n_act[a];
+    float hp[kL], hv[kL];
+    const float *p0 = Hh + ((long long)(2 * a) * N + n) * kL, *p1 = Hh + ((long long)(2 * a + 1) * N + n) * kL;
+    for (int jj = 0; jj < kL; ++jj) { hp[jj] = p0[jj]; hv[jj] = p1[jj]; }
+    float pi[kOut], v;
+    head_eval(params, lay, a, na, hp, hv, pi, v);
+    const int ac = act[idx];
+    const float adv = Advs[idx], R = Rs[idx];
+    const float invN = 1.0f / (float)N;
+    float logp[kOut], ent = 0.f;
+    bool inr[kOut];
+#pragma unroll
+    for (int k = 0; k < kOut; ++k) {
+        inr[k] = pi[k] >= 1e-10f;                                  // tf.clip_by_value(pi, 1e-10, 1)
+        logp[k] = k < na ? logf(fminf(fmaxf(pi[k], 1e-10f), 1.0f)) : 0.f;
+        if (k < na) ent -= pi[k] * logp[k];
+    }
+    // dL/dpi_k, then softmax Jacobian: dlogit_k = pi_k (g_k - sum_j pi_j g_j)
+    float gk[kOut], dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < kOut; ++k) {
+        float gpi = 0.f;
+        if (k < na) {
+            if (k == ac && inr[k]) gpi += -adv * invN / fmaxf(pi[k], 1e-10f);
+            gpi += beta * invN * (logp[k] + (inr[k] ? 1.0f : 0.f));
+        }
+        gk[k] = gpi;
+        dot += pi[k] * gpi;
+    }
+    float dl[kOut];
+#pragma unroll
+    for (int k = 0; k < kOut; ++k) dl[k] = k < na ? pi[k] * (gk[k] - dot) : 0.f;
+    const float dv = v_coef * (v - R) * invN;
+    float *o0 = dL + ((long long)(2 * a) * N + n) * kOut, *o1 = dL + ((long long)(2 * a + 1) * N + n) * kOut;
+#pragma unroll
+    for (int k = 0; k < kOut; ++k) { o0[k] = dl[k]; o1[k] = k == 0 ? dv : 0.f; }
+    const float *Wo = params + (long long)(2 * a) * lay.stride + lay.oWo;
+    const float *Wv = params + (long long)(2 * a + 1) * lay.stride + lay.oWo;
+    float *h0 = dH + ((long long)(2 * a) * N + n) * kL, *h1 = dH + ((long long)(2 * a + 1) * N + n) * kL;
+    for (int jj = 0; jj < kL; ++jj) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < kOut; ++k) s += dl[k] * Wo[jj * kOut + k];
+        h0[jj] = s;
+        h1[jj] = dv * Wv[jj * kOut];
+    }
+    if (stats) {   // logging only (policies.py:63-72)
+        atomicAdd(&stats[a * 4 + 0], (double)(-logp[ac < na ? ac : 0] * adv * invN));
+        atomicAdd(&stats[a * 4 + 1], (double)(0.5f * v_coef * (R - v) * (R - v) * invN));
+        atomicAdd(&stats[a * 4 + 2], (double)(-beta * ent * invN));
+    }
+}
+
+// n-step returns and advantages (agents/utils.py:202-228): float64 recursion from the back with
+// POST-step dones, Adv = R - v, cast to float32.   rew f64 [T][E][A], val f32, done_all u8 [T+1][E]
+__global__ void returns_kernel(const double *rew, const float *val, const uint8_t *done_all, const float *Rboot,
+                               int T, int E, int A, double gamma, float *Rs, float *Advs) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= E * A) return;
+    const int e = idx / A;
+    double R = (double)Rboot[idx];
+    for (int t = T - 1; t >= 0; --t) {
+        const double d = (double)done_all[(long long)(t + 1) * E + e];
+        R = rew[(long long)t * E * A + idx] + gamma * R * (1.0 - d);
+        const double adv = R - (double)val[(long long)t * E * A + idx];
+        Rs[(long long)t * E * A + idx] = (float)R;
+        Advs[(long long)t * E * A + idx] = (float)adv;
+    }
+}
+
+__global__ void add_transition_kernel(int E, int A, int SMAX, const float *obs, const uint8_t *done_pre,
+                                      const int *action, const double *reward, const float *value,
+                                      const uint8_t *done_post, double rnorm, double rclip, float *obs_t,
+                                      int *act_t, double *rew_t, float *val_t, uint8_t *done_t, uint8_t *done_t1) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long no = (long long)E * A * SMAX;
+    if (i < no) obs_t[i] = obs[i];
+    if (i < (long long)E * A) {
+        double r = reward[i];
+        if (rnorm != 0.0) r = r / rnorm;                         // agents/models.py:223-224
+        if (rclip != 0.0) r = fmin(fmax(r, -rclip), rclip);      // :225-226
+        rew_t[i] = r; act_t[i] = action[i]; val_t[i] = value[i];
+    }
+    if (i < E) { done_t[i] = done_pre[i]; done_t1[i] = done_post[i]; }
+}
+
+// np.random.choice(n, p=pi): cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, u, 'right')
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ void sample_kernel(const float *pi, const int *n_act, int E, int A, int AMAX, unsigned long long seed,
+                              unsigned long long step, int *action) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= E * A) return;
+    const int a = idx % A, na = n_act[a];
+    const unsigned long long h = splitmix64(splitmix64(seed ^ (step * 0xD1B54A32D192ED03ull)) + (unsigned long long)idx);
+    const double u = (double)(h >> 11) * (1.0 / 9007199254740992.0);
+    double cdf[kOut], s = 0.0;
+    for (int k = 0; k < na; ++k) { s += (double)pi[(long long)idx * AMAX + k]; cdf[k] = s; }
+    int ans = na - 1;
+    for (int k = 0; k < na; ++k)
+        if (u < cdf[k] / s) { ans = k; break; }
+    action[idx] = ans;
+}
+
+// per-agent global norm (tf.clip_by_global_norm over both towers, agents/policies.py:54-57)
+__global__ void grad_norm_kernel(const float *grad, long long per_agent, double gscale, double *norm2) {
+    __shared__ double red[256];
+    const int a = blockIdx.x;
+    const float *gp = grad + (long long)a * per_agent;
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < per_agent; i += 256) { const double v = (double)gp[i] * gscale; s += v * v; }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) norm2[a] = red[0];
+}
+
+// TF1 RMSPropOptimizer (momentum 0, not centred): ms = a ms + (1-a) g^2 ; w -= lr g / sqrt(ms + eps)
+__global__ void rmsprop_kernel(float *w, float *ms, const float *grad, long long per_agent, long long total,
+                               const double *norm2, float gscale, float clip, float lr, float alpha, float eps) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int a = (int)(i / per_agent);
+    const float nrm = (float)sqrt(norm2[a]);
+    float g = grad[i] * gscale;
+    if (clip > 0.f) g = g * (clip / fmaxf(nrm, clip));
+    const float m = alpha * ms[i] + (1.0f - alpha) * g * g;
+    ms[i] = m;
+    w[i] = w[i] - lr * g / sqrtf(m + eps);
+}
+
+__global__ void transpose_wx_kernel(const float *params, Layout lay, float *WxT) {
+    // WxT[g][c][h] = Wx[g][h][c]
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per = (long long)lay.H * kG4;
+    if (i >= per * lay.G) return;
+    const int g = (int)(i / per);
+    const long long r = i % per;
+    const int c = (int)(r / lay.H), h = (int)(r % lay.H);
+    WxT[i] = params[(long long)g * lay.stride + lay.oWx + (long long)h * kG4 + c];
+}
+
+__global__ void fill_kernel(float *p, long long n, float v) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+struct tsc_model {
+    Layout lay;
+    int E, T, device;
+    double gamma, rnorm, rclip, vcoef, max_norm, alpha, eps;
+    hipStream_t stream;
+    std::vector<void *> allocs;
+    int *n_act;
+    int16_t *rowrange;          // [A][SMAX][2]
+    float *params, *grads, *ms, *WxT;
+    float *state_fw, *state_bw, *state_tmp;     // [G][E][128]
+    // rollout (on-policy buffer)
+    float *r_obs; int *r_act; double *r_rew; float *r_val; uint8_t *r_done;   // done [T+1][E]
+    float *Rs, *Advs;
+    // activations
+    float *X1, *Z, *Hh, *Cc, *Hp, *dHh, *dL;
+    double *norm2, *stats;
+    size_t lds_fwd, lds_bwd;
+    long long nparam;
+};
+
+namespace {
+
+int gemm(tsc_model *m, bool tn, int epi, int groups, int M, int N, int K, const float *A, long long sA, int lda,
+         int gdivA, const float *B, long long sB, int ldb, float *C, long long sC, int ldc, const float *bias,
+         long long sBias, const float *aux, long long sAux, int ldaux, const int16_t *rr, long long sRR,
+         float *colsum, long long sColsum) {
+    GemmArgs a;
+    a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.rr = rr; a.colsum = colsum;
+    a.sA = sA; a.sB = sB; a.sC = sC; a.sBias = sBias; a.sAux = sAux; a.sRR = sRR; a.sColsum = sColsum;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux; a.M = M; a.N = N; a.K = K; a.gdivA = gdivA;
+    tsc::launch_gemm_dyn(tn, epi, a, groups, m->stream);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
+// X1 = relu(obs W1 + b1) ; Z = X1 Wx + bl   for `rows` samples of every group
+int dense_forward(tsc_model *m, const float *obs, long long rows, float *X1, float *Z) {
+    const Layout &L = m->lay;
+    const int AS = L.A * L.SMAX;
+    if (gemm(m, false, tsc::EPI_BIAS_RELU, L.G, (int)rows, L.H, L.SMAX, obs, L.SMAX, AS, 2, m->params + L.oW1,
+             L.stride, L.H, X1, rows * L.H, L.H, m->params + L.ob1, L.stride, nullptr, 0, 0, nullptr, 0, nullptr, 0))
+        return 1;
+    if (gemm(m, false, tsc::EPI_BIAS, L.G, (int)rows, kG4, L.H, X1, rows * L.H, L.H, 1, m->params + L.oWx, L.stride,
+             kG4, Z, rows * kG4, kG4, m->params + L.obl, L.stride, nullptr, 0, 0, nullptr, 0, nullptr, 0))
+        return 1;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+#define MALLOC(ptr, T, count)                                                          \
+    do {                                                                               \
+        TSC_HIP(hipMalloc((void **)&(ptr), sizeof(T) * (size_t)(count)));              \
+        TSC_HIP(hipMemset((ptr), 0, sizeof(T) * (size_t)(count)));                     \
+        m->allocs.push_back((void *)(ptr));                                            \
+    } while (0)
+
+int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, tsc_model **out) {
+    if (!cfg || !out || n_env <= 0) return tsc::fail("tsc_model_create: bad arguments");
+    if (cfg->n_lstm != kL) return tsc::fail("tsc_model_create: num_lstm must be %d", kL);
+    if (cfg->a_max > kOut) return tsc::fail("tsc_model_create: a_max %d > %d", cfg->a_max, kOut);
+    if (cfg->s_max % 4) return tsc::fail("tsc_model_create: s_max must be a multiple of 4");
+    TSC_HIP(hipSetDevice(device));
+    tsc_model *m = new tsc_model();
+    m->device = device; m->stream = nullptr; m->E = n_env; m->T = cfg->n_step;
+    m->gamma = cfg->gamma; m->rnorm = cfg->reward_norm; m->rclip = cfg->reward_clip; m->vcoef = cfg->value_coef;
+    m->max_norm = cfg->max_grad_norm; m->alpha = cfg->rmsp_alpha; m->eps = cfg->rmsp_epsilon;
+    Layout &L = m->lay;
+    L.A = cfg->n_agent; L.G = 2 * L.A; L.SMAX = cfg->s_max; L.AMAX = cfg->a_max;
+    L.H = cfg->n_fc_wave + cfg->n_fc_fp + cfg->n_fc_wait;
+    if (L.H % 4) return tsc::fail("tsc_model_create: hidden width must be a multiple of 4");
+    L.oW1 = 0; L.ob1 = (long long)L.SMAX * L.H; L.oWx = L.ob1 + L.H; L.oWh = L.oWx + (long long)L.H * kG4;
+    L.obl = L.oWh + (long long)kL * kG4; L.oWo = L.obl + kG4; L.obo = L.oWo + kL * kOut; L.stride = L.obo + kOut;
+    m->nparam = L.stride * L.G;
+    // structural mask of W1: obs row j of agent a feeds hidden columns [lo, hi)
+    std::vector<int16_t> rr((size_t)L.A * L.SMAX * 2, 0);
+    const int cw = cfg->n_fc_wave, cf = cfg->n_fc_fp, ct = cfg->n_fc_wait;
+    for (int a = 0; a < L.A; ++a) {
+        const int nw = cfg->n_wave[a], nt = cfg->n_wait[a], nf = cfg->n_fp[a];
+        if (nw + nt + nf > L.SMAX) return tsc::fail("tsc_model_create: agent %d obs wider than s_max", a);
+        for (int j = 0; j < L.SMAX; ++j) {
+            int lo = 0, hi = 0;
+            if (j < nw) { lo = 0; hi = cw; }                                  // fcw
+            else if (j < nw + nt) { lo = cw + cf; hi = cw + cf + ct; }        // fct (after fcf in the concat)
+            else if (j < nw + nt + nf) { lo = cw; hi = cw + cf; }             // fcf
+            rr[((size_t)a * L.SMAX + j) * 2] = (int16_t)lo;
+            rr[((size_t)a * L.SMAX + j) * 2 + 1] = (int16_t)hi;
+        }
+    }
+    TSC_HIP(tsc::upload<int16_t>(&m->rowrange, rr.data(), rr.size())); m->allocs.push_back(m->rowrange);
+    TSC_HIP(tsc::upload<int>(&m->n_act, cfg->n_act, L.A)); m->allocs.push_back(m->n_act);
+    const long long E = n_env, T = m->T, N = E * T, G = L.G, A = L.A;
+    MALLOC(m->params, float, m->nparam); MALLOC(m->grads, float, m->nparam); MALLOC(m->ms, float, m->nparam);
+    MALLOC(m->WxT, float, G * L.H * kG4);
+    MALLOC(m->state_fw, float, G * E * 2 * kL); MALLOC(m->state_bw, float, G * E * 2 * kL);
+    MALLOC(m->state_tmp, float, G * E * 2 * kL);
+    MALLOC(m->r_obs, float, N * A * L.SMAX); MALLOC(m->r_act, int, N * A); MALLOC(m->r_rew, double, N * A);
+    MALLOC(m->r_val, float, N * A); MALLOC(m->r_done, uint8_t, (T + 1) * E);
+    MALLOC(m->Rs, float, N * A); MALLOC(m->Advs, float, N * A);
+    MALLOC(m->X1, float, G * N * L.H); MALLOC(m->Z, float, G * N * kG4);
+    MALLOC(m->Hh, float, G * N * kL); MALLOC(m->Cc, float, G * N * kL); MALLOC(m->Hp, float, G * N * kL);
+    MALLOC(m->dHh, float, G * N * kL); MALLOC(m->dL, float, G * N * kOut);
+    MALLOC(m->norm2, double, A); MALLOC(m->stats, double, A * 4);
+    m->lds_fwd = sizeof(float) * (64 * kWhLd + 64 * kHsLd);
+    m->lds_bwd = sizeof(float) * (kG4 * kWtLd + kG4 * kDzLd);
+    TSC_HIP(hipFuncSetAttribute((const void *)lstm_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fwd));
+    TSC_HIP(hipFuncSetAttribute((const void *)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bwd));
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((m->nparam + 255) / 256)), dim3(256), 0, 0, m->ms, m->nparam, 1.0f);
+    TSC_HIP(hipDeviceSynchronize());
+    *out = m;
+    return 0;
+}
+
+int tsc_model_destroy(tsc_model *m) {
+    if (!m) return 0;
+    (void)hipSetDevice(m->device);
+    for (void *p : m->allocs) (void)hipFree(p);
+    delete m;
+    return 0;
+}
+
+int tsc_model_set_stream(tsc_model *m, void *s) {
+    if (!m) return tsc::fail("null handle");
+    m->stream = (hipStream_t)s;
+    return 0;
+}
+
+int tsc_model_layout(tsc_model *m, int64_t out[12]) {
+    if (!m || !out) return tsc::fail("tsc_model_layout: bad arguments");
+    const Layout &L = m->lay;
+    const int64_t v[12] = {L.G, L.stride, L.H, kL, L.oW1, L.ob1, L.oWx, L.oWh, L.obl, L.oWo, L.obo, kOut};
+    for (int i = 0; i < 12; ++i) out[i] = v[i];
+    return 0;
+}
+
+int tsc_model_set_params(tsc_model *m, const float *h) {
+    if (!m || !h) return tsc::fail("tsc_model_set_params: bad arguments");
+    TSC_HIP(hipStreamSynchronize(m->stream));
+    TSC_HIP(hipMemcpy(m->params, h, sizeof(float) * m->nparam, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((m->nparam + 255) / 256)), dim3(256), 0, m->stream, m->ms, m->nparam, 1.0f);
+    TSC_HIP(hipStreamSynchronize(m->stream));
+    return 0;
+}
+int tsc_model_get_params(tsc_model *m, float *h) {
+    if (!m || !h) return tsc::fail("tsc_model_get_params: bad arguments");
+    TSC_HIP(hipStreamSynchronize(m->stream));
+    TSC_HIP(hipMemcpy(h, m->params, sizeof(float) * m->nparam, hipMemcpyDeviceToHost));
+    return 0;
+}
+int tsc_model_get_opt_state(tsc_model *m, float *h) {
+    if (!m || !h) return tsc::fail("tsc_model_get_opt_state: bad arguments");
+    TSC_HIP(hipStreamSynchronize(m->stream));
+    TSC_HIP(hipMemcpy(h, m->ms, sizeof(float) * m->nparam, hipMemcpyDeviceToHost));
+    return 0;
+}
+int tsc_model_set_opt_state(tsc_model *m, const float *h) {
+    if (!m || !h) return tsc::fail("tsc_model_set_opt_state: bad arguments");
+    TSC_HIP(hipStreamSynchronize(m->stream));
+    TSC_HIP(hipMemcpy(m->ms, h, sizeof(float) * m->nparam, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int tsc_model_reset(tsc_model *m) {
+    if (!m) return tsc::fail("null handle");
+    const size_t b = sizeof(float) * (size_t)m->lay.G * m->E * 2 * kL;
+    TSC_HIP(hipMemsetAsync(m->state_fw, 0, b, m->stream));
+    TSC_HIP(hipMemsetAsync(m->state_bw, 0, b, m->stream));
+    return 0;
+}
+
+int tsc_model_forward(tsc_model *m, const float *obs, const uint8_t *done, float *pi, float *v, int32_t advance) {
+    if (!m || !obs || !done || !pi || !v) return tsc::fail("tsc_model_forward: bad arguments");
+    const Layout &L = m->lay;
+    const int E = m->E;
+    // the rollout forward borrows the head of the training activations (row count E <= T*E)
+    if (dense_forward(m, obs, E, m->X1, m->Z)) return tsc::fail("tsc_model_forward: gemm launch failed");
+    hipLaunchKernelGGL(lstm_fwd_kernel, dim3(L.G, (E + 63) / 64), dim3(256), m->lds_fwd, m->stream, m->params, L, m->Z,
+                       m->state_fw, advance ? m->state_fw : (float *)nullptr, m->Hh, m->Cc, m->Hp, done, 1, E, 0);
+    const long long tot = (long long)E * L.A;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((tot + 127) / 128)), dim3(128), 0, m->stream, m->params, L,
+                       m->n_act, m->Hh, E, pi, v);
+    TSC_HIP(hipGetLastError());
+    return 0;
+}
+
+int tsc_model_sample(tsc_model *m, const float *pi, int32_t *action, uint64_t seed, uint64_t step) {
+    if (!m || !pi || !action) return tsc::fail("tsc_model_sample: bad arguments");
+    const int tot = m->E * m->lay.A;
+    hipLaunchKernelGGL(sample_kernel, dim3((tot + 255) / 256), dim3(256), 0, m->stream, pi, m->n_act, m->E, m->lay.A,
+                       m->lay.AMAX, (unsigned long long)seed, (unsigned long long)step, action);
+    TSC_HIP(hipGetLastError());
+    return 0;
+}
+
+int tsc_model_add_transition(tsc_model *m, int32_t t, const float *obs, const uint8_t *done_pre, const int32_t *action,
+                             const double *reward, const float *value, const uint8_t *done_post) {
+    if (!m || t < 0 || t >= m->T) return tsc::fail("tsc_model_add_transition: slot %d outside [0,%d)", t, m->T);
+    const Layout &L = m->lay;
+    const long long E = m->E, A = L.A, no = E * A * L.SMAX;
+    hipLaunchKernelGGL(add_transition_kernel, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, m->stream, (int)E, (int)A,
+                       L.SMAX, obs, done_pre, action, reward, value, done_post, m->rnorm, m->rclip, m->r_obs + t * no,
+                       m->r_act + t * E * A, m->r_rew + t * E * A, m->r_val + t * E * A, m->r_done + t * E,
+                       m->r_done + (t + 1) * E);
+    TSC_HIP(hipGetLastError());
+    return 0;
+}
+
+int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
+    if (!m || !R_boot) return tsc::fail("tsc_model_compute_grads: bad arguments");
+    const Layout &L = m->lay;
+    const long long E = m->E, T = m->T, N = E * T, A = L.A, G = L.G;
+    const int AS = L.A * L.SMAX;
+    hipStream_t st = m->stream;
+    TSC_HIP(hipMemsetAsync(m->stats, 0, sizeof(double) * A * 4, st));
+    hipLaunchKernelGGL(returns_kernel, dim3((unsigned)((E * A + 255) / 256)), dim3(256), 0, st, m->r_rew, m->r_val, m->r_done,
+                       R_boot, (int)T, (int)E, (int)A, m->gamma, m->Rs, m->Advs);
+    // forward with stored activations, from the backward state (agents/policies.py:144-152)
+    if (dense_forward(m, m->r_obs, N, m->X1, m->Z)) return tsc::fail("gemm launch failed");
+    hipLaunchKernelGGL(lstm_fwd_kernel, dim3((unsigned)G, (unsigned)((E + 63) / 64)), dim3(256), m->lds_fwd, st, m->params, L,
+                       m->Z, m->state_bw, (float *)nullptr, m->Hh, m->Cc, m->Hp, m->r_done, (int)T, (int)E, 1);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((N * A + 127) / 128)), dim3(128), 0, st, m->params, L, m->n_act,
+                       m->Hh, m->r_act, m->Rs, m->Advs, N, (float)m->vcoef, (float)beta, m->dL, m->dHh, m->stats);
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)G, (unsigned)((E + 63) / 64)), dim3(256), m->lds_bwd, st, m->params, L,
+                       m->Z, m->Cc, m->state_bw, m->dHh, m->r_done, (int)T, (int)E);
+    hipLaunchKernelGGL(transpose_wx_kernel, dim3((unsigned)((G * L.H * kG4 + 255) / 256)), dim3(256), 0, st, m->params, L, m->WxT);
+    TSC_HIP(hipGetLastError());
+    float *g = m->grads;
+    // dWo = Hh^T dL (+ dbo) ; dWh = Hp^T dZ (+ dbl) ; dWx = X1^T dZ
+    if (gemm(m, true, tsc::EPI_NONE, (int)G, kL, kOut, (int)N, m->Hh, N * kL, kL, 1, m->dL, N * kOut, kOut, g + L.oWo,
+             L.stride, kOut, nullptr, 0, nullptr, 0, 0, nullptr, 0, g + L.obo, L.stride)) return tsc::fail("gemm failed");
+    if (gemm(m, true, tsc::EPI_NONE, (int)G, kL, kG4, (int)N, m->Hp, N * kL, kL, 1, m->Z, N * kG4, kG4, g + L.oWh, L.stride,
+             kG4, nullptr, 0, nullptr, 0, 0, nullptr, 0, g + L.obl, L.stride)) return tsc::fail("gemm failed");
+    if (gemm(m, true, tsc::EPI_NONE, (int)G, L.H, kG4, (int)N, m->X1, N * L.H, L.H, 1, m->Z, N * kG4, kG4, g + L.oWx, L.stride,
+             kG4, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, 0)) return tsc::fail("gemm failed");
+    // dX1 = (dZ Wx^T) * relu'(X1), in place over X1
+    if (gemm(m, false, tsc::EPI_MASK_POS, (int)G, (int)N, L.H, kG4, m->Z, N * kG4, kG4, 1, m->WxT, (long long)L.H * kG4, L.H,
+             m->X1, N * L.H, L.H, nullptr, 0, m->X1, N * L.H, L.H, nullptr, 0, nullptr, 0)) return tsc::fail("gemm failed");
+    // dW1 = obs^T dX1 masked to the block-diagonal structure (+ db1)
+    if (gemm(m, true, tsc::EPI_ROWRANGE, (int)G, L.SMAX, L.H, (int)N, m->r_obs, L.SMAX, AS, 2, m->X1, N * L.H, L.H, g + L.oW1,
+             L.stride, L.H, nullptr, 0, nullptr, 0, 0, m->rowrange, L.SMAX, g + L.ob1, L.stride)) return tsc::fail("gemm failed");
+    TSC_HIP(hipGetLastError());
+    return 0;
+}
+
+int tsc_model_grad_buffer(tsc_model *m, float **grad, int64_t *count) {
+    if (!m || !grad || !count) return tsc::fail("tsc_model_grad_buffer: bad arguments");
+    *grad = m->grads; *count = m->nparam;
+    return 0;
+}
+
+int tsc_model_apply_grads(tsc_model *m, double lr, double grad_scale, double *stats_host) {
+    if (!m) return tsc::fail("null handle");
+    const Layout &L = m->lay;
+    const long long per_agent = 2 * L.stride;
+    hipStream_t st = m->stream;
+    hipLaunchKernelGGL(grad_norm_kernel, dim3(L.A), dim3(256), 0, st, m->grads, per_agent, grad_scale, m->norm2);
+    hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)((m->nparam + 255) / 256)), dim3(256), 0, st, m->params, m->ms, m->grads,
+                       per_agent, m->nparam, m->norm2, (float)grad_scale, (float)m->max_norm, (float)lr, (float)m->alpha,
+                       (float)m->eps);
+    TSC_HIP(hipGetLastError());
+    // states_bw <- states_fw (policies.py:153); buffer.reset(dones[-1]) (utils.py:227)
+    TSC_HIP(hipMemcpyAsync(m->state_bw, m->state_fw, sizeof(float) * (size_t)L.G * m->E * 2 * kL, hipMemcpyDeviceToDevice, st));
+    TSC_HIP(hipMemcpyAsync(m->r_done, m->r_done + (size_t)m->T * m->E, m->E, hipMemcpyDeviceToDevice, st));
+    if (stats_host) {
+        std::vector<double> s(L.A * 4), n2(L.A);
+        TSC_HIP(hipStreamSynchronize(st));
+        TSC_HIP(hipMemcpy(s.data(), m->stats, sizeof(double) * L.A * 4, hipMemcpyDeviceToHost));
+        TSC_HIP(hipMemcpy(n2.data(), m->norm2, sizeof(double) * L.A, hipMemcpyDeviceToHost));
+        for (int a = 0; a < L.A; ++a) {
+            for (int k = 0; k < 3; ++k) stats_host[a * 4 + k] = s[a * 4 + k];
+            stats_host[a * 4 + 3] = sqrt(n2[a]);
+        }
+    }
+    return 0;
+}
+
+int tsc_model_get_returns(tsc_model *m, float *Rs, float *Advs) {
+    if (!m || !Rs || !Advs) return tsc::fail("tsc_model_get_returns: bad arguments");
+    const size_t n = (size_t)m->T * m->E * m->lay.A;
+    TSC_HIP(hipStreamSynchronize(m->stream));
+    TSC_HIP(hipMemcpy(Rs, m->Rs, sizeof(float) * n, hipMemcpyDeviceToHost));
+    TSC_HIP(hipMemcpy(Advs, m->Advs, sizeof(float) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tsc_gemm_grouped_f32(int32_t form, int32_t epi, int32_t groups, int32_t M, int32_t N, int32_t K, const float *A,
+                         int64_t sA, int32_t lda, const float *B, int64_t sB, int32_t ldb, float *C, int64_t sC,
+                         int32_t ldc, const float *bias, const float *aux, const int16_t *rowrange, float *colsum,
+                         void *hip_stream) {
+    GemmArgs a;
+    a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.rr = rowrange; a.colsum = colsum;
+    a.sA = sA; a.sB = sB; a.sC = sC; a.sBias = N; a.sAux = (long long)M * ldc; a.sRR = M; a.sColsum = N;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldc; a.M = M; a.N = N; a.K = K; a.gdivA = 1;
+    tsc::launch_gemm_dyn(form != 0, epi, a, groups, (hipStream_t)hip_stream);
+    TSC_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -103,6 +103,82 @@ int tsc_env_get_state(tsc_env *h, int32_t e, int32_t *n, float *x, float *v, flo
 /* Mean number of live vehicles per env (roofline bookkeeping). Synchronises. */
 int tsc_env_live_vehicles(tsc_env *h, double *mean_live);
 
+/* ---- model: replaces IA2C / MA2C (agents/models.py:132-262) + LstmACPolicy / FPLstmACPolicy
+ *      (agents/policies.py:75-211) + OnPolicyBuffer (agents/utils.py:182-228) + the TF1 runtime ---- */
+
+typedef struct tsc_model_cfg {
+    int32_t n_agent;          /* A                                                        */
+    int32_t s_max, a_max;     /* padded obs / action widths (= tsc_scenario s_max, p_max) */
+    const int32_t *n_wave;    /* [A] wave inputs   (policy n_s = env n_s - n_w - n_f)      */
+    const int32_t *n_wait;    /* [A] wait inputs   (n_w)                                   */
+    const int32_t *n_fp;      /* [A] fingerprint inputs (n_f; 0 for IA2C)                 */
+    const int32_t *n_act;     /* [A] actions (n_a)                                        */
+    int32_t n_fc_wave, n_fc_wait, n_fc_fp, n_lstm;   /* num_fw, num_ft, num_fp, num_lstm  */
+    int32_t n_step;           /* batch_size: control steps per update                     */
+    double gamma, reward_norm, reward_clip, value_coef, max_grad_norm, rmsp_alpha, rmsp_epsilon;
+} tsc_model_cfg;
+
+typedef struct tsc_model tsc_model;
+
+/* Parameter layout.  Agent-tower group g = 2*agent + tower (0 = pi, 1 = v); every group owns
+ * `stride` consecutive floats: W1[s_max][H] (block-diagonal fcw|fcf|fct, obs rows in env order),
+ * b1[H], Wx[H][4L], Wh[L][4L], bl[4L], Wo[L][8], bo[8]   (H = n_fc_wave+n_fc_fp+n_fc_wait,
+ * L = n_lstm, LSTM gate order i,f,o,u as agents/utils.py:107).  out[] = {G, stride, H, L,
+ * off_W1, off_b1, off_Wx, off_Wh, off_bl, off_Wo, off_bo, out_pad(8)}. */
+int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, tsc_model **out);
+int tsc_model_destroy(tsc_model *m);
+int tsc_model_set_stream(tsc_model *m, void *hip_stream);
+int tsc_model_layout(tsc_model *m, int64_t out[12]);
+int tsc_model_set_params(tsc_model *m, const float *params_host);     /* also resets RMSProp ms to 1 */
+int tsc_model_get_params(tsc_model *m, float *params_host);
+int tsc_model_get_opt_state(tsc_model *m, float *ms_host);
+int tsc_model_set_opt_state(tsc_model *m, const float *ms_host);
+
+/* IA2C.reset (agents/models.py:218-220): zero the forward and backward LSTM states. */
+int tsc_model_reset(tsc_model *m);
+
+/* IA2C.forward (agents/models.py:185-200 -> policies.py:125-136).  obs: dev f32 [E,A,SMAX];
+ * done: dev u8 [E] (pre-decision done, resets the LSTM state); pi: dev f32 [E,A,AMAX] (padded
+ * actions get 0), v: dev f32 [E,A].  advance = 1 <=> out_type contains 'p' (state is advanced);
+ * advance = 0 <=> out_type 'v' (bootstrap value, state untouched, policies.py:127-135). */
+int tsc_model_forward(tsc_model *m, const float *obs_dev, const uint8_t *done_dev, float *pi_dev,
+                      float *v_dev, int32_t advance);
+
+/* np.random.choice(n_a, p=pi) per agent (utils.py:155-157) with a counter-based generator:
+ * u = U(seed, step, e, a); action = searchsorted(cumsum(pi)/sum, u, right). action: dev i32 [E,A]. */
+int tsc_model_sample(tsc_model *m, const float *pi_dev, int32_t *action_dev, uint64_t seed, uint64_t step);
+
+/* IA2C.add_transition (agents/models.py:222-229): reward / reward_norm, clip, store
+ * (obs, action, reward, value, done) at slot t of the on-policy buffer.  reward: dev f64 [E,A]. */
+int tsc_model_add_transition(tsc_model *m, int32_t t, const float *obs_dev, const uint8_t *done_pre_dev,
+                             const int32_t *action_dev, const double *reward_dev, const float *value_dev,
+                             const uint8_t *done_post_dev);
+
+/* IA2C.backward part 1 (agents/models.py:174-183 -> utils.py:202-228 -> policies.py:41-57,138-152):
+ * n-step returns/advantages (float64, bootstrap R_boot dev f32 [E,A], ignored where the last
+ * transition was terminal), BPTT through the n_step-unrolled LSTM from the saved backward state,
+ * loss, gradients.  Gradients land in the contiguous buffer tsc_model_grad_buffer() returns
+ * (same layout as the parameters) so the caller can all-reduce it over RCCL. */
+int tsc_model_compute_grads(tsc_model *m, const float *R_boot_dev, double entropy_beta);
+int tsc_model_grad_buffer(tsc_model *m, float **grad_dev, int64_t *count);
+
+/* IA2C.backward part 2 (policies.py:57-61): per-agent clip_by_global_norm(max_grad_norm) on
+ * grad * grad_scale, TF1 RMSPropOptimizer step, states_bw <- states_fw (policies.py:153),
+ * buffer reset carrying the last done (utils.py:227).  stats_host (nullable): per agent
+ * {policy_loss, value_loss, entropy_loss, grad_norm} float64 [A,4]. */
+int tsc_model_apply_grads(tsc_model *m, double lr, double grad_scale, double *stats_host);
+
+/* Debug / parity access: the float32 returns and advantages [n_step, E, A] the last
+ * tsc_model_compute_grads() fed to the loss (agents/utils.py:223-224). Synchronises. */
+int tsc_model_get_returns(tsc_model *m, float *Rs_host, float *Advs_host);
+
+/* Test hook: the grouped fp32 MFMA GEMM used by every layer.  form: 0 = NN, 1 = TN; epi as
+ * csrc/tsc_gemm.h.  All pointers device; strides in elements. */
+int tsc_gemm_grouped_f32(int32_t form, int32_t epi, int32_t groups, int32_t M, int32_t N, int32_t K,
+                         const float *A, int64_t sA, int32_t lda, const float *B, int64_t sB, int32_t ldb,
+                         float *C, int64_t sC, int32_t ldc, const float *bias, const float *aux,
+                         const int16_t *rowrange, float *colsum, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

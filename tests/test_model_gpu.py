@@ -1,0 +1,227 @@
+"""GPU parity of the HIP learner path (csrc/tsc_model.hip, csrc/tsc_gemm.h through the C-ABI)
+against the CPU oracle (oracle/nets_oracle.py, float64 restatement of agents/policies.py +
+agents/utils.py) and against known answers recorded from the reference's OnPolicyBuffer.
+
+Tolerances (floating point, fp32 kernels vs float64 oracle): forward outputs |d| <= 2e-5;
+gradients |d| <= 2e-3 * max|g| per tensor (fp32 accumulation over T*E samples through a T-step
+BPTT); returns/advantages bit-exact (float64 recursion on both sides)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from deeprl_signal_control_amd.scenario import build_large_grid
+
+pytestmark = pytest.mark.gpu
+
+
+def _vp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _gemm(form, epi, A, B, C_, M, N, K, lda, ldb, ldc, sA, sB, sC, groups, bias=None, aux=None, rr=None, colsum=None):
+    from deeprl_signal_control_amd import _lib
+    from deeprl_signal_control_amd.agents import _setup_lib
+    L = _lib.lib()
+    _setup_lib(L)
+    _lib.check(L.tsc_gemm_grouped_f32(form, epi, groups, M, N, K, _vp(A), sA, lda, _vp(B), sB, ldb, _vp(C_), sC, ldc,
+                                      _vp(bias), _vp(aux), _vp(rr), _vp(colsum),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('M,N,K,G', [(300, 224, 52, 3), (128, 256, 224, 2), (1000, 8, 64, 2), (77, 100, 36, 1)])
+def test_gemm_nn(M, N, K, G):
+    rng = np.random.RandomState(M + N)
+    A = rng.randn(G, M, K).astype(np.float32); B = rng.randn(G, K, N).astype(np.float32)
+    bias = rng.randn(G, N).astype(np.float32)
+    dA, dB, db = (torch.from_numpy(x).cuda() for x in (A, B, bias))
+    ref = np.einsum('gmk,gkn->gmn', A.astype(np.float64), B.astype(np.float64))
+    tol = 1e-5 * K
+    for epi, want in ((0, ref), (1, ref + bias[:, None, :]), (2, np.maximum(ref + bias[:, None, :], 0))):
+        out = torch.full((G, M, N), 7.0, device='cuda')
+        _gemm(0, epi, dA, dB, out, M, N, K, K, N, N, M * K, K * N, M * N, G, bias=db)
+        np.testing.assert_allclose(out.cpu().numpy(), want, atol=tol, rtol=1e-5)
+    # relu-backward mask epilogue, in place over aux
+    aux = rng.randn(G, M, N).astype(np.float32)
+    d_aux = torch.from_numpy(aux).cuda()
+    _gemm(0, 3, dA, dB, d_aux, M, N, K, K, N, N, M * K, K * N, M * N, G, aux=d_aux)
+    np.testing.assert_allclose(d_aux.cpu().numpy(), ref * (aux > 0), atol=tol, rtol=1e-5)
+
+
+@pytest.mark.parametrize('Kred,M,N,G', [(1000, 52, 224, 2), (512, 64, 256, 2), (333, 64, 8, 3), (4096, 224, 256, 1)])
+def test_gemm_tn_colsum_rowrange(Kred, M, N, G):
+    rng = np.random.RandomState(Kred)
+    A = rng.randn(G, Kred, M).astype(np.float32); B = rng.randn(G, Kred, N).astype(np.float32)
+    dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+    ref = np.einsum('gkm,gkn->gmn', A.astype(np.float64), B.astype(np.float64))
+    out = torch.zeros(G, M, N, device='cuda'); cs = torch.zeros(G, N, device='cuda')
+    _gemm(1, 0, dA, dB, out, M, N, Kred, M, N, N, Kred * M, Kred * N, M * N, G, colsum=cs)
+    tol = 2e-6 * Kred
+    np.testing.assert_allclose(out.cpu().numpy(), ref, atol=tol, rtol=1e-4)
+    np.testing.assert_allclose(cs.cpu().numpy(), B.astype(np.float64).sum(1), atol=tol, rtol=1e-4)
+    rr = np.zeros((G, M, 2), np.int16)
+    rr[:, :, 0] = rng.randint(0, N // 2, (G, M)); rr[:, :, 1] = rr[:, :, 0] + rng.randint(0, N // 2, (G, M))
+    out2 = torch.zeros(G, M, N, device='cuda')
+    _gemm(1, 4, dA, dB, out2, M, N, Kred, M, N, N, Kred * M, Kred * N, M * N, G, rr=torch.from_numpy(rr).cuda())
+    n = np.arange(N)[None, None, :]
+    mask = (n >= rr[:, :, :1]) & (n < rr[:, :, 1:])
+    np.testing.assert_allclose(out2.cpu().numpy(), ref * mask, atol=tol, rtol=1e-4)
+
+
+def _make(agent, E, n_step, seed=0, **cfg):
+    from deeprl_signal_control_amd.agents import VecA2C
+    from oracle.nets_oracle import OracleA2C
+    scn = build_large_grid(agent)
+    mc = dict(batch_size=n_step)
+    mc.update(cfg)
+    m = VecA2C(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, scn.n_f_ls, E, scn.s_max, 5, mc, device=0, seed=seed, name=agent)
+    o = OracleA2C(m.get_tower_params(), m.n_wave_ls, m.n_w_ls, m.n_f_ls, m.n_a_ls, E,
+                  gamma=m.cfg['gamma'], reward_norm=m.cfg['reward_norm'], reward_clip=m.cfg['reward_clip'],
+                  value_coef=m.cfg['value_coef'], max_grad_norm=m.cfg['max_grad_norm'])
+    return scn, m, o
+
+
+def _rand_obs(scn, E, rng):
+    obs = np.zeros((E, scn.n_agent, scn.s_max), np.float32)
+    for a, n in enumerate(scn.n_s_ls):
+        obs[:, a, :n] = rng.rand(E, n).astype(np.float32) * 2
+    return obs
+
+
+@pytest.mark.parametrize('agent,E', [('ma2c', 5), ('ia2c', 70)])
+def test_forward_matches_oracle(agent, E):
+    scn, m, o = _make(agent, E, 4)
+    rng = np.random.RandomState(1)
+    m.reset(); o.reset()
+    for t in range(5):
+        obs = _rand_obs(scn, E, rng)
+        done = (rng.rand(E) < (1.0 if t == 0 else 0.3)).astype(np.uint8)
+        pi, v = m.forward(torch.from_numpy(obs).cuda(), torch.from_numpy(done).cuda(), 'pv')
+        pi, v = pi.cpu().numpy(), v.cpu().numpy()
+        opi, ov = o.forward(obs, done, 'pv')
+        for a in range(scn.n_agent):
+            np.testing.assert_allclose(pi[:, a, :scn.n_a_ls[a]], opi[a], atol=2e-5, err_msg='pi t=%d a=%d' % (t, a))
+        np.testing.assert_allclose(v, ov, atol=2e-5)
+        assert np.allclose(pi.sum(-1), 1.0, atol=1e-5)
+    # bootstrap value: state must NOT advance (policies.py:127-135)
+    obs = _rand_obs(scn, E, rng)
+    vb = m.forward(torch.from_numpy(obs).cuda(), False, 'v').cpu().numpy()
+    _, ovb = o.forward(obs, np.zeros(E), 'v')
+    np.testing.assert_allclose(vb, ovb, atol=2e-5)
+    vb2 = m.forward(torch.from_numpy(obs).cuda(), False, 'v').cpu().numpy()
+    np.testing.assert_array_equal(vb, vb2)
+    m.close()
+
+
+def test_sampling_is_numpy_choice_on_documented_uniform():
+    from oracle.nets_oracle import choice_from_uniform, sample_uniform
+    scn, m, o = _make('ma2c', 16, 4, seed=11)
+    rng = np.random.RandomState(2)
+    pi = rng.dirichlet(np.ones(5), size=(16, 25)).astype(np.float32)
+    pi[3, 4] = [0, 0, 1, 0, 0]
+    for step in range(3):
+        act = m.sample(torch.from_numpy(pi).cuda()).cpu().numpy()
+        for e in range(16):
+            for a in range(25):
+                u = sample_uniform(11, step, e * 25 + a)
+                assert act[e, a] == choice_from_uniform(pi[e, a], u)
+    assert act[3, 4] == 2
+    counts = np.zeros(5)
+    big = np.tile(np.array([0.1, 0.2, 0.3, 0.25, 0.15], np.float32), (16, 25, 1))
+    for step in range(200):
+        a = m.sample(torch.from_numpy(big).cuda()).cpu().numpy()
+        counts += np.bincount(a.ravel(), minlength=5)
+    np.testing.assert_allclose(counts / counts.sum(), big[0, 0], atol=0.01)
+    m.close()
+
+
+def _fill(scn, m, o, E, T, rng, p_done=0.1, terminal=False):
+    obs = _rand_obs(scn, E, rng)
+    done = np.ones(E, np.uint8)
+    for t in range(T):
+        pi, v = m.forward(torch.from_numpy(obs).cuda(), torch.from_numpy(done).cuda(), 'pv')
+        v = v.cpu().numpy()
+        o.forward(obs, done, 'pv')
+        act = rng.randint(0, 5, (E, scn.n_agent)).astype(np.int32)
+        rew = -rng.rand(E, scn.n_agent) * 6000.0
+        dpost = (rng.rand(E) < p_done).astype(np.uint8)
+        if terminal and t == T - 1:
+            dpost[:] = 1
+        m.add_transition(torch.from_numpy(obs).cuda(), torch.from_numpy(done).cuda(), torch.from_numpy(act).cuda(),
+                         torch.from_numpy(rew).cuda(), torch.from_numpy(v).cuda(), torch.from_numpy(dpost).cuda())
+        o.add_transition(obs, done, act, rew, v, dpost)
+        obs, done = _rand_obs(scn, E, rng), dpost
+    return obs, done
+
+
+@pytest.mark.parametrize('agent,E,T,terminal', [('ma2c', 3, 6, False), ('ma2c', 66, 8, True), ('ia2c', 4, 40, False)])
+def test_backward_matches_oracle(agent, E, T, terminal):
+    scn, m, o = _make(agent, E, T, seed=5)
+    rng = np.random.RandomState(E * T)
+    m.reset(); o.reset()
+    from deeprl_signal_control_amd import _lib
+    for it in range(2):                                       # second round exercises states_bw / carried done
+        obs, done = _fill(scn, m, o, E, T, rng, terminal=terminal and it == 0)
+        Rb = m.forward(torch.from_numpy(obs).cuda(), False, 'v').clone()
+        _, oRb = o.forward(obs, np.zeros(E), 'v')
+        Rb_np = Rb.cpu().numpy()
+        beta = 0.01
+        _lib.check(m._L.tsc_model_compute_grads(m._h, C.c_void_p(Rb.data_ptr()), beta))
+        ograds, ostats = o.compute_grads(Rb_np, beta)
+        Rs = np.zeros((T, E, scn.n_agent), np.float32); Advs = np.zeros_like(Rs)
+        _lib.check(m._L.tsc_model_get_returns(m._h, Rs.ctypes.data_as(C.c_void_p), Advs.ctypes.data_as(C.c_void_p)))
+        np.testing.assert_array_equal(Rs, o.Rs)               # float64 recursion on both sides
+        np.testing.assert_array_equal(Advs, o.Advs)
+        g = m.unpack(m.grad_tensor().cpu().numpy())
+        for t in range(m.G):
+            for k, og in ograds[t].items():
+                og = og.numpy()
+                scale = max(np.abs(og).max(), 1e-7)
+                np.testing.assert_allclose(g[t][k], og, atol=2e-3 * scale, rtol=0, err_msg='it=%d tower=%d %s' % (it, t, k))
+        # structural zeros of the block-diagonal FC must have exactly zero gradient
+        flat = m.grad_tensor().cpu().numpy().reshape(m.G, m.stride)
+        packed = m.pack(g).reshape(m.G, m.stride)
+        np.testing.assert_array_equal(flat, packed)
+        stats = np.zeros((scn.n_agent, 4))
+        _lib.check(m._L.tsc_model_apply_grads(m._h, 5e-4, 1.0, stats.ctypes.data_as(C.c_void_p)))
+        m.cur_t = 0
+        onorm = o.apply_grads(ograds, 5e-4)
+        np.testing.assert_allclose(stats[:, :3], ostats, rtol=2e-3, atol=1e-6)
+        np.testing.assert_allclose(stats[:, 3], onorm, rtol=2e-3)
+        p, op = m.get_tower_params(), o.tower_params()
+        for t in range(m.G):
+            for k in op[t]:
+                np.testing.assert_allclose(p[t][k], op[t][k], atol=3e-5, err_msg='param tower=%d %s' % (t, k))
+    m.close()
+
+
+def test_returns_match_reference_buffer_on_gpu(golden_dir):
+    """Feed the reference OnPolicyBuffer known answers through add_transition + returns kernel."""
+    from deeprl_signal_control_amd import _lib
+    g = np.load(os.path.join(golden_dir, 'learner_known_answers.npz'))
+    for c in ('c0', 'c1', 'c2', 'c3'):
+        r, v, dpost = g[c + '_r'], g[c + '_v'], g[c + '_done_post'].astype(np.uint8)
+        T = len(r)
+        scn, m, _ = _make('ma2c', 1, T, reward_norm=0.0, reward_clip=0.0)
+        obs = torch.zeros(1, 25, scn.s_max, device='cuda')
+        dpre = np.concatenate([[int(g[c + '_done0'])], dpost[:-1]]).astype(np.uint8)
+        for t in range(T):
+            m.add_transition(obs, torch.tensor([dpre[t]], dtype=torch.uint8, device='cuda'),
+                             torch.zeros(1, 25, dtype=torch.int32, device='cuda'),
+                             torch.full((1, 25), float(r[t]), dtype=torch.float64, device='cuda'),
+                             torch.full((1, 25), float(v[t]), dtype=torch.float32, device='cuda'),
+                             torch.tensor([dpost[t]], dtype=torch.uint8, device='cuda'))
+        Rb = torch.full((1, 25), float(g[c + '_R']), dtype=torch.float32, device='cuda')
+        _lib.check(m._L.tsc_model_compute_grads(m._h, C.c_void_p(Rb.data_ptr()), 0.01))
+        Rs = np.zeros((T, 1, 25), np.float32); Advs = np.zeros_like(Rs)
+        _lib.check(m._L.tsc_model_get_returns(m._h, Rs.ctypes.data_as(C.c_void_p), Advs.ctypes.data_as(C.c_void_p)))
+        if abs(float(np.float32(g[c + '_R'])) - float(g[c + '_R'])) == 0 or dpost[-1]:
+            np.testing.assert_array_equal(Rs[:, 0, 7], g[c + '_Rs'])
+            np.testing.assert_array_equal(Advs[:, 0, 7], g[c + '_Advs'])
+        else:                                                  # bootstrap passed as float32 (TF output)
+            np.testing.assert_allclose(Rs[:, 0, 7], g[c + '_Rs'], rtol=1e-6)
+            np.testing.assert_allclose(Advs[:, 0, 7], g[c + '_Advs'], rtol=1e-5, atol=1e-6)
+        m.close()

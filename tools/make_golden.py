@@ -116,7 +116,9 @@ def learner_fixtures():
         vs = rng.randn(n).astype(np.float32)
         acts = rng.randint(0, 5, n)
         for t in range(n):
-            buf.add_transition(np.zeros(3), int(acts[t]), float(rs[t]), vs[t], t == done_at)
+            # v goes in as a Python float: under the reference's NumPy 1.x `R - v` (utils.py:208) is a
+            # float64 subtraction; NumPy 2's weak-scalar promotion would silently make it float32.
+            buf.add_transition(np.zeros(3), int(acts[t]), float(rs[t]), float(vs[t]), t == done_at)
         R = 0.0 if done_at == n - 1 else float(rng.randn())
         obs, a, dones, Rs, Advs = buf.sample_transition(R)
         cases['c%d' % ci] = dict(r=rs, v=vs, done_post=np.array([t == done_at for t in range(n)]),
