@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""bench.py -- env-steps/s of the full on-policy A2C hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A "step" is one A2C iteration of the reference's training loop (utils.py:284-295) over one batch
+of env instances: n_step = 120 control steps (= 600 simulated seconds) of every env instance --
+policy forward, fingerprint push, action sampling, microsimulator step, transition store -- plus
+the n-step-return / BPTT / clip / RMSProp update (and, for N > 1, one RCCL all-reduce of the flat
+gradient buffer).  Workload = BASELINE.json configs[2], the config its metric is quoted on:
+large_grid 5x5, MA2C (FPLstmACPolicy), 1024 env instances per GPU, synthetic demand exactly as the
+reference generator emits it, random-init (ortho) weights.
+
+    value = agents x env instances (all ranks) x simulated seconds / wall time     [env-steps/s]
+
+Adds `roofline` (dominant kernel, timed live with HIP events on the launch stream) and
+`cpu_baseline` (the CPU oracle -- C microsim + NumPy env wrapper + torch-CPU nets -- on a bounded
+sample of the same workload, rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
+
+
+def algorithmic_flops(model, rows):
+    """Per-launch ALGORITHMIC flops of every dense kernel for `rows` samples per agent-tower
+    (per agent-tower MACs = n_wave*128 + n_fp*64 + n_wait*32 + H*256 + 64*256 + 64*n_out)."""
+    fw, fp, ft = model.n_fc
+    fc = sum(2 * (nw * fw + nf * fp + nt * ft) for nw, nf, nt in zip(model.n_wave_ls, model.n_f_ls, model.n_w_ls)) * 2
+    H, L, G = model.H, model.Lh, model.G
+    out = sum(2 * L * (na + 1) for na in model.n_a_ls)
+    return {'fc_gemm': fc * rows, 'zx_gemm': G * 2 * H * 4 * L * rows, 'lstm_fwd': G * 2 * L * 4 * L * rows,
+            'lstm_bwd': G * 2 * L * 4 * L * rows, 'dwx_gemm': G * 2 * H * 4 * L * rows,
+            'dx1_gemm': G * 2 * H * 4 * L * rows, 'dwh_gemm': G * 2 * L * 4 * L * rows, 'dw1_gemm': fc * rows,
+            'dwo_gemm': out * rows}
+
+
+def cpu_baseline(n_env=2, n_step=120):
+    """Same iteration on the host: oracle/ (test infrastructure) = C microsim + NumPy restatement of
+    envs/env.py + torch-CPU restatement of agents/policies.py.  Bounded sample: n_env env instances,
+    one iteration (n_step control steps + update)."""
+    from deeprl_signal_control_amd.agents import VecA2C  # noqa: F401  (layout helper only)
+    from deeprl_signal_control_amd.scenario import build_large_grid
+    from oracle.env_oracle import OracleEnv
+    from oracle.nets_oracle import OracleA2C, choice_from_uniform
+    from deeprl_signal_control_amd.agents import ortho_init
+    scn = build_large_grid('ma2c')
+    rng = np.random.RandomState(0)
+    nw = [s - w - f for s, w, f in zip(scn.n_s_ls, scn.n_w_ls, scn.n_f_ls)]
+    towers = []
+    for a in range(scn.n_agent):
+        for tower in ('pi', 'v'):
+            p = {'fcw_w': ortho_init((nw[a], 128), rng), 'fcw_b': np.zeros(128, np.float32),
+                 'fcf_w': ortho_init((scn.n_f_ls[a], 64), rng), 'fcf_b': np.zeros(64, np.float32),
+                 'fct_w': ortho_init((scn.n_w_ls[a], 32), rng), 'fct_b': np.zeros(32, np.float32),
+                 'lstm_wx': ortho_init((224, 256), rng), 'lstm_wh': ortho_init((64, 256), rng),
+                 'lstm_b': np.zeros(256, np.float32)}
+            n_out = scn.n_a_ls[a] if tower == 'pi' else 1
+            p['out_w'] = ortho_init((64, n_out), rng); p['out_b'] = np.zeros(n_out, np.float32)
+            towers.append(p)
+    envs = [OracleEnv(scn, seed=12 + e) for e in range(n_env)]
+    model = OracleA2C(towers, nw, scn.n_w_ls, scn.n_f_ls, scn.n_a_ls, n_env)
+    t0 = time.perf_counter()
+    obs = [e.reset() for e in envs]
+    done = np.ones(n_env)
+    S = scn.s_max
+
+    def pack(obs):
+        o = np.zeros((n_env, scn.n_agent, S))
+        for e in range(n_env):
+            for a in range(scn.n_agent):
+                o[e, a, :len(obs[e][a])] = obs[e][a]
+        return o
+    for t in range(n_step):
+        ob = pack(obs)
+        pis, v = model.forward(ob, done, 'pv')
+        acts = np.zeros((n_env, scn.n_agent), np.int64)
+        rew = np.zeros((n_env, scn.n_agent))
+        dpost = np.zeros(n_env)
+        for e in range(n_env):
+            envs[e].update_fingerprint([pis[a][e] for a in range(scn.n_agent)])
+            acts[e] = [choice_from_uniform(pis[a][e], rng.rand()) for a in range(scn.n_agent)]
+            obs[e], r, d, _ = envs[e].step(list(acts[e]))
+            rew[e], dpost[e] = r, d
+        model.add_transition(ob, done, acts, rew, v, dpost)
+        done = dpost
+    _, R = model.forward(pack(obs), np.zeros(n_env), 'v')
+    grads, _ = model.compute_grads(R, 0.01)
+    model.apply_grads(grads, 5e-4)
+    dt = time.perf_counter() - t0
+    steps = scn.n_agent * n_env * n_step * scn.control_interval_sec
+    return {'value': steps / dt, 'unit': 'env-steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': 'oracle/ (C microsim + NumPy env wrapper + float64 torch-CPU nets): %d env instances x %d control '
+                      'steps + 1 update, %.1f s' % (n_env, n_step, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=6)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--envs', type=int, default=1024, help='env instances per GPU')
+    ap.add_argument('--agent', default='ma2c', choices=['ma2c', 'ia2c'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local)
+        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+    assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world)
+    torch.cuda.set_device(local)
+
+    from deeprl_signal_control_amd import _lib
+    from deeprl_signal_control_amd.agents import VecA2C
+    from deeprl_signal_control_amd.env import VecTrafficEnv
+    from deeprl_signal_control_amd.scenario import build_large_grid
+    from deeprl_signal_control_amd.trainer import VecTrainer
+
+    E = args.envs
+    scn = build_large_grid(args.agent)
+    mcfg = dict(reward_norm=2000.0 if args.agent == 'ma2c' else 3000.0)
+    env = VecTrafficEnv(scn, E, device=local, seed=12 + rank * E, seed_stride=E * world)
+    model = VecA2C(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, scn.n_f_ls, E, scn.s_max, 5, mcfg, device=local, seed=0,
+                   name=args.agent)
+    model.sample_seed = 1000 + rank
+    tr = VecTrainer(env, model)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        tr.run_iteration()
+    sync()
+    live = []
+    if not args.no_profile:
+        _lib.profile(enable=True, reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.run_iteration()
+    sync()
+    dt = time.perf_counter() - t0
+    prof = {} if args.no_profile else _lib.profile()
+    _lib.profile(enable=False)
+    live.append(env.mean_live_vehicles())
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        n_step, ctrl = model.n_step, scn.control_interval_sec
+        env_steps = scn.n_agent * E * world * n_step * ctrl * args.steps
+        out = {'metric': 'env-steps/s (agents x envs x sim-steps/s), large_grid %s' % args.agent.upper(),
+               'value': env_steps / dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
+               'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'large_grid 5x5 (25 agents), %s LSTM (neighbour fingerprint gather), %d env '
+                                      'instances per GPU; step = %d control steps (x%d sim-steps) of every instance + 1 '
+                                      'A2C update (BPTT, clip, RMSProp%s)'
+                                      % (args.agent.upper(), E, n_step, ctrl, ', RCCL grad all-reduce' if world > 1 else ''),
+                          'envs_per_gpu': E, 'n_step': n_step, 'agents': scn.n_agent,
+                          'parallelism': 'env-sharded x%d' % world, 'mean_live_vehicles_per_env': live[-1],
+                          'mean_step_reward': tr.mean_step_reward()}}
+        if prof:
+            total = sum(ms for ms, _ in prof.values())
+            dom = max(prof, key=lambda k: prof[k][0])
+            ms, cnt = prof[dom]
+            avg_s = ms / cnt * 1e-3
+            kern = {k: {'ms_total': round(v[0], 3), 'launches': v[1]} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+            if dom == 'env_step':
+                V, Ln, A = live[-1], scn.n_lane, scn.n_agent           # 32 V + 16 L + A*52/5 B per env-sim-step
+                bytes_launch = (32.0 * V + 16.0 * Ln + A * 52.0 / 5.0) * ctrl * E
+                ach = bytes_launch / avg_s / 1e9
+                roof = {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                        'frac': ach / PEAK_HBM_GBS, 'traffic': None}
+            else:
+                rows = E * n_step if dom not in ('fc_gemm', 'zx_gemm', 'lstm_fwd') else None
+                fl = algorithmic_flops(model, E * n_step)
+                if dom in ('fc_gemm', 'zx_gemm', 'lstm_fwd'):
+                    # launched both per control step (rows = E) and once per update (rows = E * n_step)
+                    calls_small = args.steps * (n_step + 1) if dom != 'lstm_fwd' else args.steps * (n_step + 1)
+                    tot_fl = fl[dom] * args.steps + algorithmic_flops(model, E)[dom] * (cnt - args.steps)
+                    ach = tot_fl / (ms * 1e-3) / 1e12
+                else:
+                    ach = fl.get(dom, 0.0) / avg_s / 1e12
+                roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
+                        'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None}
+            roof['avg_launch_ms'] = ms / cnt
+            roof['share_of_kernel_time'] = ms / total
+            roof['kernel_time_ms_total'] = total
+            out['roofline'] = roof
+            out['kernels'] = kern
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -36,7 +36,8 @@ class TscScenario(C.Structure):
 _LIB = None
 
 # every symbol include/tsc.h declares (tests/test_abi.py checks the header against this list)
-SYMBOLS = ['tsc_last_error', 'tsc_version', 'tsc_env_create', 'tsc_env_destroy', 'tsc_env_set_stream',
+SYMBOLS = ['tsc_last_error', 'tsc_version', 'tsc_profile_enable', 'tsc_profile_reset', 'tsc_profile_read',
+           'tsc_profile_name', 'tsc_env_create', 'tsc_env_destroy', 'tsc_env_set_stream',
            'tsc_env_reset', 'tsc_env_set_fingerprint', 'tsc_env_step', 'tsc_env_get_state',
            'tsc_env_live_vehicles',
            'tsc_model_create', 'tsc_model_destroy', 'tsc_model_set_stream', 'tsc_model_layout',
@@ -59,6 +60,10 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.tsc_last_error.restype = C.c_char_p
+    L.tsc_profile_name.restype = C.c_char_p
+    L.tsc_profile_name.argtypes = [C.c_int32]
+    L.tsc_profile_enable.argtypes = [C.c_int32]
+    L.tsc_profile_read.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.tsc_env_create.argtypes = [C.POINTER(TscScenario), C.c_int32, C.c_int32, C.POINTER(vp)]
     L.tsc_env_destroy.argtypes = [vp]
     L.tsc_env_set_stream.argtypes = [vp, vp]
@@ -113,3 +118,24 @@ def scenario_struct(scn):
         coop_gamma=scn.coop_gamma, norm_wave=scn.norm_wave, norm_wait=scn.norm_wait,
         clip_wave=scn.clip_wave, clip_wait=scn.clip_wait, coef_wait=scn.coef_wait)
     return s, keep
+
+
+def profile(enable=None, reset=False):
+    """Per-kernel HIP-event timings of the library: returns {name: (total_ms, count)}."""
+    L = lib()
+    if enable is not None:
+        check(L.tsc_profile_enable(int(bool(enable))))
+    if reset:
+        check(L.tsc_profile_reset())
+        return {}
+    out, i = {}, 0
+    while True:
+        name = L.tsc_profile_name(i).decode()
+        if not name:
+            break
+        ms, cnt = C.c_double(), C.c_int64()
+        check(L.tsc_profile_read(i, C.byref(ms), C.byref(cnt)))
+        if cnt.value:
+            out[name] = (ms.value, cnt.value)
+        i += 1
+    return out

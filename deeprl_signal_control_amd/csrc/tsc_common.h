@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 namespace tsc {
 
@@ -34,5 +35,43 @@ inline hipError_t upload(T **dst, const T *src, size_t count) {
     if (count) e = hipMemcpy(*dst, src, sizeof(T) * count, hipMemcpyHostToDevice);
     return e;
 }
+
+
+// ---- per-kernel timing with HIP events (bench.py's live roofline figure) -------------------------
+// Off by default.  When on, every launch site brackets its kernel with two events on the launch
+// stream; tsc_profile_read() synchronises and folds the elapsed times per kernel id.
+enum KernelId : int {
+    KID_ENV_STEP = 0, KID_FC_GEMM, KID_ZX_GEMM, KID_LSTM_FWD, KID_HEAD_FWD, KID_SAMPLE, KID_ADD_TRANS,
+    KID_RETURNS, KID_HEAD_BWD, KID_LSTM_BWD, KID_DWO_GEMM, KID_DWH_GEMM, KID_DWX_GEMM, KID_DX1_GEMM,
+    KID_DW1_GEMM, KID_GRADNORM, KID_RMSPROP, KID_TRANSPOSE, KID_FINGERPRINT, KID_COUNT
+};
+
+struct ProfState {
+    bool on = false;
+    struct Rec { int id; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    double total_ms[KID_COUNT] = {0};
+    long long count[KID_COUNT] = {0};
+};
+ProfState &prof();          // defined in tsc_env.hip
+
+struct ProfScope {
+    int id; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(int id_, hipStream_t st_) : id(id_), st(st_) {
+        ProfState &p = prof();
+        if (!p.on) return;
+        auto get = [&]() { hipEvent_t e; if (!p.pool.empty()) { e = p.pool.back(); p.pool.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
+        a = get(); b = get();
+        (void)hipEventRecord(a, st);
+    }
+    void stop() {
+        if (!a) return;
+        (void)hipEventRecord(b, st);
+        prof().recs.push_back({id, a, b});
+        a = nullptr;
+    }
+    ~ProfScope() { stop(); }
+};
 
 }  // namespace tsc

@@ -244,9 +244,18 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             int ncross = 0;
             bool all_crossed = true;
             float pnx = INFINITY, pox = 0.0f, pov = 0.0f;
+            // software prefetch: vehicle i+1 is loaded while vehicle i is being advanced (slot i+1 is never
+            // the slot being written, kept <= i)
+            float nx = 0.f, nv = 0.f, nsf = 0.f;
+            uint32_t nm = 0u;
+            if (n > 0) { nx = X[l]; nv = V[l]; nsf = SF[l]; nm = M[l]; }
             for (int i = 0; i < n; ++i) {
-                const float x = X[i * NLP + l], v = V[i * NLP + l], sf = SF[i * NLP + l];
-                const uint32_t meta = M[i * NLP + l];
+                const float x = nx, v = nv, sf = nsf;
+                const uint32_t meta = nm;
+                if (i + 1 < n) {
+                    const int o1 = (i + 1) * NLP + l;
+                    nx = X[o1]; nv = V[o1]; nsf = SF[o1]; nm = M[o1];
+                }
                 int w = (int)(meta & 0xFFFFu);
                 const int r = (int)(meta >> 16);
                 const float v0 = vmax * sf;
@@ -452,9 +461,50 @@ struct tsc_env {
     uint32_t *d_seeds;
 };
 
+namespace tsc {
+ProfState &prof() { static ProfState p; return p; }
+}  // namespace tsc
+
 extern "C" {
 
 const char *tsc_last_error(void) { return tsc::err_buf(); }
+
+int tsc_profile_enable(int32_t on) { tsc::prof().on = on != 0; return 0; }
+
+static int prof_fold() {
+    tsc::ProfState &p = tsc::prof();
+    for (auto &r : p.recs) {
+        TSC_HIP(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        TSC_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        p.total_ms[r.id] += ms; p.count[r.id] += 1;
+        p.pool.push_back(r.a); p.pool.push_back(r.b);
+    }
+    p.recs.clear();
+    return 0;
+}
+
+int tsc_profile_reset(void) {
+    if (prof_fold()) return 1;
+    tsc::ProfState &p = tsc::prof();
+    for (int i = 0; i < tsc::KID_COUNT; ++i) { p.total_ms[i] = 0; p.count[i] = 0; }
+    return 0;
+}
+
+int tsc_profile_read(int32_t kernel_id, double *total_ms, int64_t *count) {
+    if (kernel_id < 0 || kernel_id >= tsc::KID_COUNT || !total_ms || !count) return tsc::fail("tsc_profile_read: bad arguments");
+    if (prof_fold()) return 1;
+    *total_ms = tsc::prof().total_ms[kernel_id]; *count = tsc::prof().count[kernel_id];
+    return 0;
+}
+
+const char *tsc_profile_name(int32_t id) {
+    static const char *names[] = {"env_step", "fc_gemm", "zx_gemm", "lstm_fwd", "head_fwd", "sample", "add_transition",
+                                  "returns", "head_bwd", "lstm_bwd", "dwo_gemm", "dwh_gemm", "dwx_gemm", "dx1_gemm",
+                                  "dw1_gemm", "grad_norm", "rmsprop", "transpose_wx", "fingerprint"};
+    return (id >= 0 && id < tsc::KID_COUNT) ? names[id] : "";
+}
+
 int tsc_version(void) { return 100; }
 
 #define UP(field, T, src, count)                                                 \
@@ -566,6 +616,7 @@ int tsc_env_reset(tsc_env *h, const uint32_t *seeds_host, float *obs_dev) {
 int tsc_env_set_fingerprint(tsc_env *h, const float *pi_dev) {
     if (!h || !pi_dev) return tsc::fail("tsc_env_set_fingerprint: bad arguments");
     size_t tot = (size_t)h->P.E * h->P.A * h->P.PMAX;
+    tsc::ProfScope ps(tsc::KID_FINGERPRINT, h->stream);
     hipLaunchKernelGGL(fingerprint_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->P, pi_dev);
     TSC_HIP(hipGetLastError());
     return 0;
@@ -575,6 +626,7 @@ int tsc_env_step(tsc_env *h, const int32_t *action_dev, float *obs_dev, double *
                  double *global_reward_dev, uint8_t *done_dev, int32_t train_mode) {
     if (!h || !action_dev || !obs_dev || !reward_dev || !global_reward_dev || !done_dev)
         return tsc::fail("tsc_env_step: bad arguments");
+    tsc::ProfScope ps(tsc::KID_ENV_STEP, h->stream);
     hipLaunchKernelGGL(step_kernel, dim3(h->P.E), dim3(h->P.NLP), h->smem, h->stream, h->P, action_dev, obs_dev,
                        reward_dev, global_reward_dev, done_dev, (int)train_mode);
     TSC_HIP(hipGetLastError());

@@ -40,6 +40,12 @@ struct GemmArgs {
     int lda, ldb, ldc, ldaux;
     int M, N, K;
     int gdivA;              // A (and rr) belong to group g / gdivA (both towers of an agent read the same obs)
+    // split-K (TN only): the reduction range is cut into `splitk` chunks of kchunk rows; chunk s writes its raw
+    // partial tile to ws[s][g][M][N] (and partial column sums to wsc[s][g][N]); splitk_reduce_kernel folds them
+    // in fixed order (deterministic) and applies the epilogue.
+    int splitk, kchunk;
+    float *ws, *wsc;
+    int groups;
 };
 
 constexpr int BM = 128, BN = 128, BK = 16, LDS_PAD = 4;
@@ -49,13 +55,16 @@ __global__ void __launch_bounds__(256, 2) gemm_grouped_kernel(GemmArgs p) {
     __shared__ float As[2][BK][BM + LDS_PAD];
     __shared__ float Bs[2][BK][BN + LDS_PAD];
     const int g = blockIdx.z;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int split = TN ? (int)blockIdx.x % p.splitk : 0;
+    const int m0 = (TN ? (int)blockIdx.x / p.splitk : (int)blockIdx.x) * BM, n0 = blockIdx.y * BN;
     const float *A = p.A + (long long)(g / p.gdivA) * p.sA;
     const float *B = p.B + (long long)g * p.sB;
     float *C = p.C + (long long)g * p.sC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave & 1) * 64, wn = (wave >> 1) * 64;
-    const int M = p.M, N = p.N, K = p.K;
+    const int M = p.M, N = p.N;
+    const int kbeg = TN ? split * p.kchunk : 0;
+    const int K = TN ? min(p.K, kbeg + p.kchunk) : p.K;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -146,13 +155,13 @@ __global__ void __launch_bounds__(256, 2) gemm_grouped_kernel(GemmArgs p) {
         }
     };
 
-    const int nk = (K + BK - 1) / BK;
-    load_tiles(0);
+    const int nk = (K - kbeg + BK - 1) / BK;
+    load_tiles(kbeg);
     store_tiles(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+        if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);
         const int kh = lane >> 5, li = lane & 31;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
@@ -163,7 +172,7 @@ __global__ void __launch_bounds__(256, 2) gemm_grouped_kernel(GemmArgs p) {
             if (live_m1 && live_n0) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             if (live_m1 && live_n1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (TN && p.colsum && blockIdx.x == 0 && tid < BN) {
+        if (TN && p.colsum && m0 == 0 && tid < BN) {
 #pragma unroll
             for (int kk = 0; kk < BK; ++kk) csum += Bs[buf][kk][tid];
         }
@@ -173,8 +182,28 @@ __global__ void __launch_bounds__(256, 2) gemm_grouped_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    if (TN && p.colsum && blockIdx.x == 0 && tid < BN && n0 + tid < N)
-        p.colsum[(long long)g * p.sColsum + n0 + tid] = csum;
+    const bool partial = TN && p.splitk > 1;
+    if (TN && p.colsum && m0 == 0 && tid < BN && n0 + tid < N) {
+        if (partial) p.wsc[((long long)split * p.groups + g) * N + n0 + tid] = csum;
+        else p.colsum[(long long)g * p.sColsum + n0 + tid] = csum;
+    }
+    if (partial) {      // raw partial tile -> workspace, epilogue happens in the reduce kernel
+        float *W = p.ws + ((long long)split * p.groups + g) * M * N;
+        const int li2 = lane & 31, kh2 = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn + 32 * j + li2;
+                if (n >= N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kh2;
+                    if (m < M) W[(long long)m * N + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
 
     // ---- epilogue: C/D layout of 32x32x2: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
     const int li = lane & 31, kh = lane >> 5;
@@ -206,10 +235,53 @@ __global__ void __launch_bounds__(256, 2) gemm_grouped_kernel(GemmArgs p) {
         }
 }
 
+template <int EPI>
+__global__ void splitk_reduce_kernel(GemmArgs p) {
+    const long long per = (long long)p.M * p.N;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = blockIdx.y;
+    if (idx < per) {
+        const int m = (int)(idx / p.N), n = (int)(idx % p.N);
+        float s = 0.0f;
+        for (int k = 0; k < p.splitk; ++k) s += p.ws[((long long)k * p.groups + g) * per + idx];
+        if (EPI == EPI_ROWRANGE) {
+            const int16_t *rr = p.rr + ((long long)(g / p.gdivA) * p.sRR + m) * 2;
+            if (n < rr[0] || n >= rr[1]) s = 0.0f;
+        }
+        p.C[(long long)g * p.sC + (long long)m * p.ldc + n] = s;
+    }
+    if (p.colsum && idx < p.N) {
+        float s = 0.0f;
+        for (int k = 0; k < p.splitk; ++k) s += p.wsc[((long long)k * p.groups + g) * p.N + idx];
+        p.colsum[(long long)g * p.sColsum + idx] = s;
+    }
+}
+
 template <bool TN, int EPI>
 inline void launch_gemm(const GemmArgs &a, int groups, hipStream_t st) {
-    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, groups);
+    const int sk = TN ? a.splitk : 1;
+    dim3 grid(((a.M + BM - 1) / BM) * sk, (a.N + BN - 1) / BN, groups);
     hipLaunchKernelGGL((gemm_grouped_kernel<TN, EPI>), grid, dim3(256), 0, st, a);
+    if (TN && sk > 1) {
+        const long long per = (long long)a.M * a.N;
+        dim3 rg((unsigned)((per + 255) / 256), groups);
+        hipLaunchKernelGGL((splitk_reduce_kernel<EPI>), rg, dim3(256), 0, st, a);
+    }
+}
+
+// choose a split so that the launch has ~2k workgroups and every chunk keeps >= 1024 rows
+inline void plan_splitk(GemmArgs &a, int groups, float *ws, float *wsc, size_t ws_floats, size_t wsc_floats) {
+    a.groups = groups; a.ws = ws; a.wsc = wsc; a.splitk = 1; a.kchunk = a.K;
+    if (!ws) return;
+    const long long tiles = (long long)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * groups;
+    long long s = 2048 / (tiles > 0 ? tiles : 1);
+    if (s > a.K / 1024) s = a.K / 1024;
+    while (s > 1 && ((size_t)s * groups * a.M * a.N > ws_floats || (size_t)s * groups * a.N > wsc_floats)) --s;
+    if (s <= 1) return;
+    int kc = (int)((a.K + s - 1) / s);
+    kc = (kc + BK - 1) / BK * BK;
+    a.kchunk = kc;
+    a.splitk = (a.K + kc - 1) / kc;
 }
 
 inline void launch_gemm_dyn(bool tn, int epi, const GemmArgs &a, int groups, hipStream_t st) {

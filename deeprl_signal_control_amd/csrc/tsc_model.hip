@@ -247,16 +247,40 @@ __device__ __forceinline__ void head_eval(const float *__restrict__ params, cons
     v = vv + bv[0];
 }
 
-__global__ void head_fwd_kernel(const float *__restrict__ params, Layout lay, const int *n_act, const float *Hh,
-                                int E, float *pi_out, float *v_out) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)E * lay.A) return;
-    const int e = (int)(idx / lay.A), a = (int)(idx % lay.A);
-    float hp[kL], hv[kL];
-    const float *p0 = Hh + ((long long)(2 * a) * E + e) * kL, *p1 = Hh + ((long long)(2 * a + 1) * E + e) * kL;
-    for (int jj = 0; jj < kL; ++jj) { hp[jj] = p0[jj]; hv[jj] = p1[jj]; }
+// Tile helpers: one wave per (agent, 64 consecutive samples).  The [64 samples][64 units] slab of a
+// tower is contiguous in HBM, so it is streamed with coalesced float4 accesses and transposed through
+// LDS (row stride 65: conflict-free per-sample reads).
+constexpr int kTLd = 65;
+__device__ __forceinline__ void tile_load(const float *src, long long rows_left, float (*t)[kTLd], int lane) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int q = i * 64 + lane, r = q >> 4, c = (q & 15) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < rows_left) v = *reinterpret_cast<const float4 *>(src + (long long)r * kL + c);
+        t[r][c] = v.x; t[r][c + 1] = v.y; t[r][c + 2] = v.z; t[r][c + 3] = v.w;
+    }
+}
+__device__ __forceinline__ void tile_store(float *dst, long long rows_left, float (*t)[kTLd], int lane) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int q = i * 64 + lane, r = q >> 4, c = (q & 15) * 4;
+        if (r < rows_left)
+            *reinterpret_cast<float4 *>(dst + (long long)r * kL + c) = make_float4(t[r][c], t[r][c + 1], t[r][c + 2], t[r][c + 3]);
+    }
+}
+
+__global__ void __launch_bounds__(64) head_fwd_kernel(const float *__restrict__ params, Layout lay, const int *n_act,
+                                                      const float *Hh, int E, float *pi_out, float *v_out) {
+    __shared__ float sp[64][kTLd], sv[64][kTLd];
+    const int a = blockIdx.y, lane = threadIdx.x;
+    const long long n0 = (long long)blockIdx.x * 64, left = E - n0;
+    tile_load(Hh + ((long long)(2 * a) * E + n0) * kL, left, sp, lane);
+    tile_load(Hh + ((long long)(2 * a + 1) * E + n0) * kL, left, sv, lane);
+    __syncthreads();
+    if (lane >= left) return;
     float pi[kOut], v;
-    head_eval(params, lay, a, n_act[a], hp, hv, pi, v);
+    head_eval(params, lay, a, n_act[a], sp[lane], sv[lane], pi, v);
+    const long long idx = (n0 + lane) * lay.A + a;
     for (int k = 0; k < lay.AMAX; ++k) pi_out[idx * lay.AMAX + k] = k < kOut ? pi[k] : 0.f;
     v_out[idx] = v;
 }
@@ -265,62 +289,76 @@ __global__ void head_fwd_kernel(const float *__restrict__ params, Layout lay, co
 //   L = -mean(log_pi[a] Adv) + 0.5 v_coef mean((R - v)^2) - beta mean(entropy), mean over the
 //   T*E samples of one agent.  Writes dL [G][N][8] (pi tower: dlogits, v tower: dv in col 0)
 //   and dH [G][N][64].
-__global__ void head_bwd_kernel(const float *__restrict__ params, Layout lay, const int *n_act, const float *Hh,
-                                const int *act, const float *Rs, const float *Advs, long long N,
-                                float v_coef, float beta, float *dL, float *dH, double *stats) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= N * lay.A) return;
-    const long long n = idx / lay.A;
-    const int a = (int)(idx % lay.A), na = n_act[a];
-    float hp[kL], hv[kL];
-    const float *p0 = Hh + ((long long)(2 * a) * N + n) * kL, *p1 = Hh + ((long long)(2 * a + 1) * N + n) * kL;
-    for (int jj = 0; jj < kL; ++jj) { hp[jj] = p0[jj]; hv[jj] = p1[jj]; }
-    float pi[kOut], v;
-    head_eval(params, lay, a, na, hp, hv, pi, v);
-    const int ac = act[idx];
-    const float adv = Advs[idx], R = Rs[idx];
-    const float invN = 1.0f / (float)N;
-    float logp[kOut], ent = 0.f;
-    bool inr[kOut];
+__global__ void __launch_bounds__(64) head_bwd_kernel(const float *__restrict__ params, Layout lay, const int *n_act,
+                                                      const float *Hh, const int *act, const float *Rs, const float *Advs,
+                                                      long long N, float v_coef, float beta, float *dL, float *dH,
+                                                      double *stats) {
+    __shared__ float sp[64][kTLd], sv[64][kTLd];
+    const int a = blockIdx.y, lane = threadIdx.x, na = n_act[a];
+    const long long n0 = (long long)blockIdx.x * 64, left = N - n0;
+    tile_load(Hh + ((long long)(2 * a) * N + n0) * kL, left, sp, lane);
+    tile_load(Hh + ((long long)(2 * a + 1) * N + n0) * kL, left, sv, lane);
+    __syncthreads();
+    float lp = 0.f, lv = 0.f, le = 0.f;
+    if (lane < left) {
+        const long long n = n0 + lane, idx = n * lay.A + a;
+        float pi[kOut], v;
+        head_eval(params, lay, a, na, sp[lane], sv[lane], pi, v);
+        const int ac = act[idx];
+        const float adv = Advs[idx], R = Rs[idx];
+        const float invN = 1.0f / (float)N;
+        float logp[kOut], ent = 0.f;
+        bool inr[kOut];
 #pragma unroll
-    for (int k = 0; k < kOut; ++k) {
-        inr[k] = pi[k] >= 1e-10f;                                  // tf.clip_by_value(pi, 1e-10, 1)
-        logp[k] = k < na ? logf(fminf(fmaxf(pi[k], 1e-10f), 1.0f)) : 0.f;
-        if (k < na) ent -= pi[k] * logp[k];
-    }
-    // dL/dpi_k, then softmax Jacobian: dlogit_k = pi_k (g_k - sum_j pi_j g_j)
-    float gk[kOut], dot = 0.f;
-#pragma unroll
-    for (int k = 0; k < kOut; ++k) {
-        float gpi = 0.f;
-        if (k < na) {
-            if (k == ac && inr[k]) gpi += -adv * invN / fmaxf(pi[k], 1e-10f);
-            gpi += beta * invN * (logp[k] + (inr[k] ? 1.0f : 0.f));
+        for (int k = 0; k < kOut; ++k) {
+            inr[k] = pi[k] >= 1e-10f;                                  // tf.clip_by_value(pi, 1e-10, 1)
+            logp[k] = k < na ? logf(fminf(fmaxf(pi[k], 1e-10f), 1.0f)) : 0.f;
+            if (k < na) ent -= pi[k] * logp[k];
         }
-        gk[k] = gpi;
-        dot += pi[k] * gpi;
+        // dL/dpi_k, then softmax Jacobian: dlogit_k = pi_k (g_k - sum_j pi_j g_j)
+        float gk[kOut], dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < kOut; ++k) {
+            float gpi = 0.f;
+            if (k < na) {
+                if (k == ac && inr[k]) gpi += -adv * invN / fmaxf(pi[k], 1e-10f);
+                gpi += beta * invN * (logp[k] + (inr[k] ? 1.0f : 0.f));
+            }
+            gk[k] = gpi;
+            dot += pi[k] * gpi;
+        }
+        float dl[kOut];
+#pragma unroll
+        for (int k = 0; k < kOut; ++k) dl[k] = k < na ? pi[k] * (gk[k] - dot) : 0.f;
+        const float dv = v_coef * (v - R) * invN;
+        float *o0 = dL + ((long long)(2 * a) * N + n) * kOut, *o1 = dL + ((long long)(2 * a + 1) * N + n) * kOut;
+        *reinterpret_cast<float4 *>(o0) = make_float4(dl[0], dl[1], dl[2], dl[3]);
+        *reinterpret_cast<float4 *>(o0 + 4) = make_float4(dl[4], dl[5], dl[6], dl[7]);
+        *reinterpret_cast<float4 *>(o1) = make_float4(dv, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(o1 + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float *Wo = params + (long long)(2 * a) * lay.stride + lay.oWo;
+        const float *Wv = params + (long long)(2 * a + 1) * lay.stride + lay.oWo;
+        for (int jj = 0; jj < kL; ++jj) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int k = 0; k < kOut; ++k) sacc += dl[k] * Wo[jj * kOut + k];
+            sp[lane][jj] = sacc;                                   // own row only: no hazard
+            sv[lane][jj] = dv * Wv[jj * kOut];
+        }
+        lp = -logp[ac < na ? ac : 0] * adv * invN;
+        lv = 0.5f * v_coef * (R - v) * (R - v) * invN;
+        le = -beta * ent * invN;
     }
-    float dl[kOut];
+    __syncthreads();
+    tile_store(dH + ((long long)(2 * a) * N + n0) * kL, left, sp, lane);
+    tile_store(dH + ((long long)(2 * a + 1) * N + n0) * kL, left, sv, lane);
+    if (stats) {   // logging only (policies.py:63-72): one atomic per wave
 #pragma unroll
-    for (int k = 0; k < kOut; ++k) dl[k] = k < na ? pi[k] * (gk[k] - dot) : 0.f;
-    const float dv = v_coef * (v - R) * invN;
-    float *o0 = dL + ((long long)(2 * a) * N + n) * kOut, *o1 = dL + ((long long)(2 * a + 1) * N + n) * kOut;
-#pragma unroll
-    for (int k = 0; k < kOut; ++k) { o0[k] = dl[k]; o1[k] = k == 0 ? dv : 0.f; }
-    const float *Wo = params + (long long)(2 * a) * lay.stride + lay.oWo;
-    const float *Wv = params + (long long)(2 * a + 1) * lay.stride + lay.oWo;
-    float *h0 = dH + ((long long)(2 * a) * N + n) * kL, *h1 = dH + ((long long)(2 * a + 1) * N + n) * kL;
-    for (int jj = 0; jj < kL; ++jj) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < kOut; ++k) s += dl[k] * Wo[jj * kOut + k];
-        h0[jj] = s;
-        h1[jj] = dv * Wv[jj * kOut];
-    }
-    if (stats) {   // logging only (policies.py:63-72)
-        atomicAdd(&stats[a * 4 + 0], (double)(-logp[ac < na ? ac : 0] * adv * invN));
-        atomicAdd(&stats[a * 4 + 1], (double)(0.5f * v_coef * (R - v) * (R - v) * invN));
-        atomicAdd(&stats[a * 4 + 2], (double)(-beta * ent * invN));
+        for (int o = 32; o > 0; o >>= 1) { lp += __shfl_down(lp, o); lv += __shfl_down(lv, o); le += __shfl_down(le, o); }
+        if (lane == 0) {
+            atomicAdd(&stats[a * 4 + 0], (double)lp); atomicAdd(&stats[a * 4 + 1], (double)lv);
+            atomicAdd(&stats[a * 4 + 2], (double)le);
+        }
     }
 }
 
@@ -444,13 +482,15 @@ struct tsc_model {
     // activations
     float *X1, *Z, *Hh, *Cc, *Hp, *dHh, *dL;
     double *norm2, *stats;
+    float *ws, *wsc;            // split-K workspace
+    size_t ws_floats, wsc_floats;
     size_t lds_fwd, lds_bwd;
     long long nparam;
 };
 
 namespace {
 
-int gemm(tsc_model *m, bool tn, int epi, int groups, int M, int N, int K, const float *A, long long sA, int lda,
+int gemm(tsc_model *m, int kid, bool tn, int epi, int groups, int M, int N, int K, const float *A, long long sA, int lda,
          int gdivA, const float *B, long long sB, int ldb, float *C, long long sC, int ldc, const float *bias,
          long long sBias, const float *aux, long long sAux, int ldaux, const int16_t *rr, long long sRR,
          float *colsum, long long sColsum) {
@@ -458,6 +498,8 @@ int gemm(tsc_model *m, bool tn, int epi, int groups, int M, int N, int K, const 
     a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.rr = rr; a.colsum = colsum;
     a.sA = sA; a.sB = sB; a.sC = sC; a.sBias = sBias; a.sAux = sAux; a.sRR = sRR; a.sColsum = sColsum;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldaux; a.M = M; a.N = N; a.K = K; a.gdivA = gdivA;
+    tsc::plan_splitk(a, groups, tn ? m->ws : nullptr, m->wsc, m->ws_floats, m->wsc_floats);
+    tsc::ProfScope ps(kid, m->stream);
     tsc::launch_gemm_dyn(tn, epi, a, groups, m->stream);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
@@ -466,10 +508,10 @@ int gemm(tsc_model *m, bool tn, int epi, int groups, int M, int N, int K, const 
 int dense_forward(tsc_model *m, const float *obs, long long rows, float *X1, float *Z) {
     const Layout &L = m->lay;
     const int AS = L.A * L.SMAX;
-    if (gemm(m, false, tsc::EPI_BIAS_RELU, L.G, (int)rows, L.H, L.SMAX, obs, L.SMAX, AS, 2, m->params + L.oW1,
+    if (gemm(m, tsc::KID_FC_GEMM, false, tsc::EPI_BIAS_RELU, L.G, (int)rows, L.H, L.SMAX, obs, L.SMAX, AS, 2, m->params + L.oW1,
              L.stride, L.H, X1, rows * L.H, L.H, m->params + L.ob1, L.stride, nullptr, 0, 0, nullptr, 0, nullptr, 0))
         return 1;
-    if (gemm(m, false, tsc::EPI_BIAS, L.G, (int)rows, kG4, L.H, X1, rows * L.H, L.H, 1, m->params + L.oWx, L.stride,
+    if (gemm(m, tsc::KID_ZX_GEMM, false, tsc::EPI_BIAS, L.G, (int)rows, kG4, L.H, X1, rows * L.H, L.H, 1, m->params + L.oWx, L.stride,
              kG4, Z, rows * kG4, kG4, m->params + L.obl, L.stride, nullptr, 0, 0, nullptr, 0, nullptr, 0))
         return 1;
     return 0;
@@ -532,6 +574,8 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     MALLOC(m->Hh, float, G * N * kL); MALLOC(m->Cc, float, G * N * kL); MALLOC(m->Hp, float, G * N * kL);
     MALLOC(m->dHh, float, G * N * kL); MALLOC(m->dL, float, G * N * kOut);
     MALLOC(m->norm2, double, A); MALLOC(m->stats, double, A * 4);
+    m->ws_floats = (size_t)48 << 20; m->wsc_floats = (size_t)1 << 20;      // 192 MiB + 4 MiB
+    MALLOC(m->ws, float, m->ws_floats); MALLOC(m->wsc, float, m->wsc_floats);
     m->lds_fwd = sizeof(float) * (64 * kWhLd + 64 * kHsLd);
     m->lds_bwd = sizeof(float) * (kG4 * kWtLd + kG4 * kDzLd);
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fwd));
@@ -605,11 +649,14 @@ int tsc_model_forward(tsc_model *m, const float *obs, const uint8_t *done, float
     const int E = m->E;
     // the rollout forward borrows the head of the training activations (row count E <= T*E)
     if (dense_forward(m, obs, E, m->X1, m->Z)) return tsc::fail("tsc_model_forward: gemm launch failed");
+    tsc::ProfScope ps1(tsc::KID_LSTM_FWD, m->stream);
     hipLaunchKernelGGL(lstm_fwd_kernel, dim3(L.G, (E + 63) / 64), dim3(256), m->lds_fwd, m->stream, m->params, L, m->Z,
                        m->state_fw, advance ? m->state_fw : (float *)nullptr, m->Hh, m->Cc, m->Hp, done, 1, E, 0);
-    const long long tot = (long long)E * L.A;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((tot + 127) / 128)), dim3(128), 0, m->stream, m->params, L,
+    ps1.stop();
+    tsc::ProfScope ps3(tsc::KID_HEAD_FWD, m->stream);
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((E + 63) / 64), L.A), dim3(64), 0, m->stream, m->params, L,
                        m->n_act, m->Hh, E, pi, v);
+    ps3.stop();
     TSC_HIP(hipGetLastError());
     return 0;
 }
@@ -617,8 +664,10 @@ int tsc_model_forward(tsc_model *m, const float *obs, const uint8_t *done, float
 int tsc_model_sample(tsc_model *m, const float *pi, int32_t *action, uint64_t seed, uint64_t step) {
     if (!m || !pi || !action) return tsc::fail("tsc_model_sample: bad arguments");
     const int tot = m->E * m->lay.A;
+    tsc::ProfScope ps4(tsc::KID_SAMPLE, m->stream);
     hipLaunchKernelGGL(sample_kernel, dim3((tot + 255) / 256), dim3(256), 0, m->stream, pi, m->n_act, m->E, m->lay.A,
                        m->lay.AMAX, (unsigned long long)seed, (unsigned long long)step, action);
+    ps4.stop();
     TSC_HIP(hipGetLastError());
     return 0;
 }
@@ -628,10 +677,12 @@ int tsc_model_add_transition(tsc_model *m, int32_t t, const float *obs, const ui
     if (!m || t < 0 || t >= m->T) return tsc::fail("tsc_model_add_transition: slot %d outside [0,%d)", t, m->T);
     const Layout &L = m->lay;
     const long long E = m->E, A = L.A, no = E * A * L.SMAX;
+    tsc::ProfScope ps5(tsc::KID_ADD_TRANS, m->stream);
     hipLaunchKernelGGL(add_transition_kernel, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, m->stream, (int)E, (int)A,
                        L.SMAX, obs, done_pre, action, reward, value, done_post, m->rnorm, m->rclip, m->r_obs + t * no,
                        m->r_act + t * E * A, m->r_rew + t * E * A, m->r_val + t * E * A, m->r_done + t * E,
                        m->r_done + (t + 1) * E);
+    ps5.stop();
     TSC_HIP(hipGetLastError());
     return 0;
 }
@@ -643,31 +694,41 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
     const int AS = L.A * L.SMAX;
     hipStream_t st = m->stream;
     TSC_HIP(hipMemsetAsync(m->stats, 0, sizeof(double) * A * 4, st));
+    tsc::ProfScope ps6(tsc::KID_RETURNS, m->stream);
     hipLaunchKernelGGL(returns_kernel, dim3((unsigned)((E * A + 255) / 256)), dim3(256), 0, st, m->r_rew, m->r_val, m->r_done,
                        R_boot, (int)T, (int)E, (int)A, m->gamma, m->Rs, m->Advs);
+    ps6.stop();
     // forward with stored activations, from the backward state (agents/policies.py:144-152)
     if (dense_forward(m, m->r_obs, N, m->X1, m->Z)) return tsc::fail("gemm launch failed");
+    tsc::ProfScope ps2(tsc::KID_LSTM_FWD, m->stream);
     hipLaunchKernelGGL(lstm_fwd_kernel, dim3((unsigned)G, (unsigned)((E + 63) / 64)), dim3(256), m->lds_fwd, st, m->params, L,
                        m->Z, m->state_bw, (float *)nullptr, m->Hh, m->Cc, m->Hp, m->r_done, (int)T, (int)E, 1);
-    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((N * A + 127) / 128)), dim3(128), 0, st, m->params, L, m->n_act,
+    ps2.stop();
+    tsc::ProfScope ps7(tsc::KID_HEAD_BWD, m->stream);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)A), dim3(64), 0, st, m->params, L, m->n_act,
                        m->Hh, m->r_act, m->Rs, m->Advs, N, (float)m->vcoef, (float)beta, m->dL, m->dHh, m->stats);
+    ps7.stop();
+    tsc::ProfScope ps8(tsc::KID_LSTM_BWD, m->stream);
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)G, (unsigned)((E + 63) / 64)), dim3(256), m->lds_bwd, st, m->params, L,
                        m->Z, m->Cc, m->state_bw, m->dHh, m->r_done, (int)T, (int)E);
+    ps8.stop();
+    tsc::ProfScope ps9(tsc::KID_TRANSPOSE, m->stream);
     hipLaunchKernelGGL(transpose_wx_kernel, dim3((unsigned)((G * L.H * kG4 + 255) / 256)), dim3(256), 0, st, m->params, L, m->WxT);
+    ps9.stop();
     TSC_HIP(hipGetLastError());
     float *g = m->grads;
     // dWo = Hh^T dL (+ dbo) ; dWh = Hp^T dZ (+ dbl) ; dWx = X1^T dZ
-    if (gemm(m, true, tsc::EPI_NONE, (int)G, kL, kOut, (int)N, m->Hh, N * kL, kL, 1, m->dL, N * kOut, kOut, g + L.oWo,
+    if (gemm(m, tsc::KID_DWO_GEMM, true, tsc::EPI_NONE, (int)G, kL, kOut, (int)N, m->Hh, N * kL, kL, 1, m->dL, N * kOut, kOut, g + L.oWo,
              L.stride, kOut, nullptr, 0, nullptr, 0, 0, nullptr, 0, g + L.obo, L.stride)) return tsc::fail("gemm failed");
-    if (gemm(m, true, tsc::EPI_NONE, (int)G, kL, kG4, (int)N, m->Hp, N * kL, kL, 1, m->Z, N * kG4, kG4, g + L.oWh, L.stride,
+    if (gemm(m, tsc::KID_DWH_GEMM, true, tsc::EPI_NONE, (int)G, kL, kG4, (int)N, m->Hp, N * kL, kL, 1, m->Z, N * kG4, kG4, g + L.oWh, L.stride,
              kG4, nullptr, 0, nullptr, 0, 0, nullptr, 0, g + L.obl, L.stride)) return tsc::fail("gemm failed");
-    if (gemm(m, true, tsc::EPI_NONE, (int)G, L.H, kG4, (int)N, m->X1, N * L.H, L.H, 1, m->Z, N * kG4, kG4, g + L.oWx, L.stride,
+    if (gemm(m, tsc::KID_DWX_GEMM, true, tsc::EPI_NONE, (int)G, L.H, kG4, (int)N, m->X1, N * L.H, L.H, 1, m->Z, N * kG4, kG4, g + L.oWx, L.stride,
              kG4, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, 0)) return tsc::fail("gemm failed");
     // dX1 = (dZ Wx^T) * relu'(X1), in place over X1
-    if (gemm(m, false, tsc::EPI_MASK_POS, (int)G, (int)N, L.H, kG4, m->Z, N * kG4, kG4, 1, m->WxT, (long long)L.H * kG4, L.H,
+    if (gemm(m, tsc::KID_DX1_GEMM, false, tsc::EPI_MASK_POS, (int)G, (int)N, L.H, kG4, m->Z, N * kG4, kG4, 1, m->WxT, (long long)L.H * kG4, L.H,
              m->X1, N * L.H, L.H, nullptr, 0, m->X1, N * L.H, L.H, nullptr, 0, nullptr, 0)) return tsc::fail("gemm failed");
     // dW1 = obs^T dX1 masked to the block-diagonal structure (+ db1)
-    if (gemm(m, true, tsc::EPI_ROWRANGE, (int)G, L.SMAX, L.H, (int)N, m->r_obs, L.SMAX, AS, 2, m->X1, N * L.H, L.H, g + L.oW1,
+    if (gemm(m, tsc::KID_DW1_GEMM, true, tsc::EPI_ROWRANGE, (int)G, L.SMAX, L.H, (int)N, m->r_obs, L.SMAX, AS, 2, m->X1, N * L.H, L.H, g + L.oW1,
              L.stride, L.H, nullptr, 0, nullptr, 0, 0, m->rowrange, L.SMAX, g + L.ob1, L.stride)) return tsc::fail("gemm failed");
     TSC_HIP(hipGetLastError());
     return 0;
@@ -684,10 +745,14 @@ int tsc_model_apply_grads(tsc_model *m, double lr, double grad_scale, double *st
     const Layout &L = m->lay;
     const long long per_agent = 2 * L.stride;
     hipStream_t st = m->stream;
+    tsc::ProfScope ps10(tsc::KID_GRADNORM, m->stream);
     hipLaunchKernelGGL(grad_norm_kernel, dim3(L.A), dim3(256), 0, st, m->grads, per_agent, grad_scale, m->norm2);
+    ps10.stop();
+    tsc::ProfScope ps11(tsc::KID_RMSPROP, m->stream);
     hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)((m->nparam + 255) / 256)), dim3(256), 0, st, m->params, m->ms, m->grads,
                        per_agent, m->nparam, m->norm2, (float)grad_scale, (float)m->max_norm, (float)lr, (float)m->alpha,
                        (float)m->eps);
+    ps11.stop();
     TSC_HIP(hipGetLastError());
     // states_bw <- states_fw (policies.py:153); buffer.reset(dones[-1]) (utils.py:227)
     TSC_HIP(hipMemcpyAsync(m->state_bw, m->state_fw, sizeof(float) * (size_t)L.G * m->E * 2 * kL, hipMemcpyDeviceToDevice, st));
@@ -717,11 +782,12 @@ int tsc_model_get_returns(tsc_model *m, float *Rs, float *Advs) {
 int tsc_gemm_grouped_f32(int32_t form, int32_t epi, int32_t groups, int32_t M, int32_t N, int32_t K, const float *A,
                          int64_t sA, int32_t lda, const float *B, int64_t sB, int32_t ldb, float *C, int64_t sC,
                          int32_t ldc, const float *bias, const float *aux, const int16_t *rowrange, float *colsum,
-                         void *hip_stream) {
+                         float *splitk_ws, int64_t ws_floats, float *splitk_wsc, int64_t wsc_floats, void *hip_stream) {
     GemmArgs a;
     a.A = A; a.B = B; a.C = C; a.bias = bias; a.aux = aux; a.rr = rowrange; a.colsum = colsum;
     a.sA = sA; a.sB = sB; a.sC = sC; a.sBias = N; a.sAux = (long long)M * ldc; a.sRR = M; a.sColsum = N;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldaux = ldc; a.M = M; a.N = N; a.K = K; a.gdivA = 1;
+    tsc::plan_splitk(a, groups, form != 0 ? splitk_ws : nullptr, splitk_wsc, (size_t)ws_floats, (size_t)wsc_floats);
     tsc::launch_gemm_dyn(form != 0, epi, a, groups, (hipStream_t)hip_stream);
     TSC_HIP(hipGetLastError());
     return 0;

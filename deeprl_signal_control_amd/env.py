@@ -55,10 +55,14 @@ class VecTrafficEnv:
             self.stream = torch.cuda.current_stream(self.device)
             _lib.check(L.tsc_env_set_stream(h, C.c_void_p(self.stream.cuda_stream)))
             d = self.device
-            self.obs = torch.zeros(self.E, self.A, self.SMAX, dtype=torch.float32, device=d)
+            # obs / done ping-pong: step() writes the buffers the previous call did NOT return, so the
+            # caller can still hand the previous (ob, done) to model.add_transition (utils.py:160-165)
+            self._obs2 = [torch.zeros(self.E, self.A, self.SMAX, dtype=torch.float32, device=d) for _ in range(2)]
+            self._done2 = [torch.zeros(self.E, dtype=torch.uint8, device=d) for _ in range(2)]
+            self._flip = 0
+            self.obs, self.done = self._obs2[0], self._done2[0]
             self.reward = torch.zeros(self.E, self.A, dtype=torch.float64, device=d)
             self.global_reward = torch.zeros(self.E, dtype=torch.float64, device=d)
-            self.done = torch.zeros(self.E, dtype=torch.uint8, device=d)
 
     # -- lifecycle -------------------------------------------------------------------------
     def close(self):
@@ -66,7 +70,8 @@ class VecTrafficEnv:
             self._L.tsc_env_destroy(self._h)
             self._h = None
 
-    terminate = close
+    def terminate(self):
+        """envs/env.py:563 closes the SUMO connection; the device-resident instances simply stay."""
 
     def __del__(self):
         try:
@@ -101,9 +106,11 @@ class VecTrafficEnv:
 
     def step(self, action):
         """envs/env.py:566-631; action int32 [E, A] on the device.  Returns the env's own
-        output buffers (obs f32 [E,A,SMAX], reward f64 [E,A], done u8 [E], global f64 [E]),
-        overwritten by the next call."""
+        output buffers (obs f32 [E,A,SMAX], reward f64 [E,A], done u8 [E], global f64 [E]);
+        obs / done alternate between two buffers, reward / global are overwritten by the next call."""
         assert action.dtype == torch.int32 and action.is_contiguous() and tuple(action.shape) == (self.E, self.A)
+        self._flip ^= 1
+        self.obs, self.done = self._obs2[self._flip], self._done2[self._flip]
         _lib.check(self._L.tsc_env_step(self._h, C.c_void_p(action.data_ptr()), C.c_void_p(self.obs.data_ptr()),
                                         C.c_void_p(self.reward.data_ptr()),
                                         C.c_void_p(self.global_reward.data_ptr()),

@@ -73,6 +73,13 @@ typedef struct tsc_env tsc_env;
 const char *tsc_last_error(void);
 int tsc_version(void);
 
+/* Per-kernel timing with HIP events on the launch stream (bench.py's live roofline figure; the
+ * reference has no equivalent).  Off by default; read() synchronises the recorded events. */
+int tsc_profile_enable(int32_t on);
+int tsc_profile_reset(void);
+int tsc_profile_read(int32_t kernel_id, double *total_ms, int64_t *count);
+const char *tsc_profile_name(int32_t kernel_id);   /* "" past the last id */
+
 /* ---- env: replaces TrafficSimulator (envs/env.py:82-635) + SUMO/TraCI ------------------ */
 
 /* TrafficSimulator.__init__ (envs/env.py:83-110) for E parallel instances. */
@@ -173,11 +180,13 @@ int tsc_model_apply_grads(tsc_model *m, double lr, double grad_scale, double *st
 int tsc_model_get_returns(tsc_model *m, float *Rs_host, float *Advs_host);
 
 /* Test hook: the grouped fp32 MFMA GEMM used by every layer.  form: 0 = NN, 1 = TN; epi as
- * csrc/tsc_gemm.h.  All pointers device; strides in elements. */
+ * csrc/tsc_gemm.h.  All pointers device; strides in elements.  A non-null split-K workspace lets
+ * the TN form cut its reduction into deterministic chunks (as the weight-gradient GEMMs do). */
 int tsc_gemm_grouped_f32(int32_t form, int32_t epi, int32_t groups, int32_t M, int32_t N, int32_t K,
                          const float *A, int64_t sA, int32_t lda, const float *B, int64_t sB, int32_t ldb,
                          float *C, int64_t sC, int32_t ldc, const float *bias, const float *aux,
-                         const int16_t *rowrange, float *colsum, void *hip_stream);
+                         const int16_t *rowrange, float *colsum, float *splitk_ws, int64_t ws_floats,
+                         float *splitk_wsc, int64_t wsc_floats, void *hip_stream);
 
 #ifdef __cplusplus
 }

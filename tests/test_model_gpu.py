@@ -21,13 +21,15 @@ def _vp(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _gemm(form, epi, A, B, C_, M, N, K, lda, ldb, ldc, sA, sB, sC, groups, bias=None, aux=None, rr=None, colsum=None):
+def _gemm(form, epi, A, B, C_, M, N, K, lda, ldb, ldc, sA, sB, sC, groups, bias=None, aux=None, rr=None, colsum=None,
+          ws=None, wsc=None):
     from deeprl_signal_control_amd import _lib
     from deeprl_signal_control_amd.agents import _setup_lib
     L = _lib.lib()
     _setup_lib(L)
     _lib.check(L.tsc_gemm_grouped_f32(form, epi, groups, M, N, K, _vp(A), sA, lda, _vp(B), sB, ldb, _vp(C_), sC, ldc,
-                                      _vp(bias), _vp(aux), _vp(rr), _vp(colsum),
+                                      _vp(bias), _vp(aux), _vp(rr), _vp(colsum), _vp(ws), ws.numel() if ws is not None else 0,
+                                      _vp(wsc), wsc.numel() if wsc is not None else 0,
                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
 
@@ -51,21 +53,29 @@ def test_gemm_nn(M, N, K, G):
     np.testing.assert_allclose(d_aux.cpu().numpy(), ref * (aux > 0), atol=tol, rtol=1e-5)
 
 
-@pytest.mark.parametrize('Kred,M,N,G', [(1000, 52, 224, 2), (512, 64, 256, 2), (333, 64, 8, 3), (4096, 224, 256, 1)])
-def test_gemm_tn_colsum_rowrange(Kred, M, N, G):
+@pytest.mark.parametrize('Kred,M,N,G,split', [(1000, 52, 224, 2, False), (512, 64, 256, 2, False), (333, 64, 8, 3, False),
+                                               (4096, 224, 256, 1, False), (20000, 52, 224, 2, True), (9001, 64, 8, 3, True),
+                                               (16384, 224, 256, 2, True)])
+def test_gemm_tn_colsum_rowrange(Kred, M, N, G, split):
     rng = np.random.RandomState(Kred)
     A = rng.randn(G, Kred, M).astype(np.float32); B = rng.randn(G, Kred, N).astype(np.float32)
     dA, dB = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
     ref = np.einsum('gkm,gkn->gmn', A.astype(np.float64), B.astype(np.float64))
     out = torch.zeros(G, M, N, device='cuda'); cs = torch.zeros(G, N, device='cuda')
-    _gemm(1, 0, dA, dB, out, M, N, Kred, M, N, N, Kred * M, Kred * N, M * N, G, colsum=cs)
+    ws = torch.zeros(8 << 20, device='cuda') if split else None      # split-K workspace (deterministic chunks)
+    wsc = torch.zeros(1 << 16, device='cuda') if split else None
+    _gemm(1, 0, dA, dB, out, M, N, Kred, M, N, N, Kred * M, Kred * N, M * N, G, colsum=cs, ws=ws, wsc=wsc)
     tol = 2e-6 * Kred
     np.testing.assert_allclose(out.cpu().numpy(), ref, atol=tol, rtol=1e-4)
     np.testing.assert_allclose(cs.cpu().numpy(), B.astype(np.float64).sum(1), atol=tol, rtol=1e-4)
     rr = np.zeros((G, M, 2), np.int16)
     rr[:, :, 0] = rng.randint(0, N // 2, (G, M)); rr[:, :, 1] = rr[:, :, 0] + rng.randint(0, N // 2, (G, M))
     out2 = torch.zeros(G, M, N, device='cuda')
-    _gemm(1, 4, dA, dB, out2, M, N, Kred, M, N, N, Kred * M, Kred * N, M * N, G, rr=torch.from_numpy(rr).cuda())
+    _gemm(1, 4, dA, dB, out2, M, N, Kred, M, N, N, Kred * M, Kred * N, M * N, G, rr=torch.from_numpy(rr).cuda(), ws=ws, wsc=wsc)
+    if split:                                              # deterministic: bit-identical on a second run
+        out3 = torch.zeros(G, M, N, device='cuda')
+        _gemm(1, 4, dA, dB, out3, M, N, Kred, M, N, N, Kred * M, Kred * N, M * N, G, rr=torch.from_numpy(rr).cuda(), ws=ws, wsc=wsc)
+        assert torch.equal(out2, out3)
     n = np.arange(N)[None, None, :]
     mask = (n >= rr[:, :, :1]) & (n < rr[:, :, 1:])
     np.testing.assert_allclose(out2.cpu().numpy(), ref * mask, atol=tol, rtol=1e-4)
