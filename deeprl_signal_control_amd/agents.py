@@ -57,6 +57,98 @@ def ortho_init(shape, rng, scale=np.sqrt(2)):
     return (scale * q.reshape(shape)).astype(np.float32)
 
 
+class ParamLayout:
+    """Flat parameter layout of csrc/tsc_model.hip (see include/tsc.h tsc_model_layout): group
+    g = 2*agent + tower owns `stride` floats  W1[s_max][H] | b1[H] | Wx[H][4L] | Wh[L][4L] | bl[4L] |
+    Wo[L][8] | bo[8]."""
+
+    def __init__(self, n_wave_ls, n_w_ls, n_f_ls, n_a_ls, s_max, n_fc, n_lstm=64, out_pad=8):
+        self.n_wave_ls, self.n_w_ls, self.n_f_ls, self.n_a_ls = map(list, (n_wave_ls, n_w_ls, n_f_ls, n_a_ls))
+        self.s_max, self.n_fc, self.Lh, self.out_pad = int(s_max), tuple(n_fc), int(n_lstm), int(out_pad)
+        self.G = 2 * len(self.n_a_ls)
+        self.H = sum(self.n_fc)
+        L4 = 4 * self.Lh
+        self.oW1 = 0
+        self.ob1 = self.s_max * self.H
+        self.oWx = self.ob1 + self.H
+        self.oWh = self.oWx + self.H * L4
+        self.obl = self.oWh + self.Lh * L4
+        self.oWo = self.obl + L4
+        self.obo = self.oWo + self.Lh * self.out_pad
+        self.stride = self.obo + self.out_pad
+        self.n_param = self.G * self.stride
+
+    def as_tuple(self):
+        return (self.G, self.stride, self.H, self.Lh, self.oW1, self.ob1, self.oWx, self.oWh, self.obl, self.oWo,
+                self.obo, self.out_pad)
+
+    def pack(self, towers):
+        """List of per-tower dicts (order: agent0 pi, agent0 v, agent1 pi, ...) -> flat [G*stride]."""
+        flat = np.zeros((self.G, self.stride), np.float32)
+        fw, fp, ft = self.n_fc
+        for g, p in enumerate(towers):
+            a = g // 2
+            nw, nt, nf = self.n_wave_ls[a], self.n_w_ls[a], self.n_f_ls[a]
+            W1 = np.zeros((self.s_max, self.H), np.float32)
+            b1 = np.zeros(self.H, np.float32)
+            W1[:nw, :fw] = p['fcw_w']; b1[:fw] = p['fcw_b']
+            if fp:
+                W1[nw + nt:nw + nt + nf, fw:fw + fp] = p['fcf_w']; b1[fw:fw + fp] = p['fcf_b']
+            if ft:
+                W1[nw:nw + nt, fw + fp:] = p['fct_w']; b1[fw + fp:] = p['fct_b']
+            Wo = np.zeros((self.Lh, self.out_pad), np.float32)
+            bo = np.zeros(self.out_pad, np.float32)
+            Wo[:, :p['out_w'].shape[1]] = p['out_w']; bo[:len(p['out_b'])] = p['out_b']
+            f = flat[g]
+            f[self.oW1:self.ob1] = W1.ravel(); f[self.ob1:self.oWx] = b1
+            f[self.oWx:self.oWh] = np.asarray(p['lstm_wx'], np.float32).ravel()
+            f[self.oWh:self.obl] = np.asarray(p['lstm_wh'], np.float32).ravel()
+            f[self.obl:self.oWo] = p['lstm_b']; f[self.oWo:self.obo] = Wo.ravel(); f[self.obo:] = bo
+        return flat.ravel()
+
+    def unpack(self, flat):
+        flat = np.asarray(flat, np.float32).reshape(self.G, self.stride)
+        fw, fp, ft = self.n_fc
+        towers = []
+        for g in range(self.G):
+            a = g // 2
+            nw, nt, nf = self.n_wave_ls[a], self.n_w_ls[a], self.n_f_ls[a]
+            f = flat[g]
+            W1 = f[self.oW1:self.ob1].reshape(self.s_max, self.H); b1 = f[self.ob1:self.oWx]
+            p = {'fcw_w': W1[:nw, :fw].copy(), 'fcw_b': b1[:fw].copy()}
+            if fp:
+                p['fcf_w'] = W1[nw + nt:nw + nt + nf, fw:fw + fp].copy(); p['fcf_b'] = b1[fw:fw + fp].copy()
+            if ft:
+                p['fct_w'] = W1[nw:nw + nt, fw + fp:].copy(); p['fct_b'] = b1[fw + fp:].copy()
+            p['lstm_wx'] = f[self.oWx:self.oWh].reshape(self.H, 4 * self.Lh).copy()
+            p['lstm_wh'] = f[self.oWh:self.obl].reshape(self.Lh, 4 * self.Lh).copy()
+            p['lstm_b'] = f[self.obl:self.oWo].copy()
+            n_out = self.n_a_ls[a] if g % 2 == 0 else 1
+            p['out_w'] = f[self.oWo:self.obo].reshape(self.Lh, self.out_pad)[:, :n_out].copy()
+            p['out_b'] = f[self.obo:self.obo + n_out].copy()
+            towers.append(p)
+        return towers
+
+
+def allreduce_grads_(flat_grad, group=None):
+    """The one collective of the path: sum the flat gradient buffer over ranks (RCCL
+    on GPUs, gloo in the CPU test) and return the 1/world factor apply_grads folds in BEFORE the
+    per-agent clip, so every replica applies the identical update."""
+    dist = torch.distributed
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1.0
+    world = dist.get_world_size(group)
+    if world == 1:
+        return 1.0
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / world
+
+
+def shard_seeds(seed0, n_env, rank):
+    """Global env index -> seed: rank r owns instances [r*E, (r+1)*E)."""
+    return [seed0 + rank * n_env + e for e in range(n_env)]
+
+
 def _setup_lib(L):
     if getattr(L, '_model_ready', False):
         return
@@ -120,6 +212,9 @@ class VecA2C:
         _lib.check(L.tsc_model_layout(h, lay))
         (self.G, self.stride, self.H, self.Lh, self.oW1, self.ob1, self.oWx, self.oWh, self.obl, self.oWo,
          self.obo, self.out_pad) = [int(x) for x in lay]
+        self.layout = ParamLayout(self.n_wave_ls, self.n_w_ls, self.n_f_ls, self.n_a_ls, self.s_max, self.n_fc,
+                                  self.Lh, self.out_pad)
+        assert self.layout.as_tuple() == tuple(int(x) for x in lay), 'host / device parameter layouts disagree'
         with torch.cuda.device(self.device):
             self.stream = torch.cuda.current_stream(self.device)
             _lib.check(L.tsc_model_set_stream(h, C.c_void_p(self.stream.cuda_stream)))
@@ -177,50 +272,10 @@ class VecA2C:
         self.set_tower_params(towers)
 
     def pack(self, towers):
-        """List of per-tower dicts (order: agent0 pi, agent0 v, agent1 pi, ...) -> flat [G*stride]."""
-        flat = np.zeros((self.G, self.stride), np.float32)
-        fw, fp, ft = self.n_fc
-        for g, p in enumerate(towers):
-            a = g // 2
-            nw, nt, nf = self.n_wave_ls[a], self.n_w_ls[a], self.n_f_ls[a]
-            W1 = np.zeros((self.s_max, self.H), np.float32)
-            b1 = np.zeros(self.H, np.float32)
-            W1[:nw, :fw] = p['fcw_w']; b1[:fw] = p['fcw_b']
-            if fp:
-                W1[nw + nt:nw + nt + nf, fw:fw + fp] = p['fcf_w']; b1[fw:fw + fp] = p['fcf_b']
-            if ft:
-                W1[nw:nw + nt, fw + fp:] = p['fct_w']; b1[fw + fp:] = p['fct_b']
-            Wo = np.zeros((self.Lh, self.out_pad), np.float32)
-            bo = np.zeros(self.out_pad, np.float32)
-            Wo[:, :p['out_w'].shape[1]] = p['out_w']; bo[:len(p['out_b'])] = p['out_b']
-            f = flat[g]
-            f[self.oW1:self.ob1] = W1.ravel(); f[self.ob1:self.oWx] = b1
-            f[self.oWx:self.oWh] = p['lstm_wx'].ravel(); f[self.oWh:self.obl] = p['lstm_wh'].ravel()
-            f[self.obl:self.oWo] = p['lstm_b']; f[self.oWo:self.obo] = Wo.ravel(); f[self.obo:] = bo
-        return flat.ravel()
+        return self.layout.pack(towers)
 
     def unpack(self, flat):
-        flat = np.asarray(flat, np.float32).reshape(self.G, self.stride)
-        fw, fp, ft = self.n_fc
-        towers = []
-        for g in range(self.G):
-            a = g // 2
-            nw, nt, nf = self.n_wave_ls[a], self.n_w_ls[a], self.n_f_ls[a]
-            f = flat[g]
-            W1 = f[self.oW1:self.ob1].reshape(self.s_max, self.H); b1 = f[self.ob1:self.oWx]
-            p = {'fcw_w': W1[:nw, :fw].copy(), 'fcw_b': b1[:fw].copy()}
-            if fp:
-                p['fcf_w'] = W1[nw + nt:nw + nt + nf, fw:fw + fp].copy(); p['fcf_b'] = b1[fw:fw + fp].copy()
-            if ft:
-                p['fct_w'] = W1[nw:nw + nt, fw + fp:].copy(); p['fct_b'] = b1[fw + fp:].copy()
-            p['lstm_wx'] = f[self.oWx:self.oWh].reshape(self.H, 4 * self.Lh).copy()
-            p['lstm_wh'] = f[self.oWh:self.obl].reshape(self.Lh, 4 * self.Lh).copy()
-            p['lstm_b'] = f[self.obl:self.oWo].copy()
-            n_out = self.n_a_ls[a] if g % 2 == 0 else 1
-            p['out_w'] = f[self.oWo:self.obo].reshape(self.Lh, self.out_pad)[:, :n_out].copy()
-            p['out_b'] = f[self.obo:self.obo + n_out].copy()
-            towers.append(p)
-        return towers
+        return self.layout.unpack(flat)
 
     def set_tower_params(self, towers):
         flat = np.ascontiguousarray(self.pack(towers))
@@ -287,11 +342,8 @@ class VecA2C:
         cur_beta = self.beta_scheduler.get(self.n_step)
         _lib.check(self._L.tsc_model_compute_grads(self._h, C.c_void_p(R.data_ptr()), float(cur_beta)))
         scale = 1.0
-        if self.pg is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()
-                                   and torch.distributed.get_world_size() > 1):
-            g = self.grad_tensor()
-            torch.distributed.all_reduce(g, group=self.pg)       # RCCL over xGMI, one flat buffer
-            scale = 1.0 / torch.distributed.get_world_size(self.pg)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            scale = allreduce_grads_(self.grad_tensor(), self.pg)   # RCCL over xGMI, one flat buffer
         stats = np.zeros((self.n_agent, 4), np.float64) if want_stats else None
         _lib.check(self._L.tsc_model_apply_grads(self._h, float(cur_lr), scale,
                                                  stats.ctypes.data_as(C.c_void_p) if want_stats else None))

@@ -187,6 +187,7 @@ class TrafficEnv:
 
 def make_env(scenario='large_grid', agent='ma2c', n_env=None, **kw):
     """init_env (main.py:51-79) equivalent; n_env=None gives the reference's single-env type."""
-    scn_kw = {k: kw.pop(k) for k in list(kw) if k in Scenario.__dataclass_fields__}
+    scn_kw = {k: kw.pop(k) for k in list(kw)
+              if k in Scenario.__dataclass_fields__ or k in ('peak_flow1', 'peak_flow2', 'sort_lanes')}
     scn = build_scenario(scenario, agent, **scn_kw)
     return TrafficEnv(scn, **kw) if n_env is None else VecTrafficEnv(scn, n_env, **kw)

@@ -259,7 +259,7 @@ _RIGHT, _THROUGH, _LEFT = 0, 1, 2
 
 
 def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: int = 925,
-                     **env_kw) -> Scenario:
+                     sort_lanes: bool = True, **env_kw) -> Scenario:
     L0, L0_END, N = 200.0, 75.0, 5
     pos: Dict[str, Tuple[float, float]] = {}
     for r in range(N):
@@ -456,7 +456,7 @@ def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: in
     rid = {rn: i for i, rn in enumerate(route_names)}
     flows = np.array([[tb, te, vph, rid[(e1, e2)]] for e1, e2, tb, te, vph in demand], np.int32)
 
-    return Scenario(
+    scn = Scenario(
         name='large_grid', agent=agent, node_names=node_names, n_agent=N * N,
         lane_names=lane_names, lane_len=lane_len, lane_vmax=lane_vmax, lane_node=lane_node,
         lane_det_start=lane_det, lane_opp=lane_opp, lane_up=lane_up,
@@ -470,6 +470,61 @@ def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: in
         obs_kind=obs_kind, obs_src=obs_src, flows=flows, obs_len=lens,
         extra={'peak_flow1': peak_flow1, 'peak_flow2': peak_flow2, 'demand': demand},
         **env_kw)
+    return sort_lanes_by_load(scn) if sort_lanes else scn
+
+
+def lane_load(scn: Scenario) -> np.ndarray:
+    """Vehicles per episode routed over every lane (static proxy for queue length)."""
+    load = np.zeros(scn.n_lane)
+    for tb, te, vph, r in scn.flows:
+        veh = (te - tb) * vph / 3600.0
+        l = int(scn.route_entry_lane[r])
+        while l >= 0:
+            load[l] += veh
+            l = int(scn.mv_next[l, r])
+    return load
+
+
+def permute_lanes(scn: Scenario, order) -> Scenario:
+    """Renumber lanes: new lane i = old lane order[i].  Lane numbering is free (every table is
+    index based); the HIP microsimulator maps thread -> lane, so putting the busiest lanes first
+    packs long queues into the same wavefront and lets the other wavefronts retire early."""
+    order = np.asarray(order)
+    new_of = np.empty(len(order), np.int64)
+    new_of[order] = np.arange(len(order))
+
+    def remap(v):
+        v = np.asarray(v)
+        out = v.copy()
+        m = v >= 0
+        out[m] = new_of[v[m]]
+        return out.astype(v.dtype)
+    scn.lane_names = [scn.lane_names[i] for i in order]
+    for k in ('lane_len', 'lane_vmax', 'lane_node', 'lane_det_start'):
+        setattr(scn, k, getattr(scn, k)[order])
+    scn.lane_opp = remap(scn.lane_opp[order])
+    up = remap(scn.lane_up[order])
+    for i in range(len(up)):                                    # keep "ascending feeder index" order
+        row = np.sort(up[i][up[i] >= 0])
+        up[i] = -1
+        up[i, :len(row)] = row
+    scn.lane_up = up
+    scn.mv_next = remap(scn.mv_next[order])
+    scn.mv_link = scn.mv_link[order]
+    scn.route_entry_lane = remap(scn.route_entry_lane)
+    scn.agent_lanes = remap(scn.agent_lanes)
+    scn.link_lane = remap(scn.link_lane)
+    src = scn.obs_src.copy()
+    m = (scn.obs_kind >= 1) & (scn.obs_kind <= 3)
+    src[m] = new_of[scn.obs_src[m]]
+    scn.obs_src = src.astype(np.int32)
+    return scn
+
+
+def sort_lanes_by_load(scn: Scenario) -> Scenario:
+    load = lane_load(scn)
+    order = sorted(range(scn.n_lane), key=lambda i: (-load[i], i))
+    return permute_lanes(scn, order)
 
 
 def build_scenario(name: str, agent: str = 'ma2c', **kw) -> Scenario:
