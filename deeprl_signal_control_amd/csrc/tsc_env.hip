@@ -23,6 +23,7 @@
 #include "../../include/tsc.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -39,6 +40,9 @@ struct EnvDev {
     const int *route_entry;        // [NR]
     const int *flow_ptr;           // [NR+1] CSR over flows sorted by route
     const int *flows;              // [NF*4] begin,end,vph,route (sorted by route, stable)
+    const int *lane_routes;        // [NL][2] routes whose entry lane this is (-1 pad)
+    const uint8_t *emit_tab;       // [NR][emit_len] vehicles each route's flows emit at second t
+    int emit_len;
     const int *agent_lanes, *agent_nlane, *agent_nlink, *agent_nphase;
     const uint8_t *green_tab, *yellow_tab;
     const int *nbr, *obs_kind, *obs_src;
@@ -199,7 +203,9 @@ __global__ void fingerprint_kernel(EnvDev P, const float *pi) {
     if (i < tot) P.fp[i] = pi[i];                                  // pi[:-1] is applied at gather time
 }
 
-__global__ void __launch_bounds__(1024)
+template <int MAXT, int CH>   // MAXT: register budget (256-thread instantiation for networks with <= 256 lanes);
+                              // CH: vehicles advanced per chunk (1 = scalar walk, 4 = 4-wide ILP)
+__global__ void __launch_bounds__(MAXT)
 step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, double *__restrict__ reward,
             double *__restrict__ greward, uint8_t *__restrict__ done, int train_mode) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -234,6 +240,25 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     int t = P.tsec[e];
     const uint32_t seed = P.seed[e];
     unsigned arrived = 0;
+    // everything the per-second loop needs from constant tables / per-route state is pulled into registers
+    // here, so no dependent global load sits between two barriers
+    int up0 = -1, up1 = -1, up2 = -1, up3 = -1, opp_node = -1, myr0 = -1, myr1 = -1;
+    int pend0 = 0, pend1 = 0, ser0 = 0, ser1 = 0;
+    unsigned long long em0 = 0ull, em1 = 0ull;            // emissions of my routes, 8 bits per second of this step
+    float opp_len = 1.0f;
+    if (lane) {
+        up0 = P.lane_up[l * kMaxUp]; up1 = P.lane_up[l * kMaxUp + 1]; up2 = P.lane_up[l * kMaxUp + 2]; up3 = P.lane_up[l * kMaxUp + 3];
+        if (my_opp >= 0) { opp_len = P.lane_len[my_opp]; opp_node = P.lane_node[my_opp]; }
+        myr0 = P.lane_routes[l * 2]; myr1 = P.lane_routes[l * 2 + 1];
+        if (myr0 >= 0) {
+            pend0 = P.pending[(size_t)e * NR + myr0]; ser0 = P.serial[(size_t)e * NR + myr0];
+            for (int q = 0; q < P.ctrl; ++q) em0 |= (unsigned long long)P.emit_tab[(size_t)myr0 * P.emit_len + t + q] << (8 * q);
+        }
+        if (myr1 >= 0) {
+            pend1 = P.pending[(size_t)e * NR + myr1]; ser1 = P.serial[(size_t)e * NR + myr1];
+            for (int q = 0; q < P.ctrl; ++q) em1 |= (unsigned long long)P.emit_tab[(size_t)myr1 * P.emit_len + t + q] << (8 * q);
+        }
+    }
     __syncthreads();
 
     for (int sub = 0; sub < P.ctrl; ++sub, ++t) {
@@ -244,84 +269,121 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             int ncross = 0;
             bool all_crossed = true;
             float pnx = INFINITY, pox = 0.0f, pov = 0.0f;
-            // software prefetch: vehicle i+1 is loaded while vehicle i is being advanced (slot i+1 is never
-            // the slot being written, kept <= i)
-            float nx = 0.f, nv = 0.f, nsf = 0.f;
-            uint32_t nm = 0u;
-            if (n > 0) { nx = X[l]; nv = V[l]; nsf = SF[l]; nm = M[l]; }
-            for (int i = 0; i < n; ++i) {
-                const float x = nx, v = nv, sf = nsf;
-                const uint32_t meta = nm;
-                if (i + 1 < n) {
-                    const int o1 = (i + 1) * NLP + l;
-                    nx = X[o1]; nv = V[o1]; nsf = SF[o1]; nm = M[o1];
+            // Vehicles are advanced in chunks of CH: stage 1 does everything that only needs the OLD state
+            // (table look-ups, signal test, car-following evaluations), stage 2 is the sequential part (who
+            // may cross, clamps, compaction); the next chunk is prefetched meanwhile.  CH = 1 is what ships:
+            // CH = 4 (4 overlapped div/sqrt chains) needs 203 VGPRs, halves the resident workgroups and
+            // measured 2x slower.  Same operations on the same inputs either way -> bit-identical.
+            float cx[CH], cv[CH], csf[CH];
+            uint32_t cm[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                cx[u] = 0.f; cv[u] = 0.f; csf[u] = 1.f; cm[u] = 0u;
+                if (u < n) { const int o = u * NLP + l; cx[u] = X[o]; cv[u] = V[o]; csf[u] = SF[o]; cm[u] = M[o]; }
+            }
+            for (int i0 = 0; i0 < n; i0 += CH) {
+                float x4[CH], v4[CH], sf4[CH], v04[CH], vcar[CH], vline[CH];
+                uint32_t m4[CH];
+                int tl4[CH], k4[CH];
+                bool open4[CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) { x4[u] = cx[u]; v4[u] = cv[u]; sf4[u] = csf[u]; m4[u] = cm[u]; }
+                // prefetch the next chunk (slots > i0+3 are never written before they are read)
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const int i = i0 + CH + u;
+                    if (i < n) { const int o = i * NLP + l; cx[u] = X[o]; cv[u] = V[o]; csf[u] = SF[o]; cm[u] = M[o]; }
                 }
-                int w = (int)(meta & 0xFFFFu);
-                const int r = (int)(meta >> 16);
-                const float v0 = vmax * sf;
-                const int mvp = s.mv[l * NR + r];
-                const int tl = (int)(short)(mvp & 0xFFFF), k = (int)(short)(mvp >> 16);
-                const bool sink = tl == -1;
-                const bool open = sig_open(tl, k, my_node, w, x, v, L, link, P.KMAX, P.teleport);
-                bool can_cross = false;
-                if (all_crossed) {
-                    can_cross = open;
-                    if (can_cross && k >= 0 && k % 3 == 2 && w < P.teleport && my_opp >= 0 && s.n[my_opp] > 0) {
-                        // left turns yield to the opposing head going right / through
-                        const uint32_t om = s.hm[my_opp];
-                        const int mo = s.mv[my_opp * NR + (int)(om >> 16)];
-                        const int tlo = (int)(short)(mo & 0xFFFF), ko = (int)(short)(mo >> 16);
-                        if (ko >= 0 && ko % 3 != 2) {
-                            const float xo = s.hx[my_opp], vo = s.hv[my_opp], Lo = P.lane_len[my_opp];
-                            if (sig_open(tlo, ko, P.lane_node[my_opp], (int)(om & 0xFFFFu), xo, vo, Lo, link, P.KMAX, P.teleport)) {
-                                const float d = Lo - xo;
-                                if (d < vo * kYieldT + kYieldD) can_cross = false;
+                // ---- stage 1
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    vcar[u] = 0.f; vline[u] = 0.f; open4[u] = false; tl4[u] = -2; k4[u] = -1; v04[u] = 1.f;
+                    const int i = i0 + u;
+                    if (i < n) {
+                        const int w = (int)(m4[u] & 0xFFFFu), r = (int)(m4[u] >> 16);
+                        v04[u] = vmax * sf4[u];
+                        const int mvp = s.mv[l * NR + r];
+                        tl4[u] = (int)(short)(mvp & 0xFFFF); k4[u] = (int)(short)(mvp >> 16);
+                        open4[u] = sig_open(tl4[u], k4[u], my_node, w, x4[u], v4[u], L, link, P.KMAX, P.teleport);
+                        if (i > 0) {
+                            const float lx = u == 0 ? pox : x4[u > 0 ? u - 1 : 0], lv = u == 0 ? pov : v4[u > 0 ? u - 1 : 0];
+                            vcar[u] = follow(v4[u], v04[u], true, (lx - kLen) - x4[u], lv, kS0);
+                        }
+                        if (!open4[u]) vline[u] = follow(v4[u], v04[u], true, L - x4[u], 0.0f, 0.0f);
+                    }
+                }
+                // ---- stage 2
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const int i = i0 + u;
+                    if (i >= n) break;
+                    const float x = x4[u], v = v4[u], sf = sf4[u], v0 = v04[u];
+                    const uint32_t meta = m4[u];
+                    int w = (int)(meta & 0xFFFFu);
+                    const int r = (int)(meta >> 16);
+                    const int tl = tl4[u], k = k4[u];
+                    const bool sink = tl == -1;
+                    const bool open = open4[u];
+                    bool can_cross = false;
+                    if (all_crossed) {
+                        can_cross = open;
+                        if (can_cross && k >= 0 && k % 3 == 2 && w < P.teleport && my_opp >= 0 && s.n[my_opp] > 0) {
+                            // left turns yield to the opposing head going right / through
+                            const uint32_t om = s.hm[my_opp];
+                            const int mo = s.mv[my_opp * NR + (int)(om >> 16)];
+                            const int tlo = (int)(short)(mo & 0xFFFF), ko = (int)(short)(mo >> 16);
+                            if (ko >= 0 && ko % 3 != 2) {
+                                const float xo = s.hx[my_opp], vo = s.hv[my_opp], Lo = opp_len;
+                                if (sig_open(tlo, ko, opp_node, (int)(om & 0xFFFFu), xo, vo, Lo, link, P.KMAX, P.teleport)) {
+                                    const float d = Lo - xo;
+                                    if (d < vo * kYieldT + kYieldD) can_cross = false;
+                                }
                             }
                         }
+                        if (can_cross && tl >= 0 && s.n[tl] + kMaxCross > kCap) can_cross = false;
+                        if (can_cross && ncross >= kMaxCross) can_cross = false;
+                        if (tl < -1) can_cross = false;
                     }
-                    if (can_cross && tl >= 0 && s.n[tl] + kMaxCross > kCap) can_cross = false;
-                    if (can_cross && ncross >= kMaxCross) can_cross = false;
-                    if (tl < -1) can_cross = false;
-                }
-                const bool line_block = all_crossed ? !can_cross : !open;
-                const bool tgt_lead = can_cross && !sink && s.n[tl] > 0;
-                float vn;
-                if (i > 0) vn = follow(v, v0, true, (pox - kLen) - x, pov, kS0);
-                else if (tgt_lead) vn = follow(v, v0, true, (L - x) + (s.tx[tl] - kLen), s.tv[tl], kS0);
-                else vn = follow(v, v0, false, 0.0f, 0.0f, 0.0f);
-                if (line_block) {
-                    const float v2 = follow(v, v0, true, L - x, 0.0f, 0.0f);
-                    if (v2 < vn) vn = v2;
-                }
-                float xn = x + vn;
-                bool clamped = false;
-                if (xn > pnx - kLen) { xn = pnx - kLen; clamped = true; }
-                if (tgt_lead) {
-                    const float lim = L + (s.tx[tl] - kLen);
-                    if (xn > lim) { xn = lim; clamped = true; }
-                }
-                if (!can_cross && xn > L) { xn = L; clamped = true; }
-                if (xn < x) { xn = x; clamped = true; }
-                if (clamped) vn = xn - x;
-                w = (vn < kHalt) ? w + 1 : 0;
-                pnx = xn; pox = x; pov = v;
-                const uint32_t nmeta = (uint32_t)w | ((uint32_t)r << 16);
-                if (can_cross && xn >= L) {
-                    if (!sink) {
-                        const int o = nsent * NLP + l;
-                        s.ox[o] = xn - L; s.ov[o] = vn; s.osf[o] = sf; s.om[o] = nmeta; s.oto[o] = tl;
-                        ++nsent;
+                    const bool line_block = all_crossed ? !can_cross : !open;
+                    const bool tgt_lead = can_cross && !sink && s.n[tl] > 0;
+                    float vn;
+                    if (i > 0) vn = vcar[u];
+                    else if (tgt_lead) vn = follow(v, v0, true, (L - x) + (s.tx[tl] - kLen), s.tv[tl], kS0);
+                    else vn = follow(v, v0, false, 0.0f, 0.0f, 0.0f);
+                    if (line_block) {
+                        const float v2 = open ? follow(v, v0, true, L - x, 0.0f, 0.0f) : vline[u];
+                        if (v2 < vn) vn = v2;
+                    }
+                    float xn = x + vn;
+                    bool clamped = false;
+                    if (xn > pnx - kLen) { xn = pnx - kLen; clamped = true; }
+                    if (tgt_lead) {
+                        const float lim = L + (s.tx[tl] - kLen);
+                        if (xn > lim) { xn = lim; clamped = true; }
+                    }
+                    if (!can_cross && xn > L) { xn = L; clamped = true; }
+                    if (xn < x) { xn = x; clamped = true; }
+                    if (clamped) vn = xn - x;
+                    w = (vn < kHalt) ? w + 1 : 0;
+                    pnx = xn; pox = x; pov = v;
+                    const uint32_t nmeta = (uint32_t)w | ((uint32_t)r << 16);
+                    if (can_cross && xn >= L) {
+                        if (!sink) {
+                            const int o = nsent * NLP + l;
+                            s.ox[o] = xn - L; s.ov[o] = vn; s.osf[o] = sf; s.om[o] = nmeta; s.oto[o] = tl;
+                            ++nsent;
+                        } else {
+                            ++arrived;
+                        }
+                        ++ncross;
                     } else {
-                        ++arrived;
+                        all_crossed = false;
+                        const int o = kept * NLP + l;
+                        X[o] = xn; V[o] = vn; SF[o] = sf; M[o] = nmeta;
+                        if (kept == 0) { hx = xn; hv = vn; hm = nmeta; }
+                        tx = xn; tv = vn;
+                        ++kept;
                     }
-                    ++ncross;
-                } else {
-                    all_crossed = false;
-                    const int o = kept * NLP + l;
-                    X[o] = xn; V[o] = vn; SF[o] = sf; M[o] = nmeta;
-                    if (kept == 0) { hx = xn; hv = vn; hm = nmeta; }
-                    tx = xn; tv = vn;
-                    ++kept;
                 }
             }
             s.nout[l] = nsent;
@@ -331,7 +393,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         if (lane) {
             n = kept;
             for (int u = 0; u < kMaxUp; ++u) {
-                const int src = P.lane_up[l * kMaxUp + u];
+                const int src = u == 0 ? up0 : u == 1 ? up1 : u == 2 ? up2 : up3;
                 if (src < 0) continue;
                 const int cnt = s.nout[src];
                 for (int j = 0; j < cnt; ++j) {
@@ -347,24 +409,19 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     }
                 }
             }
-            for (int r = 0; r < NR; ++r) {
-                if (P.route_entry[r] != l) continue;
-                int pend = P.pending[(size_t)e * NR + r];
-                for (int f = P.flow_ptr[r]; f < P.flow_ptr[r + 1]; ++f) {
-                    const int b = P.flows[f * 4], en = P.flows[f * 4 + 1];
-                    if (t >= b && t < en) {
-                        const long long tau = t - b, vph = P.flows[f * 4 + 2];
-                        pend += (int)((((tau + 1) * vph + 3599) / 3600) - ((tau * vph + 3599) / 3600));
-                    }
-                }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {                       // my entry routes, ascending
+                const int r = q == 0 ? myr0 : myr1;
+                if (r < 0) continue;
+                int pend = (q == 0 ? pend0 : pend1) + (int)(((q == 0 ? em0 : em1) >> (8 * sub)) & 0xFFull);
+                int ser = q == 0 ? ser0 : ser1;
                 if (pend > 0 && n < kCap) {
                     const float xt = n > 0 ? tx : (L + kLen) + kS0;
                     const float xmax = (xt - kLen) - kS0;
                     if (!(xmax < kLen)) {
-                        const uint32_t ser = (uint32_t)P.serial[(size_t)e * NR + r];
-                        const float u0 = u01(hash32(seed, (uint32_t)r, ser, 0));
-                        const float u1 = u01(hash32(seed, (uint32_t)r, ser, 1));
-                        const float u2 = u01(hash32(seed, (uint32_t)r, ser, 2));
+                        const float u0 = u01(hash32(seed, (uint32_t)r, (uint32_t)ser, 0));
+                        const float u1 = u01(hash32(seed, (uint32_t)r, (uint32_t)ser, 1));
+                        const float u2 = u01(hash32(seed, (uint32_t)r, (uint32_t)ser, 2));
                         const float ax = kLen + u0 * (xmax - kLen);
                         const float asf = 1.0f + 0.2f * ((u1 + u2) - 1.0f);
                         const uint32_t am = (uint32_t)r << 16;
@@ -374,10 +431,10 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                         tx = ax; tv = 0.0f;
                         ++n;
                         --pend;
-                        P.serial[(size_t)e * NR + r] = (int)ser + 1;
+                        ++ser;
                     }
                 }
-                P.pending[(size_t)e * NR + r] = pend;
+                if (q == 0) { pend0 = pend; ser0 = ser; } else { pend1 = pend; ser1 = ser; }
             }
             s.n[l] = n; s.hx[l] = hx; s.hv[l] = hv; s.hm[l] = hm; s.tx[l] = tx; s.tv[l] = tv;
         }
@@ -387,6 +444,8 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     // ---- K4: detectors (envs/env.py:325-407): wave, halting, wait of the front-most vehicle
     if (lane) {
         P.N[(size_t)e * NLP + l] = n;
+        if (myr0 >= 0) { P.pending[(size_t)e * NR + myr0] = pend0; P.serial[(size_t)e * NR + myr0] = ser0; }
+        if (myr1 >= 0) { P.pending[(size_t)e * NR + myr1] = pend1; P.serial[(size_t)e * NR + myr1] = ser1; }
         int wave = 0, halt = 0, hw = 0;
         for (int i = 0; i < n; ++i) {
             const float x = X[i * NLP + l];
@@ -459,6 +518,7 @@ struct tsc_env {
     std::vector<void *> allocs;
     size_t smem;
     uint32_t *d_seeds;
+    int chunk;
 };
 
 namespace tsc {
@@ -564,6 +624,32 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     ptr[NR] = (int)fl.size() / 4;
     UP(flows, int, fl.data(), fl.size());
     UP(flow_ptr, int, ptr.data(), NR + 1);
+    {   // per-lane entry routes (<= 2) and per-route emission table (DESIGN.md microsim spec, rule 6)
+        std::vector<int> lr((size_t)NL * 2, -1);
+        for (int r = 0; r < NR; ++r) {
+            const int l = sc->route_entry[r];
+            if (l < 0 || l >= NL) return tsc::fail("tsc_env_create: route %d has no entry lane", r);
+            if (lr[l * 2] < 0) lr[l * 2] = r;
+            else if (lr[l * 2 + 1] < 0) lr[l * 2 + 1] = r;
+            else return tsc::fail("tsc_env_create: more than 2 routes enter lane %d", l);
+        }
+        UP(lane_routes, int, lr.data(), lr.size());
+        P.emit_len = sc->episode_length_sec + 64;
+        std::vector<uint8_t> em((size_t)NR * P.emit_len, 0);
+        for (int f = 0; f < sc->n_flow; ++f) {
+            const long long b = sc->flows[f * 4], en = sc->flows[f * 4 + 1], vph = sc->flows[f * 4 + 2];
+            const int r = sc->flows[f * 4 + 3];
+            for (long long t = b; t < en && t < P.emit_len; ++t) {
+                const long long tau = t - b;
+                const long long c = (((tau + 1) * vph + 3599) / 3600) - ((tau * vph + 3599) / 3600);
+                const long long v = em[(size_t)r * P.emit_len + t] + c;
+                if (v > 255) return tsc::fail("tsc_env_create: flow %d emits more than 255 vehicles per second", f);
+                em[(size_t)r * P.emit_len + t] = (uint8_t)v;
+            }
+        }
+        UP(emit_tab, uint8_t, em.data(), em.size());
+    }
+    if (sc->control_interval_sec > 8) return tsc::fail("tsc_env_create: control interval > 8 s unsupported");
     UP(agent_lanes, int, sc->agent_lanes, A * P.LMAX);
     UP(agent_nlane, int, sc->agent_nlane, A); UP(agent_nlink, int, sc->agent_nlink, A);
     UP(agent_nphase, int, sc->agent_nphase, A);
@@ -584,7 +670,9 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     h->allocs.push_back(h->d_seeds);
     h->smem = smem_bytes(P);
     if (h->smem > 160 * 1024) return tsc::fail("tsc_env_create: LDS need %zu B > 160 KiB", h->smem);
-    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    h->chunk = 1;   // 4-wide chunks were measured 2x slower (203 VGPRs -> half the resident workgroups)
     TSC_HIP(hipFuncSetAttribute((const void *)reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     *out = h;
     return 0;
@@ -627,8 +715,12 @@ int tsc_env_step(tsc_env *h, const int32_t *action_dev, float *obs_dev, double *
     if (!h || !action_dev || !obs_dev || !reward_dev || !global_reward_dev || !done_dev)
         return tsc::fail("tsc_env_step: bad arguments");
     tsc::ProfScope ps(tsc::KID_ENV_STEP, h->stream);
-    hipLaunchKernelGGL(step_kernel, dim3(h->P.E), dim3(h->P.NLP), h->smem, h->stream, h->P, action_dev, obs_dev,
-                       reward_dev, global_reward_dev, done_dev, (int)train_mode);
+    if (h->P.NLP <= 256)
+        hipLaunchKernelGGL((step_kernel<256, 1>), dim3(h->P.E), dim3(h->P.NLP), h->smem, h->stream, h->P, action_dev, obs_dev,
+                           reward_dev, global_reward_dev, done_dev, (int)train_mode);
+    else
+        hipLaunchKernelGGL((step_kernel<1024, 1>), dim3(h->P.E), dim3(h->P.NLP), h->smem, h->stream, h->P, action_dev, obs_dev,
+                           reward_dev, global_reward_dev, done_dev, (int)train_mode);
     TSC_HIP(hipGetLastError());
     return 0;
 }

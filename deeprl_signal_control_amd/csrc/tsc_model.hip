@@ -53,7 +53,9 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 constexpr int kWhLd = kG4 + 4;
 constexpr int kHsLd = 64 + 4;
 
-__global__ void __launch_bounds__(256) lstm_fwd_kernel(const float *__restrict__ params, Layout lay, float *Z,
+template <bool PF>   // PF: prefetch the next step's Z under the MFMAs (training, T > 1); the 1-step rollout
+                      // variant keeps the register budget for 2 workgroups per CU
+__global__ void __launch_bounds__(256, PF ? 1 : 2) lstm_fwd_kernel(const float *__restrict__ params, Layout lay, float *Z,
                                                       const float *state_in, float *state_out,
                                                       float *Hh, float *Cc, float *Hp, const uint8_t *done,
                                                       int T, int E, int store) {
@@ -84,15 +86,36 @@ __global__ void __launch_bounds__(256) lstm_fwd_kernel(const float *__restrict__
         hs[j * kHsLd + erow[r]] = h0;
     }
     __syncthreads();
+    f32x16 zn[4];                                   // x*Wx+b of the NEXT step, prefetched under the MFMAs
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int e = e0 + erow[r];
+            zn[q][r] = e < E ? Z[(((long long)g * N + e) * kG4) + 64 * q + j] : 0.f;
+        }
     for (int t = 0; t < T; ++t) {
+        if (!PF && t > 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int e = e0 + erow[r];
+                    zn[q][r] = e < E ? Z[(((long long)g * N + (long long)t * E + e) * kG4) + 64 * q + j] : 0.f;
+                }
+        }
         f32x16 acc[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q) acc[q] = zn[q];
+        if (PF && t + 1 < T) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int e = e0 + erow[r];
-                acc[q][r] = e < E ? Z[(((long long)g * N + (long long)t * E + e) * kG4) + 64 * q + j] : 0.f;
-            }
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int e = e0 + erow[r];
+                    zn[q][r] = e < E ? Z[(((long long)g * N + (long long)(t + 1) * E + e) * kG4) + 64 * q + j] : 0.f;
+                }
+        }
         if (store) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -169,6 +192,31 @@ __global__ void __launch_bounds__(256) lstm_bwd_kernel(const float *__restrict__
         erow[r] = r0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         dh_rec[r] = 0.f; dc_rec[r] = 0.f;
     }
+    // inputs of the CURRENT step live in registers; those of step t-1 are prefetched while the MFMAs of
+    // step t run (one workgroup per CU: nothing else would hide the HBM latency)
+    float gi[16], gf[16], go[16], gu[16], c_cur[16], c_prv[16], dh_in[16], keepv[16];
+    float ni[16], nf[16], no_[16], nu[16], n_prv[16], ndh[16], nkeep[16];
+    auto load_step = [&](int t, float *li_, float *lf_, float *lo_, float *lu_, float *lprv, float *ldh, float *lkeep) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int e = e0 + erow[r];
+            if (e < E) {
+                const long long n = (long long)g * N + (long long)t * E + e;
+                li_[r] = Z[n * kG4 + j]; lf_[r] = Z[n * kG4 + 64 + j]; lo_[r] = Z[n * kG4 + 128 + j]; lu_[r] = Z[n * kG4 + 192 + j];
+                ldh[r] = dH[n * kL + j];
+                lprv[r] = t > 0 ? Cc[(n - E) * kL + j] : state_bw[((long long)g * E + e) * 2 * kL + j];
+                lkeep[r] = 1.0f - (float)done[(long long)t * E + e];
+            } else {
+                li_[r] = lf_[r] = lo_[r] = lu_[r] = ldh[r] = lprv[r] = 0.f; lkeep[r] = 0.f;
+            }
+        }
+    };
+    load_step(T - 1, gi, gf, go, gu, c_prv, dh_in, keepv);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int e = e0 + erow[r];
+        c_cur[r] = e < E ? Cc[((long long)g * N + (long long)(T - 1) * E + e) * kL + j] : 0.f;
+    }
     __syncthreads();
     for (int t = T - 1; t >= 0; --t) {
 #pragma unroll
@@ -177,11 +225,11 @@ __global__ void __launch_bounds__(256) lstm_bwd_kernel(const float *__restrict__
             float di = 0.f, df = 0.f, dog = 0.f, du = 0.f;
             if (e < E) {
                 const long long n = (long long)g * N + (long long)t * E + e;
-                const float ig = Z[n * kG4 + j], fg = Z[n * kG4 + 64 + j], og = Z[n * kG4 + 128 + j], ug = Z[n * kG4 + 192 + j];
-                const float cn = Cc[n * kL + j];
-                const float keep = 1.0f - (float)done[(long long)t * E + e];
-                const float cp = (t > 0 ? Cc[(n - E) * kL + j] : state_bw[((long long)g * E + e) * 2 * kL + j]) * keep;
-                const float dh = dH[n * kL + j] + dh_rec[r];
+                const float ig = gi[r], fg = gf[r], og = go[r], ug = gu[r];
+                const float cn = c_cur[r];
+                const float keep = keepv[r];
+                const float cp = c_prv[r] * keep;
+                const float dh = dh_in[r] + dh_rec[r];
                 const float tc = tanhf(cn);
                 dog = dh * tc * og * (1.0f - og);
                 const float dc = dh * og * (1.0f - tc * tc) + dc_rec[r];
@@ -197,6 +245,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_kernel(const float *__restrict__
             dzs[(192 + j) * kDzLd + erow[r]] = du;
         }
         __syncthreads();
+        if (t > 0) load_step(t - 1, ni, nf, no_, nu, n_prv, ndh, nkeep);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -208,9 +257,10 @@ __global__ void __launch_bounds__(256) lstm_bwd_kernel(const float *__restrict__
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int e = e0 + erow[r];
-            const float keep = e < E ? 1.0f - (float)done[(long long)t * E + e] : 0.f;
-            dh_rec[r] = acc[r] * keep;
+            dh_rec[r] = acc[r] * keepv[r];
+            c_cur[r] = c_prv[r];                                // Cc[t-1] (unmasked) becomes the current cell
+            gi[r] = ni[r]; gf[r] = nf[r]; go[r] = no_[r]; gu[r] = nu[r];
+            c_prv[r] = n_prv[r]; dh_in[r] = ndh[r]; keepv[r] = nkeep[r];
         }
         __syncthreads();
     }
@@ -578,7 +628,8 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     MALLOC(m->ws, float, m->ws_floats); MALLOC(m->wsc, float, m->wsc_floats);
     m->lds_fwd = sizeof(float) * (64 * kWhLd + 64 * kHsLd);
     m->lds_bwd = sizeof(float) * (kG4 * kWtLd + kG4 * kDzLd);
-    TSC_HIP(hipFuncSetAttribute((const void *)lstm_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fwd));
+    TSC_HIP(hipFuncSetAttribute((const void *)lstm_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fwd));
+    TSC_HIP(hipFuncSetAttribute((const void *)lstm_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fwd));
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bwd));
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((m->nparam + 255) / 256)), dim3(256), 0, 0, m->ms, m->nparam, 1.0f);
     TSC_HIP(hipDeviceSynchronize());
@@ -650,7 +701,7 @@ int tsc_model_forward(tsc_model *m, const float *obs, const uint8_t *done, float
     // the rollout forward borrows the head of the training activations (row count E <= T*E)
     if (dense_forward(m, obs, E, m->X1, m->Z)) return tsc::fail("tsc_model_forward: gemm launch failed");
     tsc::ProfScope ps1(tsc::KID_LSTM_FWD, m->stream);
-    hipLaunchKernelGGL(lstm_fwd_kernel, dim3(L.G, (E + 63) / 64), dim3(256), m->lds_fwd, m->stream, m->params, L, m->Z,
+    hipLaunchKernelGGL(lstm_fwd_kernel<false>, dim3(L.G, (E + 63) / 64), dim3(256), m->lds_fwd, m->stream, m->params, L, m->Z,
                        m->state_fw, advance ? m->state_fw : (float *)nullptr, m->Hh, m->Cc, m->Hp, done, 1, E, 0);
     ps1.stop();
     tsc::ProfScope ps3(tsc::KID_HEAD_FWD, m->stream);
@@ -701,7 +752,7 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
     // forward with stored activations, from the backward state (agents/policies.py:144-152)
     if (dense_forward(m, m->r_obs, N, m->X1, m->Z)) return tsc::fail("gemm launch failed");
     tsc::ProfScope ps2(tsc::KID_LSTM_FWD, m->stream);
-    hipLaunchKernelGGL(lstm_fwd_kernel, dim3((unsigned)G, (unsigned)((E + 63) / 64)), dim3(256), m->lds_fwd, st, m->params, L,
+    hipLaunchKernelGGL(lstm_fwd_kernel<true>, dim3((unsigned)G, (unsigned)((E + 63) / 64)), dim3(256), m->lds_fwd, st, m->params, L,
                        m->Z, m->state_bw, (float *)nullptr, m->Hh, m->Cc, m->Hp, m->r_done, (int)T, (int)E, 1);
     ps2.stop();
     tsc::ProfScope ps7(tsc::KID_HEAD_BWD, m->stream);
