@@ -39,7 +39,7 @@ _LIB = None
 SYMBOLS = ['tsc_last_error', 'tsc_version', 'tsc_profile_enable', 'tsc_profile_reset', 'tsc_profile_read',
            'tsc_profile_name', 'tsc_env_create', 'tsc_env_destroy', 'tsc_env_set_stream',
            'tsc_env_reset', 'tsc_env_set_fingerprint', 'tsc_env_step', 'tsc_env_get_state',
-           'tsc_env_live_vehicles',
+           'tsc_env_live_vehicles', 'tsc_env_debug_clock',
            'tsc_model_create', 'tsc_model_destroy', 'tsc_model_set_stream', 'tsc_model_layout',
            'tsc_model_set_params', 'tsc_model_get_params', 'tsc_model_get_opt_state', 'tsc_model_set_opt_state',
            'tsc_model_reset', 'tsc_model_forward', 'tsc_model_sample', 'tsc_model_add_transition',
@@ -72,6 +72,7 @@ def lib():
     L.tsc_env_step.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int32]
     L.tsc_env_get_state.argtypes = [vp, C.c_int32, _ip, _fp, _fp, _fp, _ip, _ip, _ip, _ip, _ip]
     L.tsc_env_live_vehicles.argtypes = [vp, C.POINTER(C.c_double)]
+    L.tsc_env_debug_clock.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64)]
     _LIB = L
     return L
 

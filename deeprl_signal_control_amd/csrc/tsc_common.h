@@ -43,7 +43,7 @@ inline hipError_t upload(T **dst, const T *src, size_t count) {
 enum KernelId : int {
     KID_ENV_STEP = 0, KID_FC_GEMM, KID_ZX_GEMM, KID_LSTM_FWD, KID_HEAD_FWD, KID_SAMPLE, KID_ADD_TRANS,
     KID_RETURNS, KID_HEAD_BWD, KID_LSTM_BWD, KID_DWO_GEMM, KID_DWH_GEMM, KID_DWX_GEMM, KID_DX1_GEMM,
-    KID_DW1_GEMM, KID_GRADNORM, KID_RMSPROP, KID_TRANSPOSE, KID_FINGERPRINT, KID_COUNT
+    KID_DW1_GEMM, KID_GRADNORM, KID_RMSPROP, KID_TRANSPOSE, KID_FINGERPRINT, KID_FUSED_FWD, KID_COUNT
 };
 
 struct ProfState {

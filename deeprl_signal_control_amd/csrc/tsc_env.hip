@@ -34,6 +34,7 @@ constexpr int kCap = TSC_LANE_CAP, kMaxCross = TSC_MAX_CROSS, kMaxUp = TSC_MAX_U
 
 struct EnvDev {
     int NL, NLP, NR, A, NF, KMAX, PMAX, LMAX, SMAX, NBR, E;
+    int NU, NLA;                   // lanes that can ever hold a vehicle (prefix after load sorting); threads per workgroup
     const float *lane_len, *lane_vmax, *lane_det;
     const int *lane_node, *lane_opp, *lane_up;
     const int *mv;                 // [NL*NR] packed: low16 = next lane (int16), high16 = link (int16)
@@ -57,6 +58,7 @@ struct EnvDev {
     int *prev_action;              // [E][A]
     float *fp;                     // [E][A][PMAX]
     unsigned long long *arrived;   // [E]
+    long long *dbg;                // optional: shader-clock stamps of workgroup 0 / thread 0 (tsc_env_debug_clock)
 };
 
 __device__ __forceinline__ uint32_t hash32(uint32_t seed, uint32_t route, uint32_t serial, uint32_t stream) {
@@ -90,6 +92,46 @@ __device__ __forceinline__ float follow(float v, float v0, bool has_lead, float 
     if (vn > v0 && v <= v0) vn = v0;
     if (vn < 0.0f) vn = 0.0f;
     return vn;
+}
+
+// Both car-following candidates of one vehicle at once: against its leader (or free road) and against
+// the stop line.  Same operations in the same order as two follow() calls (the free-road term is shared,
+// it is the same value), but branch-free so the div / sqrt chains of the two candidates overlap.
+__device__ __forceinline__ void follow2(float v, float v0, bool has_lead, float g, float vl, float gline,
+                                        float &vn_lead, float &vn_line) {
+    const float ratio = v / v0;
+    const float r2 = ratio * ratio;
+    const float afree = kAcc * (1.0f - r2 * r2);
+    const float base = kS0 + v * kTHead;
+    // leader
+    float sstar1 = base + (v * (v - vl)) / kCab;
+    if (sstar1 < kS0) sstar1 = kS0;
+    const float s1 = g < 0.5f ? 0.5f : g;
+    const float q1 = sstar1 / s1;
+    float acc1 = afree - kAcc * (q1 * q1);
+    float gs1 = g - kS0;
+    if (gs1 < 0.0f) gs1 = 0.0f;
+    float vsafe1 = sqrtf((kDec * kDec + vl * vl) + (2.0f * kDec) * gs1) - kDec;
+    if (!has_lead) { acc1 = afree; vsafe1 = INFINITY; }
+    // stop line (leader speed 0, no min gap)
+    float sstar2 = base + (v * (v - 0.0f)) / kCab;
+    if (sstar2 < kS0) sstar2 = kS0;
+    const float s2 = gline < 0.5f ? 0.5f : gline;
+    const float q2 = sstar2 / s2;
+    float acc2 = afree - kAcc * (q2 * q2);
+    float gs2 = gline - 0.0f;
+    if (gs2 < 0.0f) gs2 = 0.0f;
+    const float vsafe2 = sqrtf((kDec * kDec + 0.0f * 0.0f) + (2.0f * kDec) * gs2) - kDec;
+    if (acc1 < -kDec) acc1 = -kDec;
+    if (acc2 < -kDec) acc2 = -kDec;
+    float a1 = v + acc1, a2 = v + acc2;
+    if (a1 > vsafe1) a1 = vsafe1;
+    if (a2 > vsafe2) a2 = vsafe2;
+    if (a1 > v0 && v <= v0) a1 = v0;
+    if (a2 > v0 && v <= v0) a2 = v0;
+    if (a1 < 0.0f) a1 = 0.0f;
+    if (a2 < 0.0f) a2 = 0.0f;
+    vn_lead = a1; vn_line = a2;
 }
 
 __device__ __forceinline__ bool sig_open(int tl, int k, int a, int w, float x, float v, float L,
@@ -203,15 +245,23 @@ __global__ void fingerprint_kernel(EnvDev P, const float *pi) {
     if (i < tot) P.fp[i] = pi[i];                                  // pi[:-1] is applied at gather time
 }
 
-template <int MAXT, int CH>   // MAXT: register budget (256-thread instantiation for networks with <= 256 lanes);
-                              // CH: vehicles advanced per chunk (1 = scalar walk, 4 = 4-wide ILP)
-__global__ void __launch_bounds__(MAXT)
+// Register budget: the 256-thread instantiation is capped at 128 VGPRs (4 waves / SIMD).  With 155 VGPRs the
+// grid fits the chip with no slack, and whenever another kernel ran in between (i.e. always, in the training
+// loop) XCD 0 admitted ~30 workgroups one full round late -> 178 us became 316 us per step
+// (tools/bench_env.py, tsc_env_debug_clock).  The cap costs ~120 B of scratch per lane and 8 % in isolation.
+template <int MAXT>
+__global__ void __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1)
 step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, double *__restrict__ reward,
             double *__restrict__ greward, uint8_t *__restrict__ done, int train_mode) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Smem s = carve(smem_raw, P);
     const int e = blockIdx.x, l = threadIdx.x, NLP = P.NLP, NR = P.NR;
-    const bool lane = l < P.NL;
+    const bool lane = l < P.NU;             // lanes >= NU are never entered by any route: no thread, always empty
+    const bool stamp = P.dbg && blockIdx.x == 0 && threadIdx.x == 0;
+    int nstamp = 0;
+#define TSC_STAMP() do { if (stamp) P.dbg[nstamp++] = clock64(); } while (0)
+    TSC_STAMP();
+    if (P.dbg && threadIdx.x == 0) P.dbg[64 + 2 * blockIdx.x] = wall_clock64();
     float *X = P.X + (size_t)e * kCap * NLP, *V = P.V + (size_t)e * kCap * NLP, *SF = P.SF + (size_t)e * kCap * NLP;
     uint32_t *M = P.M + (size_t)e * kCap * NLP;
 
@@ -236,7 +286,21 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         my_node = P.lane_node[l]; my_opp = P.lane_opp[l];
         if (n > 0) { hx = X[l]; hv = V[l]; hm = M[l]; tx = X[(n - 1) * NLP + l]; tv = V[(n - 1) * NLP + l]; }
     }
-    if (l < NLP) { s.n[l] = n; s.hx[l] = hx; s.hv[l] = hv; s.hm[l] = hm; s.tx[l] = tx; s.tv[l] = tv; }
+    s.n[l] = n; s.hx[l] = hx; s.hv[l] = hv; s.hm[l] = hm; s.tx[l] = tx; s.tv[l] = tv;
+    for (int q = blockDim.x + l; q < NLP; q += blockDim.x) { s.n[q] = 0; s.nout[q] = 0; s.wave[q] = 0; s.halt[q] = 0; s.hwait[q] = 0; }
+    // Warm the cache hierarchy with this lane's live slots: between two control steps the policy kernels
+    // evict the vehicle state from L2, and the front-to-back walk below is a dependent chain that would pay
+    // the full HBM latency per vehicle (measured: 178 -> 310 us per step).  All loads are issued back to back
+    // here and overlap with the rest of the prologue.
+    {
+        float sink = 0.0f;
+#pragma unroll 4
+        for (int i = 1; i < n; ++i) {
+            const int o = i * NLP + l;
+            sink += X[o] + V[o] + SF[o] + __uint_as_float(M[o]);
+        }
+        if (sink == 1.2345e-37f) s.hv[l] = sink;                  // never true; keeps the loads alive
+    }
     int t = P.tsec[e];
     const uint32_t seed = P.seed[e];
     unsigned arrived = 0;
@@ -260,6 +324,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         }
     }
     __syncthreads();
+    TSC_STAMP();
 
     for (int sub = 0; sub < P.ctrl; ++sub, ++t) {
         const uint8_t *link = sub < P.yellow ? s.link_y : s.link_g;
@@ -269,126 +334,104 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             int ncross = 0;
             bool all_crossed = true;
             float pnx = INFINITY, pox = 0.0f, pov = 0.0f;
-            // Vehicles are advanced in chunks of CH: stage 1 does everything that only needs the OLD state
-            // (table look-ups, signal test, car-following evaluations), stage 2 is the sequential part (who
-            // may cross, clamps, compaction); the next chunk is prefetched meanwhile.  CH = 1 is what ships:
-            // CH = 4 (4 overlapped div/sqrt chains) needs 203 VGPRs, halves the resident workgroups and
-            // measured 2x slower.  Same operations on the same inputs either way -> bit-identical.
-            float cx[CH], cv[CH], csf[CH];
-            uint32_t cm[CH];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                cx[u] = 0.f; cv[u] = 0.f; csf[u] = 1.f; cm[u] = 0u;
-                if (u < n) { const int o = u * NLP + l; cx[u] = X[o]; cv[u] = V[o]; csf[u] = SF[o]; cm[u] = M[o]; }
-            }
-            for (int i0 = 0; i0 < n; i0 += CH) {
-                float x4[CH], v4[CH], sf4[CH], v04[CH], vcar[CH], vline[CH];
-                uint32_t m4[CH];
-                int tl4[CH], k4[CH];
-                bool open4[CH];
-#pragma unroll
-                for (int u = 0; u < CH; ++u) { x4[u] = cx[u]; v4[u] = cv[u]; sf4[u] = csf[u]; m4[u] = cm[u]; }
-                // prefetch the next chunk (slots > i0+3 are never written before they are read)
-#pragma unroll
-                for (int u = 0; u < CH; ++u) {
-                    const int i = i0 + CH + u;
-                    if (i < n) { const int o = i * NLP + l; cx[u] = X[o]; cv[u] = V[o]; csf[u] = SF[o]; cm[u] = M[o]; }
-                }
-                // ---- stage 1
-#pragma unroll
-                for (int u = 0; u < CH; ++u) {
-                    vcar[u] = 0.f; vline[u] = 0.f; open4[u] = false; tl4[u] = -2; k4[u] = -1; v04[u] = 1.f;
-                    const int i = i0 + u;
-                    if (i < n) {
-                        const int w = (int)(m4[u] & 0xFFFFu), r = (int)(m4[u] >> 16);
-                        v04[u] = vmax * sf4[u];
-                        const int mvp = s.mv[l * NR + r];
-                        tl4[u] = (int)(short)(mvp & 0xFFFF); k4[u] = (int)(short)(mvp >> 16);
-                        open4[u] = sig_open(tl4[u], k4[u], my_node, w, x4[u], v4[u], L, link, P.KMAX, P.teleport);
-                        if (i > 0) {
-                            const float lx = u == 0 ? pox : x4[u > 0 ? u - 1 : 0], lv = u == 0 ? pov : v4[u > 0 ? u - 1 : 0];
-                            vcar[u] = follow(v4[u], v04[u], true, (lx - kLen) - x4[u], lv, kS0);
-                        }
-                        if (!open4[u]) vline[u] = follow(v4[u], v04[u], true, L - x4[u], 0.0f, 0.0f);
-                    }
-                }
-                // ---- stage 2
-#pragma unroll
-                for (int u = 0; u < CH; ++u) {
-                    const int i = i0 + u;
-                    if (i >= n) break;
-                    const float x = x4[u], v = v4[u], sf = sf4[u], v0 = v04[u];
-                    const uint32_t meta = m4[u];
-                    int w = (int)(meta & 0xFFFFu);
-                    const int r = (int)(meta >> 16);
-                    const int tl = tl4[u], k = k4[u];
-                    const bool sink = tl == -1;
-                    const bool open = open4[u];
-                    bool can_cross = false;
-                    if (all_crossed) {
-                        can_cross = open;
-                        if (can_cross && k >= 0 && k % 3 == 2 && w < P.teleport && my_opp >= 0 && s.n[my_opp] > 0) {
-                            // left turns yield to the opposing head going right / through
-                            const uint32_t om = s.hm[my_opp];
-                            const int mo = s.mv[my_opp * NR + (int)(om >> 16)];
-                            const int tlo = (int)(short)(mo & 0xFFFF), ko = (int)(short)(mo >> 16);
-                            if (ko >= 0 && ko % 3 != 2) {
-                                const float xo = s.hx[my_opp], vo = s.hv[my_opp], Lo = opp_len;
-                                if (sig_open(tlo, ko, opp_node, (int)(om & 0xFFFFu), xo, vo, Lo, link, P.KMAX, P.teleport)) {
-                                    const float d = Lo - xo;
-                                    if (d < vo * kYieldT + kYieldD) can_cross = false;
-                                }
+            // Front-to-back walk; the raw state of vehicle i+1 is loaded while vehicle i is advanced.  The
+            // busiest lane's wavefront is instruction-issue bound (~500 instructions per vehicle, measured with
+            // tsc_env_debug_clock): deeper software pipelining (look-ups of vehicle i+1 one iteration ahead)
+            // and 4-wide chunks were both measured SLOWER (more instructions / fewer resident workgroups).
+            struct Raw { float x, v, sf; uint32_t m; };
+            struct Pre { int tl, k; bool open; float v0; };
+            auto load_raw = [&](int i) {
+                Raw r; r.x = 0.f; r.v = 0.f; r.sf = 1.f; r.m = 0u;
+                if (i < n) { const int o = i * NLP + l; r.x = X[o]; r.v = V[o]; r.sf = SF[o]; r.m = M[o]; }
+                return r;
+            };
+            auto stage1 = [&](const Raw &r) {
+                Pre q;
+                const int mvp = s.mv[l * NR + (int)(r.m >> 16)];
+                q.tl = (int)(short)(mvp & 0xFFFF); q.k = (int)(short)(mvp >> 16);
+                q.v0 = vmax * r.sf;
+                q.open = sig_open(q.tl, q.k, my_node, (int)(r.m & 0xFFFFu), r.x, r.v, L, link, P.KMAX, P.teleport);
+                return q;
+            };
+            Raw cur = load_raw(0);
+            for (int i = 0; i < n; ++i) {
+                const Raw nxt = load_raw(i + 1);
+                const Pre pc = stage1(cur);
+                const float x = cur.x, v = cur.v, sf = cur.sf, v0 = pc.v0;
+                const uint32_t meta = cur.m;
+                int w = (int)(meta & 0xFFFFu);
+                const int r = (int)(meta >> 16);
+                const int tl = pc.tl, k = pc.k;
+                const bool sink = tl == -1;
+                const bool open = pc.open;
+                bool can_cross = false;
+                if (all_crossed) {
+                    can_cross = open;
+                    if (can_cross && k >= 0 && k % 3 == 2 && w < P.teleport && my_opp >= 0 && s.n[my_opp] > 0) {
+                        // left turns yield to the opposing head going right / through
+                        const uint32_t om = s.hm[my_opp];
+                        const int mo = s.mv[my_opp * NR + (int)(om >> 16)];
+                        const int tlo = (int)(short)(mo & 0xFFFF), ko = (int)(short)(mo >> 16);
+                        if (ko >= 0 && ko % 3 != 2) {
+                            const float xo = s.hx[my_opp], vo = s.hv[my_opp], Lo = opp_len;
+                            if (sig_open(tlo, ko, opp_node, (int)(om & 0xFFFFu), xo, vo, Lo, link, P.KMAX, P.teleport)) {
+                                const float d = Lo - xo;
+                                if (d < vo * kYieldT + kYieldD) can_cross = false;
                             }
                         }
-                        if (can_cross && tl >= 0 && s.n[tl] + kMaxCross > kCap) can_cross = false;
-                        if (can_cross && ncross >= kMaxCross) can_cross = false;
-                        if (tl < -1) can_cross = false;
                     }
-                    const bool line_block = all_crossed ? !can_cross : !open;
-                    const bool tgt_lead = can_cross && !sink && s.n[tl] > 0;
-                    float vn;
-                    if (i > 0) vn = vcar[u];
-                    else if (tgt_lead) vn = follow(v, v0, true, (L - x) + (s.tx[tl] - kLen), s.tv[tl], kS0);
-                    else vn = follow(v, v0, false, 0.0f, 0.0f, 0.0f);
-                    if (line_block) {
-                        const float v2 = open ? follow(v, v0, true, L - x, 0.0f, 0.0f) : vline[u];
-                        if (v2 < vn) vn = v2;
-                    }
-                    float xn = x + vn;
-                    bool clamped = false;
-                    if (xn > pnx - kLen) { xn = pnx - kLen; clamped = true; }
-                    if (tgt_lead) {
-                        const float lim = L + (s.tx[tl] - kLen);
-                        if (xn > lim) { xn = lim; clamped = true; }
-                    }
-                    if (!can_cross && xn > L) { xn = L; clamped = true; }
-                    if (xn < x) { xn = x; clamped = true; }
-                    if (clamped) vn = xn - x;
-                    w = (vn < kHalt) ? w + 1 : 0;
-                    pnx = xn; pox = x; pov = v;
-                    const uint32_t nmeta = (uint32_t)w | ((uint32_t)r << 16);
-                    if (can_cross && xn >= L) {
-                        if (!sink) {
-                            const int o = nsent * NLP + l;
-                            s.ox[o] = xn - L; s.ov[o] = vn; s.osf[o] = sf; s.om[o] = nmeta; s.oto[o] = tl;
-                            ++nsent;
-                        } else {
-                            ++arrived;
-                        }
-                        ++ncross;
-                    } else {
-                        all_crossed = false;
-                        const int o = kept * NLP + l;
-                        X[o] = xn; V[o] = vn; SF[o] = sf; M[o] = nmeta;
-                        if (kept == 0) { hx = xn; hv = vn; hm = nmeta; }
-                        tx = xn; tv = vn;
-                        ++kept;
-                    }
+                    if (can_cross && tl >= 0 && s.n[tl] + kMaxCross > kCap) can_cross = false;
+                    if (can_cross && ncross >= kMaxCross) can_cross = false;
+                    if (tl < -1) can_cross = false;
                 }
+                const bool line_block = all_crossed ? !can_cross : !open;
+                const bool tgt_lead = can_cross && !sink && s.n[tl] > 0;
+                // leader: vehicle ahead (old state), else the old tail of the target lane, else free road
+                const bool has_lead = i > 0 || tgt_lead;
+                const float lg = i > 0 ? (pox - kLen) - x : (L - x) + (s.tx[tgt_lead ? tl : 0] - kLen);
+                const float lvl = i > 0 ? pov : s.tv[tgt_lead ? tl : 0];
+                float vn, v2;
+                follow2(v, v0, has_lead, lg, lvl, L - x, vn, v2);
+                if (line_block && v2 < vn) vn = v2;
+                float xn = x + vn;
+                bool clamped = false;
+                if (xn > pnx - kLen) { xn = pnx - kLen; clamped = true; }
+                if (tgt_lead) {
+                    const float lim = L + (s.tx[tl] - kLen);
+                    if (xn > lim) { xn = lim; clamped = true; }
+                }
+                if (!can_cross && xn > L) { xn = L; clamped = true; }
+                if (xn < x) { xn = x; clamped = true; }
+                if (clamped) vn = xn - x;
+                w = (vn < kHalt) ? w + 1 : 0;
+                pnx = xn; pox = x; pov = v;
+                const uint32_t nmeta = (uint32_t)w | ((uint32_t)r << 16);
+                if (can_cross && xn >= L) {
+                    if (!sink) {
+                        const int o = nsent * NLP + l;
+                        s.ox[o] = xn - L; s.ov[o] = vn; s.osf[o] = sf; s.om[o] = nmeta; s.oto[o] = tl;
+                        ++nsent;
+                    } else {
+                        ++arrived;
+                    }
+                    ++ncross;
+                } else {
+                    all_crossed = false;
+                    const int o = kept * NLP + l;
+                    X[o] = xn; V[o] = vn; SF[o] = sf; M[o] = nmeta;
+                    if (kept == 0) { hx = xn; hv = vn; hm = nmeta; }
+                    tx = xn; tv = vn;
+                    ++kept;
+                }
+                cur = nxt;
             }
             s.nout[l] = nsent;
+        } else {
+            s.nout[l] = 0;
         }
+        TSC_STAMP();
         __syncthreads();
+        TSC_STAMP();
         // ================= phase B (K3): gather hand-offs from feeder lanes, then demand =========
         if (lane) {
             n = kept;
@@ -438,7 +481,9 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             }
             s.n[l] = n; s.hx[l] = hx; s.hv[l] = hv; s.hm[l] = hm; s.tx[l] = tx; s.tv[l] = tv;
         }
+        TSC_STAMP();
         __syncthreads();
+        TSC_STAMP();
     }
 
     // ---- K4: detectors (envs/env.py:325-407): wave, halting, wait of the front-most vehicle
@@ -456,14 +501,19 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             }
         }
         s.wave[l] = wave; s.halt[l] = halt; s.hwait[l] = hw;
+    } else {
+        s.wave[l] = 0; s.halt[l] = 0; s.hwait[l] = 0;
     }
     if (arrived) atomicAdd(&P.arrived[e], (unsigned long long)arrived);
     if (l == 0) { P.tsec[e] = t; done[e] = t >= P.episode ? 1 : 0; }
+    TSC_STAMP();
     __syncthreads();
+    TSC_STAMP();
 
     // ---- K5: observations
     emit_obs(P, s, e, obs);
 
+    TSC_STAMP();
     // ---- K6: reward (envs/env.py:356-367) and shaping (:580,:590-631), float64
     for (int a = l; a < P.A; a += blockDim.x) {
         long long queue = 0;
@@ -506,6 +556,16 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         }
         reward[(size_t)e * P.A + a] = out;
     }
+    TSC_STAMP();
+    if (stamp) P.dbg[63] = nstamp;
+    if (P.dbg && threadIdx.x == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        // end time in the low 48 bits, XCC id and HW_ID (cu / se / simd / wave slot) on top
+        P.dbg[64 + 2 * blockIdx.x + 1] = (long long)(wall_clock64() & 0xFFFFFFFFFFFFll) | ((long long)(xcc & 0xF) << 60) | ((long long)(hwid & 0xFFF) << 48);
+    }
+#undef TSC_STAMP
 }
 
 }  // namespace
@@ -518,7 +578,6 @@ struct tsc_env {
     std::vector<void *> allocs;
     size_t smem;
     uint32_t *d_seeds;
-    int chunk;
 };
 
 namespace tsc {
@@ -561,7 +620,7 @@ int tsc_profile_read(int32_t kernel_id, double *total_ms, int64_t *count) {
 const char *tsc_profile_name(int32_t id) {
     static const char *names[] = {"env_step", "fc_gemm", "zx_gemm", "lstm_fwd", "head_fwd", "sample", "add_transition",
                                   "returns", "head_bwd", "lstm_bwd", "dwo_gemm", "dwh_gemm", "dwx_gemm", "dx1_gemm",
-                                  "dw1_gemm", "grad_norm", "rmsprop", "transpose_wx", "fingerprint"};
+                                  "dw1_gemm", "grad_norm", "rmsprop", "transpose_wx", "fingerprint", "policy_fwd_fused"};
     return (id >= 0 && id < tsc::KID_COUNT) ? names[id] : "";
 }
 
@@ -602,6 +661,16 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     P.clip_wave = sc->clip_wave; P.clip_wait = sc->clip_wait; P.coef_wait = sc->coef_wait;
 
     const int NL = P.NL, NR = P.NR, A = P.A;
+    {   // lanes that some route can put a vehicle on
+        int nu = 0;
+        for (int r = 0; r < NR; ++r) if (sc->route_entry[r] + 1 > nu) nu = sc->route_entry[r] + 1;
+        for (int i = 0; i < NL * NR; ++i) if (sc->mv_next[i] >= 0) {
+            if (sc->mv_next[i] + 1 > nu) nu = sc->mv_next[i] + 1;
+            if (i / NR + 1 > nu) nu = i / NR + 1;
+        }
+        P.NU = nu < 1 ? 1 : nu;
+        P.NLA = (P.NU + 63) / 64 * 64;
+    }
     UP(lane_len, float, sc->lane_len, NL); UP(lane_vmax, float, sc->lane_vmax, NL);
     UP(lane_det, float, sc->lane_det_start, NL);
     UP(lane_node, int, sc->lane_node, NL); UP(lane_opp, int, sc->lane_opp, NL);
@@ -666,13 +735,13 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     ALLOC(prev_action, int, (size_t)n_env * A);
     ALLOC(fp, float, (size_t)n_env * A * P.PMAX);
     ALLOC(arrived, unsigned long long, n_env);
+    P.dbg = nullptr;
     TSC_HIP(hipMalloc((void **)&h->d_seeds, sizeof(uint32_t) * n_env));
     h->allocs.push_back(h->d_seeds);
     h->smem = smem_bytes(P);
     if (h->smem > 160 * 1024) return tsc::fail("tsc_env_create: LDS need %zu B > 160 KiB", h->smem);
-    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
-    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
-    h->chunk = 1;   // 4-wide chunks were measured 2x slower (203 VGPRs -> half the resident workgroups)
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     *out = h;
     return 0;
@@ -715,11 +784,11 @@ int tsc_env_step(tsc_env *h, const int32_t *action_dev, float *obs_dev, double *
     if (!h || !action_dev || !obs_dev || !reward_dev || !global_reward_dev || !done_dev)
         return tsc::fail("tsc_env_step: bad arguments");
     tsc::ProfScope ps(tsc::KID_ENV_STEP, h->stream);
-    if (h->P.NLP <= 256)
-        hipLaunchKernelGGL((step_kernel<256, 1>), dim3(h->P.E), dim3(h->P.NLP), h->smem, h->stream, h->P, action_dev, obs_dev,
+    if (h->P.NLA <= 256)
+        hipLaunchKernelGGL((step_kernel<256>), dim3(h->P.E), dim3(h->P.NLA), h->smem, h->stream, h->P, action_dev, obs_dev,
                            reward_dev, global_reward_dev, done_dev, (int)train_mode);
     else
-        hipLaunchKernelGGL((step_kernel<1024, 1>), dim3(h->P.E), dim3(h->P.NLP), h->smem, h->stream, h->P, action_dev, obs_dev,
+        hipLaunchKernelGGL((step_kernel<1024>), dim3(h->P.E), dim3(h->P.NLA), h->smem, h->stream, h->P, action_dev, obs_dev,
                            reward_dev, global_reward_dev, done_dev, (int)train_mode);
     TSC_HIP(hipGetLastError());
     return 0;
@@ -751,6 +820,21 @@ int tsc_env_get_state(tsc_env *h, int32_t e, int32_t *n, float *x, float *v, flo
     if (pending) TSC_HIP(hipMemcpy(pending, P.pending + (size_t)e * P.NR, P.NR * 4, hipMemcpyDeviceToHost));
     if (serial) TSC_HIP(hipMemcpy(serial, P.serial + (size_t)e * P.NR, P.NR * 4, hipMemcpyDeviceToHost));
     if (time_sec) TSC_HIP(hipMemcpy(time_sec, P.tsec + e, 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tsc_env_debug_clock(tsc_env *h, int32_t enable, int64_t *stamps64_host) {
+    if (!h) return tsc::fail("null handle");
+    TSC_HIP(hipStreamSynchronize(h->stream));
+    if (enable && !h->P.dbg) {
+        long long *d = nullptr;
+        TSC_HIP(hipMalloc((void **)&d, (64 + 2 * (size_t)h->P.E) * sizeof(long long)));
+        TSC_HIP(hipMemset(d, 0, (64 + 2 * (size_t)h->P.E) * sizeof(long long)));
+        h->allocs.push_back(d);
+        h->P.dbg = d;
+    }
+    if (stamps64_host && h->P.dbg)
+        TSC_HIP(hipMemcpy(stamps64_host, h->P.dbg, (enable == 2 ? 64 + 2 * (size_t)h->P.E : 64) * sizeof(long long), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -22,6 +22,7 @@
 #include "tsc_gemm.h"
 #include "../../include/tsc.h"
 
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -412,6 +413,174 @@ __global__ void __launch_bounds__(64) head_bwd_kernel(const float *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused rollout forward (one control step, IA2C.forward agents/models.py:185-200): for one agent-tower
+// and a tile of 64 env instances, in ONE launch:
+//   obs -> relu(obs W1 + b1) -> [x | h] [Wx ; Wh] + b -> LSTM cell -> head (softmax / value).
+// Activations never leave the CU: obs tile, X1 and h live k-major in LDS (XH[(H+64)][68]); the
+// weights are streamed from L2 straight into MFMA B operands (Wx and Wh are contiguous in the
+// parameter layout, so the gate GEMM is one K = H+64 loop), double-buffered in registers 8 k-steps
+// ahead.  Blocks are numbered so that all tiles of a tower run on the same XCD (block b -> XCD b%8)
+// and reuse its L2-resident weights.
+// ------------------------------------------------------------------------------------------------
+constexpr int kXLd = 68;
+
+__global__ void __launch_bounds__(256, 2)
+policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int *__restrict__ n_act,
+                        const float *__restrict__ obs, const uint8_t *__restrict__ done, float *state, int advance,
+                        int E, int n_tiles, float *__restrict__ pi_out, float *__restrict__ v_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *XH = (float *)smem_raw;
+    const int b = blockIdx.x, xcd = b & 7, sidx = b >> 3;
+    const int g = xcd + 8 * (sidx / n_tiles), tile = sidx % n_tiles;
+    if (g >= lay.G) return;
+    const int a = g >> 1, tower = g & 1, e0 = tile * 64, H = lay.H, SMAX = lay.SMAX;
+    float *Hs = XH + H * kXLd;                      // rows H..H+63: obs staging, then h
+    const float *P = params + (long long)g * lay.stride;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
+
+    // ---- phase 0: obs tile -> LDS, k-major
+    {
+        const int q4 = SMAX >> 2, AS = lay.A * SMAX;
+        for (int idx = tid; idx < 64 * q4; idx += 256) {
+            const int m = idx / q4, k4 = (idx % q4) * 4, e = e0 + m;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < E) v = *reinterpret_cast<const float4 *>(obs + (long long)e * AS + a * SMAX + k4);
+            Hs[(k4 + 0) * kXLd + m] = v.x; Hs[(k4 + 1) * kXLd + m] = v.y;
+            Hs[(k4 + 2) * kXLd + m] = v.z; Hs[(k4 + 3) * kXLd + m] = v.w;
+        }
+    }
+    __syncthreads();
+    // ---- phase 1: X1 = relu(obs W1 + b1) -> XH rows [0, H)
+    {
+        const float *W1 = P + lay.oW1, *b1 = P + lay.ob1;
+        const int nct = H >> 5;
+        for (int ct = wave; ct < nct; ct += 4) {
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+            const int col = ct * 32 + li;
+#pragma unroll 2
+            for (int kk = 0; kk < SMAX; kk += 2) {
+                const float bw = W1[(long long)(kk + kh) * H + col];
+                const float a0 = Hs[(kk + kh) * kXLd + li], a1 = Hs[(kk + kh) * kXLd + 32 + li];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bw, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bw, acc1, 0, 0, 0);
+            }
+            const float bias = b1[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const float v0 = acc0[r] + bias, v1 = acc1[r] + bias;
+                XH[col * kXLd + row] = v0 > 0.f ? v0 : 0.f;
+                XH[col * kXLd + 32 + row] = v1 > 0.f ? v1 : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 1.5: LSTM state (done-masked): c -> registers, h -> LDS rows [H, H+64)
+    const int r0 = 32 * (wave & 1), j0 = 32 * (wave >> 1), j = j0 + li;
+    float c[16];
+    int erow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        erow[r] = r0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int e = e0 + erow[r];
+        float c0 = 0.f, h0 = 0.f;
+        if (e < E) {
+            const float *st = state + ((long long)g * E + e) * 2 * kL;
+            const float keep = 1.0f - (float)done[e];
+            c0 = st[j] * keep; h0 = st[kL + j] * keep;
+        }
+        c[r] = c0;
+        Hs[j * kXLd + erow[r]] = h0;
+    }
+    __syncthreads();
+    // ---- phase 2: gates = bl + [X1 | h] [Wx ; Wh]   (K = H + 64)
+    f32x16 acc[4];
+    {
+        const float *bl = P + lay.obl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float bv = bl[64 * q + j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = bv;
+        }
+        const float *B = P + lay.oWx;                  // [H + 64][256] (Wx then Wh)
+        const int nchunk = (H + 64) >> 4;              // 16 k rows per chunk
+        float bA[8][4], bB[8][4];
+        auto loadB = [&](float (*dst)[4], int chunk) {
+            const float *src = B + (long long)(chunk * 16 + kh) * kG4 + j;
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dst[s2][q] = src[(long long)(2 * s2) * kG4 + 64 * q];
+        };
+        auto compute = [&](float (*bv)[4], int chunk) {
+            const float *As = XH + (chunk * 16 + kh) * kXLd + r0 + li;
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) {
+                const float av = As[(2 * s2) * kXLd];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s2][q], acc[q], 0, 0, 0);
+            }
+        };
+        loadB(bA, 0);
+        for (int ch = 0; ch < nchunk; ch += 2) {
+            if (ch + 1 < nchunk) loadB(bB, ch + 1);
+            compute(bA, ch);
+            if (ch + 2 < nchunk) loadB(bA, ch + 2);
+            if (ch + 1 < nchunk) compute(bB, ch + 1);
+        }
+    }
+    __syncthreads();                                   // everyone is done reading XH
+    // ---- phase 3: cell update, state write-back, h -> LDS rows [0, 64)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int e = e0 + erow[r];
+        const float ig = sigmoidf_(acc[0][r]), fg = sigmoidf_(acc[1][r]);
+        const float og = sigmoidf_(acc[2][r]), ug = tanhf(acc[3][r]);
+        const float cn = fg * c[r] + ig * ug;
+        const float hn = og * tanhf(cn);
+        if (advance && e < E) {
+            float *st = state + ((long long)g * E + e) * 2 * kL;
+            st[j] = cn; st[kL + j] = hn;
+        }
+        XH[j * kXLd + erow[r]] = hn;
+    }
+    __syncthreads();
+    // ---- phase 4: head.  thread -> (env = tid & 63, outputs 2*(tid>>6), 2*(tid>>6)+1)
+    float *LG = XH + 64 * kXLd;                        // [64][8] logits
+    {
+        const float *Wo = P + lay.oWo, *bo = P + lay.obo;
+        const int e = tid & 63, k0 = 2 * (tid >> 6);
+        float s0 = 0.f, s1 = 0.f;
+        for (int jj = 0; jj < kL; ++jj) {
+            const float h = XH[jj * kXLd + e];
+            s0 += h * Wo[jj * kOut + k0];
+            s1 += h * Wo[jj * kOut + k0 + 1];
+        }
+        LG[e * kOut + k0] = s0 + bo[k0];
+        LG[e * kOut + k0 + 1] = s1 + bo[k0 + 1];
+    }
+    __syncthreads();
+    if (tid < 64 && e0 + tid < E) {
+        const long long idx = (long long)(e0 + tid) * lay.A + a;
+        const float *lg = LG + tid * kOut;
+        if (tower == 0) {
+            const int na = n_act[a];
+            float mx = -INFINITY;
+            for (int k = 0; k < na; ++k) mx = fmaxf(mx, lg[k]);
+            float pk[kOut], sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < kOut; ++k) { pk[k] = k < na ? expf(lg[k] - mx) : 0.f; sum += pk[k]; }
+            for (int k = 0; k < lay.AMAX; ++k) pi_out[idx * lay.AMAX + k] = k < kOut ? pk[k] / sum : 0.f;
+        } else {
+            v_out[idx] = lg[0];
+        }
+    }
+}
+
 // n-step returns and advantages (agents/utils.py:202-228): float64 recursion from the back with
 // POST-step dones, Adv = R - v, cast to float32.   rew f64 [T][E][A], val f32, done_all u8 [T+1][E]
 __global__ void returns_kernel(const double *rew, const float *val, const uint8_t *done_all, const float *Rboot,
@@ -534,7 +703,8 @@ struct tsc_model {
     double *norm2, *stats;
     float *ws, *wsc;            // split-K workspace
     size_t ws_floats, wsc_floats;
-    size_t lds_fwd, lds_bwd;
+    size_t lds_fwd, lds_bwd, lds_fused;
+    int fused_fwd;
     long long nparam;
 };
 
@@ -631,6 +801,11 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fwd));
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fwd));
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bwd));
+    m->lds_fused = sizeof(float) * (size_t)(L.H + 64) * kXLd;
+    m->fused_fwd = (L.H % 32 == 0) && (L.SMAX <= 64) && (L.SMAX % 4 == 0) && ((L.H + 64) % 16 == 0) && m->lds_fused <= 160 * 1024;
+    if (const char *ev = getenv("TSC_UNFUSED_FWD")) if (atoi(ev)) m->fused_fwd = 0;
+    if (m->fused_fwd)
+        TSC_HIP(hipFuncSetAttribute((const void *)policy_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fused));
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((m->nparam + 255) / 256)), dim3(256), 0, 0, m->ms, m->nparam, 1.0f);
     TSC_HIP(hipDeviceSynchronize());
     *out = m;
@@ -698,7 +873,16 @@ int tsc_model_forward(tsc_model *m, const float *obs, const uint8_t *done, float
     if (!m || !obs || !done || !pi || !v) return tsc::fail("tsc_model_forward: bad arguments");
     const Layout &L = m->lay;
     const int E = m->E;
-    // the rollout forward borrows the head of the training activations (row count E <= T*E)
+    if (m->fused_fwd) {
+        const int n_tiles = (E + 63) / 64, per_xcd = (L.G + 7) / 8;
+        tsc::ProfScope ps(tsc::KID_FUSED_FWD, m->stream);
+        hipLaunchKernelGGL(policy_fwd_fused_kernel, dim3(8 * per_xcd * n_tiles), dim3(256), m->lds_fused, m->stream, m->params,
+                           L, m->n_act, obs, done, m->state_fw, (int)advance, E, n_tiles, pi, v);
+        ps.stop();
+        TSC_HIP(hipGetLastError());
+        return 0;
+    }
+    // unfused path (shapes the fused kernel does not cover): the training kernels with T = 1
     if (dense_forward(m, obs, E, m->X1, m->Z)) return tsc::fail("tsc_model_forward: gemm launch failed");
     tsc::ProfScope ps1(tsc::KID_LSTM_FWD, m->stream);
     hipLaunchKernelGGL(lstm_fwd_kernel<false>, dim3(L.G, (E + 63) / 64), dim3(256), m->lds_fwd, m->stream, m->params, L, m->Z,

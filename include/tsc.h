@@ -107,6 +107,12 @@ int tsc_env_step(tsc_env *h, const int32_t *action_dev, float *obs_dev, double *
 int tsc_env_get_state(tsc_env *h, int32_t e, int32_t *n, float *x, float *v, float *sf,
                       int32_t *w, int32_t *r, int32_t *pending, int32_t *serial, int32_t *time_sec);
 
+/* Tuning aid: shader-clock stamps (s_memtime) taken by workgroup 0 / thread 0 of the last step at
+ * every phase boundary; stamps[63] = number of stamps. enable != 0 allocates the buffer; enable == 2 also
+ * returns [64 + 2e], [64 + 2e + 1] = constant-rate (100 MHz) start / end time of workgroup e (host buffer of
+ * 64 + 2E entries). */
+int tsc_env_debug_clock(tsc_env *h, int32_t enable, int64_t *stamps64_host);
+
 /* Mean number of live vehicles per env (roofline bookkeeping). Synchronises. */
 int tsc_env_live_vehicles(tsc_env *h, double *mean_live);
 

@@ -28,4 +28,68 @@ for chunk in ('1',):
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print('chunk=%s %s: %.1f us/control-step, %.0f live veh/env, %.3g env-steps/s (sim only)'
               % (chunk, phase, 1e6 * dt / n, env.mean_live_vehicles(), 25 * E * 5 * n / dt))
+    import ctypes as C
+    from deeprl_signal_control_amd import _lib
+    st = (C.c_int64 * 64)()
+    _lib.check(env._L.tsc_env_debug_clock(env._h, 1, None))
+    env.step(acts[0]); env.step(acts[1])
+    _lib.check(env._L.tsc_env_debug_clock(env._h, 1, st))
+    n = st[63]
+    d = [st[i + 1] - st[i] for i in range(n - 1)]
+    names = ['prologue'] + sum([['A%d' % k, 'barrier', 'B%d' % k, 'barrier'] for k in range(5)], []) + ['detectors', 'barrier', 'obs', 'reward']
+    print('workgroup 0 / thread 0 shader-clock cycles per phase (total %d):' % (st[n - 1] - st[0]))
+    print('  ' + ', '.join('%s=%d' % (names[i] if i < len(names) else '?', d[i]) for i in range(len(d))))
     env.close()
+
+# --- cache / interference experiment: how much slower is env_step when other kernels run in between?
+from deeprl_signal_control_amd import _lib as _l
+env = VecTrafficEnv(scn, E, seed=12)
+env.reset()
+for i in range(300):
+    env.step(acts[i % 16])
+big = torch.zeros(64 << 20, device='cuda')           # 256 MB
+for label, fn in (('nothing between', lambda: None), ('256 MB memset between', lambda: big.zero_()),
+                  ('16 MB memset between', lambda: big[:4 << 20].zero_())):
+    _l.profile(enable=True, reset=True)
+    for i in range(60):
+        env.step(acts[i % 16]); fn()
+    p = _l.profile()
+    _l.profile(enable=False)
+    print('env_step avg %.1f us with %s' % (1e3 * p['env_step'][0] / p['env_step'][1], label))
+
+# --- phase stamps with and without an interfering kernel
+import ctypes as C
+st = (C.c_int64 * 64)()
+_l.check(env._L.tsc_env_debug_clock(env._h, 1, None))
+names = ['prologue'] + sum([['A%d' % k, 'bar', 'B%d' % k, 'bar'] for k in range(5)], []) + ['detectors', 'bar', 'obs', 'reward']
+for label, fn in (('nothing between', lambda: None), ('16 MB memset between', lambda: big[:4 << 20].zero_())):
+    for i in range(4):
+        env.step(acts[i]); fn()
+    torch.cuda.synchronize()
+    _l.check(env._L.tsc_env_debug_clock(env._h, 1, st))
+    n = st[63]
+    d = [st[i + 1] - st[i] for i in range(n - 1)]
+    print('%s: total %d cycles: ' % (label, st[n - 1] - st[0]) + ', '.join('%s=%d' % (names[i], d[i]) for i in range(len(d)) if names[i] != 'bar'))
+
+# --- per-workgroup wall-clock (100 MHz) start/end: is it the blocks or the dispatch that gets slower?
+import numpy as np
+buf = (C.c_int64 * (64 + 2 * E))()
+for label, fn in (('nothing between', lambda: None), ('16 MB memset between', lambda: big[:4 << 20].zero_())):
+    for i in range(4):
+        env.step(acts[i]); fn()
+    torch.cuda.synchronize()
+    _l.check(env._L.tsc_env_debug_clock(env._h, 2, buf))
+    w = np.array(buf[64:], dtype=np.int64).reshape(E, 2)
+    tag = (w[:, 1] >> 48) & 0xFFFF
+    w[:, 1] &= 0xFFFFFFFFFFFF
+    w[:, 0] &= 0xFFFFFFFFFFFF
+    st0, en0 = w[:, 0] - w[:, 0].min(), w[:, 1] - w[:, 0].min()
+    dur = (w[:, 1] - w[:, 0]) / 100.0
+    print('%s: kernel span %.1f us; block start p50/p99/max %.1f/%.1f/%.1f us; block duration min/p50/max %.1f/%.1f/%.1f us'
+          % (label, en0.max() / 100.0, np.percentile(st0, 50) / 100.0, np.percentile(st0, 99) / 100.0, st0.max() / 100.0,
+             dur.min(), np.median(dur), dur.max()))
+    late = np.where(st0 > 5000)[0]
+    print('   late blocks: %d; (block, start_us, xcc, hwid) %s' % (len(late), [(int(b), float(st0[b]) / 100.0, int(tag[b] >> 12), hex(int(tag[b] & 0xFFF))) for b in late[:12]]))
+    import collections
+    cnt = collections.Counter((int(t >> 12), int(t & 0xFFF) >> 4) for t in tag)
+    print('   blocks per (xcc, hwid>>4): max %d min %d distinct %d' % (max(cnt.values()), min(cnt.values()), len(cnt)))
