@@ -167,6 +167,7 @@ def _setup_lib(L):
     L.tsc_model_grad_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
     L.tsc_model_apply_grads.argtypes = [vp, C.c_double, C.c_double, vp]
     L.tsc_model_get_returns.argtypes = [vp, vp, vp]
+    L.tsc_model_debug_clock.argtypes = [vp, C.c_int32, vp, C.c_int32]
     L.tsc_gemm_grouped_f32.argtypes = [C.c_int32] * 6 + [vp, C.c_int64, C.c_int32, vp, C.c_int64, C.c_int32,
                                                         vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, C.c_int64, vp, C.c_int64, vp]
     L._model_ready = True

@@ -39,7 +39,15 @@ struct Layout {
     long long stride, oW1, ob1, oWx, oWh, obl, oWo, obo;
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate non-linearities on the hardware exp2 / rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each): 4-5 instructions
+// instead of the ~30-50 of the IEEE expf / tanhf / division sequences.  Absolute error < 3e-7, far inside the
+// fp32-vs-float64 tolerance the parity tests state; the cell update was 26 % of the fused forward before.
+__device__ __forceinline__ float sigmoidf_(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanhf_(float x) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
 
 // ------------------------------------------------------------------------------------------------
 // LSTM forward (agents/utils.py:88-116), T steps, one workgroup per (group, 64-env tile).
@@ -138,9 +146,9 @@ __global__ void __launch_bounds__(256, PF ? 1 : 2) lstm_fwd_kernel(const float *
         for (int r = 0; r < 16; ++r) {
             const int e = e0 + erow[r];
             const float ig = sigmoidf_(acc[0][r]), fg = sigmoidf_(acc[1][r]);
-            const float og = sigmoidf_(acc[2][r]), ug = tanhf(acc[3][r]);
+            const float og = sigmoidf_(acc[2][r]), ug = tanhf_(acc[3][r]);
             const float cn = fg * c[r] + ig * ug;
-            const float hn = og * tanhf(cn);
+            const float hn = og * tanhf_(cn);
             float keep = 1.0f;
             if (e < E) {
                 const long long n = (long long)g * N + (long long)t * E + e;
@@ -231,7 +239,7 @@ __global__ void __launch_bounds__(256) lstm_bwd_kernel(const float *__restrict__
                 const float keep = keepv[r];
                 const float cp = c_prv[r] * keep;
                 const float dh = dh_in[r] + dh_rec[r];
-                const float tc = tanhf(cn);
+                const float tc = tanhf_(cn);
                 dog = dh * tc * og * (1.0f - og);
                 const float dc = dh * og * (1.0f - tc * tc) + dc_rec[r];
                 di = dc * ug * ig * (1.0f - ig);
@@ -428,9 +436,14 @@ constexpr int kXLd = 68;
 __global__ void __launch_bounds__(256, 2)
 policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int *__restrict__ n_act,
                         const float *__restrict__ obs, const uint8_t *__restrict__ done, float *state, int advance,
-                        int E, int n_tiles, float *__restrict__ pi_out, float *__restrict__ v_out) {
+                        int E, int n_tiles, float *__restrict__ pi_out, float *__restrict__ v_out, long long *dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float *XH = (float *)smem_raw;
+    const bool stamp = dbg && blockIdx.x == 8 && threadIdx.x == 0;      // a block that does real work
+    int nstamp = 0;
+#define FSTAMP() do { if (stamp) dbg[nstamp++] = clock64(); } while (0)
+    if (dbg && threadIdx.x == 0) dbg[64 + 2 * blockIdx.x] = wall_clock64();
+    FSTAMP();
     const int b = blockIdx.x, xcd = b & 7, sidx = b >> 3;
     const int g = xcd + 8 * (sidx / n_tiles), tile = sidx % n_tiles;
     if (g >= lay.G) return;
@@ -439,6 +452,22 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
     const float *P = params + (long long)g * lay.stride;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
 
+    // LSTM state of this wave's 16 (env, unit) pairs: issued first so the HBM latency hides under phases 0-1
+    const int r0 = 32 * (wave & 1), j0 = 32 * (wave >> 1), j = j0 + li;
+    float c[16], h0v[16];
+    int erow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        erow[r] = r0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int e = e0 + erow[r];
+        float c0 = 0.f, h0 = 0.f;
+        if (e < E) {
+            const float *st = state + ((long long)g * E + e) * 2 * kL;
+            const float keep = 1.0f - (float)done[e];
+            c0 = st[j] * keep; h0 = st[kL + j] * keep;
+        }
+        c[r] = c0; h0v[r] = h0;
+    }
     // ---- phase 0: obs tile -> LDS, k-major
     {
         const int q4 = SMAX >> 2, AS = lay.A * SMAX;
@@ -451,6 +480,7 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
         }
     }
     __syncthreads();
+    FSTAMP();
     // ---- phase 1: X1 = relu(obs W1 + b1) -> XH rows [0, H)
     {
         const float *W1 = P + lay.oW1, *b1 = P + lay.ob1;
@@ -460,12 +490,17 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
             const int col = ct * 32 + li;
-#pragma unroll 2
-            for (int kk = 0; kk < SMAX; kk += 2) {
-                const float bw = W1[(long long)(kk + kh) * H + col];
-                const float a0 = Hs[(kk + kh) * kXLd + li], a1 = Hs[(kk + kh) * kXLd + 32 + li];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bw, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bw, acc1, 0, 0, 0);
+            // all B operands of this column tile first (<= 32 independent loads in flight), then the MFMAs
+            float bw[32];
+#pragma unroll
+            for (int s2 = 0; s2 < 32; ++s2) bw[s2] = 2 * s2 < SMAX ? W1[(long long)(2 * s2 + kh) * H + col] : 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 32; ++s2) {
+                if (2 * s2 < SMAX) {
+                    const float a0 = Hs[(2 * s2 + kh) * kXLd + li], a1 = Hs[(2 * s2 + kh) * kXLd + 32 + li];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bw[s2], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bw[s2], acc1, 0, 0, 0);
+                }
             }
             const float bias = b1[col];
 #pragma unroll
@@ -478,24 +513,12 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
         }
     }
     __syncthreads();
-    // ---- phase 1.5: LSTM state (done-masked): c -> registers, h -> LDS rows [H, H+64)
-    const int r0 = 32 * (wave & 1), j0 = 32 * (wave >> 1), j = j0 + li;
-    float c[16];
-    int erow[16];
+    FSTAMP();
+    // ---- phase 1.5: h (loaded at kernel entry, done-masked) -> LDS rows [H, H+64)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        erow[r] = r0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        const int e = e0 + erow[r];
-        float c0 = 0.f, h0 = 0.f;
-        if (e < E) {
-            const float *st = state + ((long long)g * E + e) * 2 * kL;
-            const float keep = 1.0f - (float)done[e];
-            c0 = st[j] * keep; h0 = st[kL + j] * keep;
-        }
-        c[r] = c0;
-        Hs[j * kXLd + erow[r]] = h0;
-    }
+    for (int r = 0; r < 16; ++r) Hs[j * kXLd + erow[r]] = h0v[r];
     __syncthreads();
+    FSTAMP();
     // ---- phase 2: gates = bl + [X1 | h] [Wx ; Wh]   (K = H + 64)
     f32x16 acc[4];
     {
@@ -533,15 +556,17 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
             if (ch + 1 < nchunk) compute(bB, ch + 1);
         }
     }
+    FSTAMP();
     __syncthreads();                                   // everyone is done reading XH
+    FSTAMP();
     // ---- phase 3: cell update, state write-back, h -> LDS rows [0, 64)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int e = e0 + erow[r];
         const float ig = sigmoidf_(acc[0][r]), fg = sigmoidf_(acc[1][r]);
-        const float og = sigmoidf_(acc[2][r]), ug = tanhf(acc[3][r]);
+        const float og = sigmoidf_(acc[2][r]), ug = tanhf_(acc[3][r]);
         const float cn = fg * c[r] + ig * ug;
-        const float hn = og * tanhf(cn);
+        const float hn = og * tanhf_(cn);
         if (advance && e < E) {
             float *st = state + ((long long)g * E + e) * 2 * kL;
             st[j] = cn; st[kL + j] = hn;
@@ -549,6 +574,7 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
         XH[j * kXLd + erow[r]] = hn;
     }
     __syncthreads();
+    FSTAMP();
     // ---- phase 4: head.  thread -> (env = tid & 63, outputs 2*(tid>>6), 2*(tid>>6)+1)
     float *LG = XH + 64 * kXLd;                        // [64][8] logits
     {
@@ -579,6 +605,10 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
             v_out[idx] = lg[0];
         }
     }
+    FSTAMP();
+    if (stamp) dbg[63] = nstamp;
+    if (dbg && threadIdx.x == 0) dbg[64 + 2 * blockIdx.x + 1] = wall_clock64();
+#undef FSTAMP
 }
 
 // n-step returns and advantages (agents/utils.py:202-228): float64 recursion from the back with
@@ -705,6 +735,7 @@ struct tsc_model {
     size_t ws_floats, wsc_floats;
     size_t lds_fwd, lds_bwd, lds_fused;
     int fused_fwd;
+    long long *dbg;
     long long nparam;
 };
 
@@ -801,6 +832,7 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fwd));
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fwd));
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bwd));
+    m->dbg = nullptr;
     m->lds_fused = sizeof(float) * (size_t)(L.H + 64) * kXLd;
     m->fused_fwd = (L.H % 32 == 0) && (L.SMAX <= 64) && (L.SMAX % 4 == 0) && ((L.H + 64) % 16 == 0) && m->lds_fused <= 160 * 1024;
     if (const char *ev = getenv("TSC_UNFUSED_FWD")) if (atoi(ev)) m->fused_fwd = 0;
@@ -877,7 +909,7 @@ int tsc_model_forward(tsc_model *m, const float *obs, const uint8_t *done, float
         const int n_tiles = (E + 63) / 64, per_xcd = (L.G + 7) / 8;
         tsc::ProfScope ps(tsc::KID_FUSED_FWD, m->stream);
         hipLaunchKernelGGL(policy_fwd_fused_kernel, dim3(8 * per_xcd * n_tiles), dim3(256), m->lds_fused, m->stream, m->params,
-                           L, m->n_act, obs, done, m->state_fw, (int)advance, E, n_tiles, pi, v);
+                           L, m->n_act, obs, done, m->state_fw, (int)advance, E, n_tiles, pi, v, m->dbg);
         ps.stop();
         TSC_HIP(hipGetLastError());
         return 0;
@@ -1002,6 +1034,20 @@ int tsc_model_apply_grads(tsc_model *m, double lr, double grad_scale, double *st
             stats_host[a * 4 + 3] = sqrt(n2[a]);
         }
     }
+    return 0;
+}
+
+int tsc_model_debug_clock(tsc_model *m, int32_t enable, int64_t *stamps_host, int32_t count) {
+    if (!m) return tsc::fail("null handle");
+    TSC_HIP(hipStreamSynchronize(m->stream));
+    const size_t n = 64 + 2 * 8 * (size_t)((m->lay.G + 7) / 8) * ((m->E + 63) / 64);
+    if (enable && !m->dbg) {
+        TSC_HIP(hipMalloc((void **)&m->dbg, n * sizeof(long long)));
+        TSC_HIP(hipMemset(m->dbg, 0, n * sizeof(long long)));
+        m->allocs.push_back(m->dbg);
+    }
+    if (stamps_host && m->dbg)
+        TSC_HIP(hipMemcpy(stamps_host, m->dbg, sizeof(long long) * ((size_t)count < n ? (size_t)count : n), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -181,6 +181,10 @@ int tsc_model_grad_buffer(tsc_model *m, float **grad_dev, int64_t *count);
  * {policy_loss, value_loss, entropy_loss, grad_norm} float64 [A,4]. */
 int tsc_model_apply_grads(tsc_model *m, double lr, double grad_scale, double *stats_host);
 
+/* Tuning aid for the fused rollout forward: like tsc_env_debug_clock (phase stamps of one workgroup in
+ * [0,63), per-workgroup 100 MHz start / end from index 64). */
+int tsc_model_debug_clock(tsc_model *m, int32_t enable, int64_t *stamps_host, int32_t count);
+
 /* Debug / parity access: the float32 returns and advantages [n_step, E, A] the last
  * tsc_model_compute_grads() fed to the loss (agents/utils.py:223-224). Synchronises. */
 int tsc_model_get_returns(tsc_model *m, float *Rs_host, float *Advs_host);
