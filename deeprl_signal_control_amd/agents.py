@@ -33,7 +33,7 @@ class TscModelCfg(C.Structure):
                 ('n_lstm', C.c_int32), ('n_step', C.c_int32),
                 ('gamma', C.c_double), ('reward_norm', C.c_double), ('reward_clip', C.c_double),
                 ('value_coef', C.c_double), ('max_grad_norm', C.c_double), ('rmsp_alpha', C.c_double),
-                ('rmsp_epsilon', C.c_double)]
+                ('rmsp_epsilon', C.c_double), ('policy_kind', C.c_int32)]
 
 
 class Scheduler:
@@ -62,17 +62,19 @@ class ParamLayout:
     g = 2*agent + tower owns `stride` floats  W1[s_max][H] | b1[H] | Wx[H][4L] | Wh[L][4L] | bl[4L] |
     Wo[L][8] | bo[8]."""
 
-    def __init__(self, n_wave_ls, n_w_ls, n_f_ls, n_a_ls, s_max, n_fc, n_lstm=64, out_pad=8):
+    def __init__(self, n_wave_ls, n_w_ls, n_f_ls, n_a_ls, s_max, n_fc, n_lstm=64, out_pad=8, policy='lstm'):
+        self.policy = policy
         self.n_wave_ls, self.n_w_ls, self.n_f_ls, self.n_a_ls = map(list, (n_wave_ls, n_w_ls, n_f_ls, n_a_ls))
         self.s_max, self.n_fc, self.Lh, self.out_pad = int(s_max), tuple(n_fc), int(n_lstm), int(out_pad)
         self.G = 2 * len(self.n_a_ls)
         self.H = sum(self.n_fc)
-        L4 = 4 * self.Lh
+        L4 = 4 * self.Lh if policy == 'lstm' else self.Lh      # second-layer width (gates | fc units)
+        self.NZ = L4
         self.oW1 = 0
         self.ob1 = self.s_max * self.H
         self.oWx = self.ob1 + self.H
         self.oWh = self.oWx + self.H * L4
-        self.obl = self.oWh + self.Lh * L4
+        self.obl = self.oWh + (self.Lh * L4 if policy == 'lstm' else 0)
         self.oWo = self.obl + L4
         self.obo = self.oWo + self.Lh * self.out_pad
         self.stride = self.obo + self.out_pad
@@ -101,9 +103,14 @@ class ParamLayout:
             Wo[:, :p['out_w'].shape[1]] = p['out_w']; bo[:len(p['out_b'])] = p['out_b']
             f = flat[g]
             f[self.oW1:self.ob1] = W1.ravel(); f[self.ob1:self.oWx] = b1
-            f[self.oWx:self.oWh] = np.asarray(p['lstm_wx'], np.float32).ravel()
-            f[self.oWh:self.obl] = np.asarray(p['lstm_wh'], np.float32).ravel()
-            f[self.obl:self.oWo] = p['lstm_b']; f[self.oWo:self.obo] = Wo.ravel(); f[self.obo:] = bo
+            if self.policy == 'lstm':
+                f[self.oWx:self.oWh] = np.asarray(p['lstm_wx'], np.float32).ravel()
+                f[self.oWh:self.obl] = np.asarray(p['lstm_wh'], np.float32).ravel()
+                f[self.obl:self.oWo] = p['lstm_b']
+            else:
+                f[self.oWx:self.oWh] = np.asarray(p['fc_w'], np.float32).ravel()
+                f[self.obl:self.oWo] = p['fc_b']
+            f[self.oWo:self.obo] = Wo.ravel(); f[self.obo:] = bo
         return flat.ravel()
 
     def unpack(self, flat):
@@ -120,9 +127,13 @@ class ParamLayout:
                 p['fcf_w'] = W1[nw + nt:nw + nt + nf, fw:fw + fp].copy(); p['fcf_b'] = b1[fw:fw + fp].copy()
             if ft:
                 p['fct_w'] = W1[nw:nw + nt, fw + fp:].copy(); p['fct_b'] = b1[fw + fp:].copy()
-            p['lstm_wx'] = f[self.oWx:self.oWh].reshape(self.H, 4 * self.Lh).copy()
-            p['lstm_wh'] = f[self.oWh:self.obl].reshape(self.Lh, 4 * self.Lh).copy()
-            p['lstm_b'] = f[self.obl:self.oWo].copy()
+            if self.policy == 'lstm':
+                p['lstm_wx'] = f[self.oWx:self.oWh].reshape(self.H, 4 * self.Lh).copy()
+                p['lstm_wh'] = f[self.oWh:self.obl].reshape(self.Lh, 4 * self.Lh).copy()
+                p['lstm_b'] = f[self.obl:self.oWo].copy()
+            else:
+                p['fc_w'] = f[self.oWx:self.oWh].reshape(self.H, self.Lh).copy()
+                p['fc_b'] = f[self.obl:self.oWo].copy()
             n_out = self.n_a_ls[a] if g % 2 == 0 else 1
             p['out_w'] = f[self.oWo:self.obo].reshape(self.Lh, self.out_pad)[:, :n_out].copy()
             p['out_b'] = f[self.obo:self.obo + n_out].copy()
@@ -177,12 +188,15 @@ class VecA2C:
     """IA2C / MA2C for A agents x E env instances on one GPU."""
 
     def __init__(self, n_s_ls, n_a_ls, n_w_ls, n_f_ls, n_env, s_max, a_max, model_config=None,
-                 total_step=0, device=0, seed=None, name='ma2c', process_group=None):
+                 total_step=0, device=0, seed=None, name='ma2c', process_group=None, policy='lstm'):
         if not torch.cuda.is_available():
             raise RuntimeError('VecA2C needs a GPU (MI355X); there is no CPU fallback')
         cfg = dict(A2C_DEFAULTS)
         cfg.update(model_config or {})
         self.cfg, self.name = cfg, name
+        self.policy = policy                    # 'lstm' (what the reference instantiates) or 'fc' (FcACPolicy)
+        if policy == 'fc' and name == 'ma2c':
+            raise ValueError('FcACPolicy has no working fingerprint variant in the reference (policies.py:259-282)')
         self.n_agent, self.E = len(n_s_ls), int(n_env)
         self.n_s_ls, self.n_a_ls, self.n_w_ls, self.n_f_ls = map(list, (n_s_ls, n_a_ls, n_w_ls, n_f_ls))
         if name != 'ma2c':
@@ -204,7 +218,8 @@ class VecA2C:
         mc = TscModelCfg(self.n_agent, self.s_max, self.a_max, *[a.ctypes.data_as(ip) for a in self._arrs],
                          int(cfg['num_fw']), n_ft, n_fp, int(cfg['num_lstm']), self.n_step, float(cfg['gamma']),
                          float(cfg['reward_norm']), float(cfg['reward_clip']), float(cfg['value_coef']),
-                         float(cfg['max_grad_norm']), float(cfg['rmsp_alpha']), float(cfg['rmsp_epsilon']))
+                         float(cfg['max_grad_norm']), float(cfg['rmsp_alpha']), float(cfg['rmsp_epsilon']),
+                         1 if policy == 'fc' else 0)
         self.n_fc = (int(cfg['num_fw']), n_fp, n_ft)
         h = C.c_void_p()
         _lib.check(L.tsc_model_create(C.byref(mc), self.E, self.device.index or 0, C.byref(h)))
@@ -214,7 +229,7 @@ class VecA2C:
         (self.G, self.stride, self.H, self.Lh, self.oW1, self.ob1, self.oWx, self.oWh, self.obl, self.oWo,
          self.obo, self.out_pad) = [int(x) for x in lay]
         self.layout = ParamLayout(self.n_wave_ls, self.n_w_ls, self.n_f_ls, self.n_a_ls, self.s_max, self.n_fc,
-                                  self.Lh, self.out_pad)
+                                  self.Lh, self.out_pad, policy)
         assert self.layout.as_tuple() == tuple(int(x) for x in lay), 'host / device parameter layouts disagree'
         with torch.cuda.device(self.device):
             self.stream = torch.cuda.current_stream(self.device)
@@ -255,7 +270,10 @@ class VecA2C:
             sh.update({'fcf_w': (self.n_f_ls[a], fp), 'fcf_b': (fp,)})
         if ft:
             sh.update({'fct_w': (self.n_w_ls[a], ft), 'fct_b': (ft,)})
-        sh.update({'lstm_wx': (self.H, 4 * self.Lh), 'lstm_wh': (self.Lh, 4 * self.Lh), 'lstm_b': (4 * self.Lh,)})
+        if self.policy == 'lstm':
+            sh.update({'lstm_wx': (self.H, 4 * self.Lh), 'lstm_wh': (self.Lh, 4 * self.Lh), 'lstm_b': (4 * self.Lh,)})
+        else:
+            sh.update({'fc_w': (self.H, self.Lh), 'fc_b': (self.Lh,)})
         return sh
 
     def init_params(self, seed=None):

@@ -36,6 +36,7 @@ constexpr int kG4 = 4 * kL;      // gate columns i|f|o|u
 
 struct Layout {
     int G, A, SMAX, AMAX, H;
+    int NZ, fc;      // second-layer width: 4L gate columns (LSTM) or L units (FcACPolicy, agents/policies.py:214-256)
     long long stride, oW1, ob1, oWx, oWh, obl, oWo, obo;
 };
 
@@ -401,8 +402,10 @@ __global__ void __launch_bounds__(64) head_bwd_kernel(const float *__restrict__ 
             float sacc = 0.f;
 #pragma unroll
             for (int k = 0; k < kOut; ++k) sacc += dl[k] * Wo[jj * kOut + k];
-            sp[lane][jj] = sacc;                                   // own row only: no hazard
-            sv[lane][jj] = dv * Wv[jj * kOut];
+            // FC policy: the head input is relu(.), fold its derivative in here (dZ = dH * (h > 0))
+            const float hp_ = sp[lane][jj], hv_ = sv[lane][jj];
+            sp[lane][jj] = (lay.fc && !(hp_ > 0.f)) ? 0.f : sacc;  // own row only: no hazard
+            sv[lane][jj] = (lay.fc && !(hv_ > 0.f)) ? 0.f : dv * Wv[jj * kOut];
         }
         lp = -logp[ac < na ? ac : 0] * adv * invN;
         lv = 0.5f * v_coef * (R - v) * (R - v) * invN;
@@ -699,12 +702,12 @@ __global__ void rmsprop_kernel(float *w, float *ms, const float *grad, long long
 __global__ void transpose_wx_kernel(const float *params, Layout lay, float *WxT) {
     // WxT[g][c][h] = Wx[g][h][c]
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long per = (long long)lay.H * kG4;
+    const long long per = (long long)lay.H * lay.NZ;
     if (i >= per * lay.G) return;
     const int g = (int)(i / per);
     const long long r = i % per;
     const int c = (int)(r / lay.H), h = (int)(r % lay.H);
-    WxT[i] = params[(long long)g * lay.stride + lay.oWx + (long long)h * kG4 + c];
+    WxT[i] = params[(long long)g * lay.stride + lay.oWx + (long long)h * lay.NZ + c];
 }
 
 __global__ void fill_kernel(float *p, long long n, float v) {
@@ -755,15 +758,16 @@ int gemm(tsc_model *m, int kid, bool tn, int epi, int groups, int M, int N, int 
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 
-// X1 = relu(obs W1 + b1) ; Z = X1 Wx + bl   for `rows` samples of every group
+// X1 = relu(obs W1 + b1) ; then LSTM: Z = X1 Wx + bl,  FC policy: Hh = relu(X1 Wfc + bfc)
 int dense_forward(tsc_model *m, const float *obs, long long rows, float *X1, float *Z) {
     const Layout &L = m->lay;
     const int AS = L.A * L.SMAX;
     if (gemm(m, tsc::KID_FC_GEMM, false, tsc::EPI_BIAS_RELU, L.G, (int)rows, L.H, L.SMAX, obs, L.SMAX, AS, 2, m->params + L.oW1,
              L.stride, L.H, X1, rows * L.H, L.H, m->params + L.ob1, L.stride, nullptr, 0, 0, nullptr, 0, nullptr, 0))
         return 1;
-    if (gemm(m, tsc::KID_ZX_GEMM, false, tsc::EPI_BIAS, L.G, (int)rows, kG4, L.H, X1, rows * L.H, L.H, 1, m->params + L.oWx, L.stride,
-             kG4, Z, rows * kG4, kG4, m->params + L.obl, L.stride, nullptr, 0, 0, nullptr, 0, nullptr, 0))
+    if (gemm(m, tsc::KID_ZX_GEMM, false, L.fc ? tsc::EPI_BIAS_RELU : tsc::EPI_BIAS, L.G, (int)rows, L.NZ, L.H, X1, rows * L.H, L.H, 1,
+             m->params + L.oWx, L.stride, L.NZ, Z, rows * L.NZ, L.NZ, m->params + L.obl, L.stride, nullptr, 0, 0, nullptr, 0,
+             nullptr, 0))
         return 1;
     return 0;
 }
@@ -782,6 +786,7 @@ extern "C" {
 int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, tsc_model **out) {
     if (!cfg || !out || n_env <= 0) return tsc::fail("tsc_model_create: bad arguments");
     if (cfg->n_lstm != kL) return tsc::fail("tsc_model_create: num_lstm must be %d", kL);
+    if (cfg->policy_kind != 0 && cfg->policy_kind != 1) return tsc::fail("tsc_model_create: policy_kind must be 0 (lstm) or 1 (fc)");
     if (cfg->a_max > kOut) return tsc::fail("tsc_model_create: a_max %d > %d", cfg->a_max, kOut);
     if (cfg->s_max % 4) return tsc::fail("tsc_model_create: s_max must be a multiple of 4");
     TSC_HIP(hipSetDevice(device));
@@ -793,8 +798,9 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     L.A = cfg->n_agent; L.G = 2 * L.A; L.SMAX = cfg->s_max; L.AMAX = cfg->a_max;
     L.H = cfg->n_fc_wave + cfg->n_fc_fp + cfg->n_fc_wait;
     if (L.H % 4) return tsc::fail("tsc_model_create: hidden width must be a multiple of 4");
-    L.oW1 = 0; L.ob1 = (long long)L.SMAX * L.H; L.oWx = L.ob1 + L.H; L.oWh = L.oWx + (long long)L.H * kG4;
-    L.obl = L.oWh + (long long)kL * kG4; L.oWo = L.obl + kG4; L.obo = L.oWo + kL * kOut; L.stride = L.obo + kOut;
+    L.fc = cfg->policy_kind; L.NZ = L.fc ? kL : kG4;
+    L.oW1 = 0; L.ob1 = (long long)L.SMAX * L.H; L.oWx = L.ob1 + L.H; L.oWh = L.oWx + (long long)L.H * L.NZ;
+    L.obl = L.oWh + (L.fc ? 0 : (long long)kL * kG4); L.oWo = L.obl + L.NZ; L.obo = L.oWo + kL * kOut; L.stride = L.obo + kOut;
     m->nparam = L.stride * L.G;
     // structural mask of W1: obs row j of agent a feeds hidden columns [lo, hi)
     std::vector<int16_t> rr((size_t)L.A * L.SMAX * 2, 0);
@@ -834,7 +840,7 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bwd));
     m->dbg = nullptr;
     m->lds_fused = sizeof(float) * (size_t)(L.H + 64) * kXLd;
-    m->fused_fwd = (L.H % 32 == 0) && (L.SMAX <= 64) && (L.SMAX % 4 == 0) && ((L.H + 64) % 16 == 0) && m->lds_fused <= 160 * 1024;
+    m->fused_fwd = !L.fc && (L.H % 32 == 0) && (L.SMAX <= 64) && (L.SMAX % 4 == 0) && ((L.H + 64) % 16 == 0) && m->lds_fused <= 160 * 1024;
     if (const char *ev = getenv("TSC_UNFUSED_FWD")) if (atoi(ev)) m->fused_fwd = 0;
     if (m->fused_fwd)
         TSC_HIP(hipFuncSetAttribute((const void *)policy_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fused));
@@ -914,8 +920,16 @@ int tsc_model_forward(tsc_model *m, const float *obs, const uint8_t *done, float
         TSC_HIP(hipGetLastError());
         return 0;
     }
-    // unfused path (shapes the fused kernel does not cover): the training kernels with T = 1
-    if (dense_forward(m, obs, E, m->X1, m->Z)) return tsc::fail("tsc_model_forward: gemm launch failed");
+    // unfused path (FC policy, or shapes the fused kernel does not cover): the training kernels with T = 1
+    if (dense_forward(m, obs, E, m->X1, L.fc ? m->Hh : m->Z)) return tsc::fail("tsc_model_forward: gemm launch failed");
+    if (L.fc) {                                   // stateless: FcACPolicy.forward (agents/policies.py:237-240)
+        tsc::ProfScope psh(tsc::KID_HEAD_FWD, m->stream);
+        hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((E + 63) / 64), L.A), dim3(64), 0, m->stream, m->params, L,
+                           m->n_act, m->Hh, E, pi, v);
+        psh.stop();
+        TSC_HIP(hipGetLastError());
+        return 0;
+    }
     tsc::ProfScope ps1(tsc::KID_LSTM_FWD, m->stream);
     hipLaunchKernelGGL(lstm_fwd_kernel<false>, dim3(L.G, (E + 63) / 64), dim3(256), m->lds_fwd, m->stream, m->params, L, m->Z,
                        m->state_fw, advance ? m->state_fw : (float *)nullptr, m->Hh, m->Cc, m->Hp, done, 1, E, 0);
@@ -965,6 +979,25 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
     hipLaunchKernelGGL(returns_kernel, dim3((unsigned)((E * A + 255) / 256)), dim3(256), 0, st, m->r_rew, m->r_val, m->r_done,
                        R_boot, (int)T, (int)E, (int)A, m->gamma, m->Rs, m->Advs);
     ps6.stop();
+    float *g = m->grads;
+    if (L.fc) {
+        // FcACPolicy (agents/policies.py:214-256): Hh = relu(X1 Wfc + bfc); dZ = dH * (Hh > 0) comes out of head_bwd
+        if (dense_forward(m, m->r_obs, N, m->X1, m->Hh)) return tsc::fail("gemm launch failed");
+        tsc::ProfScope ps7(tsc::KID_HEAD_BWD, m->stream);
+        hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)A), dim3(64), 0, st, m->params, L, m->n_act,
+                           m->Hh, m->r_act, m->Rs, m->Advs, N, (float)m->vcoef, (float)beta, m->dL, m->dHh, m->stats);
+        ps7.stop();
+        tsc::ProfScope ps9(tsc::KID_TRANSPOSE, m->stream);
+        hipLaunchKernelGGL(transpose_wx_kernel, dim3((unsigned)((G * L.H * L.NZ + 255) / 256)), dim3(256), 0, st, m->params, L, m->WxT);
+        ps9.stop();
+        TSC_HIP(hipGetLastError());
+        if (gemm(m, tsc::KID_DWO_GEMM, true, tsc::EPI_NONE, (int)G, kL, kOut, (int)N, m->Hh, N * kL, kL, 1, m->dL, N * kOut, kOut, g + L.oWo,
+                 L.stride, kOut, nullptr, 0, nullptr, 0, 0, nullptr, 0, g + L.obo, L.stride)) return tsc::fail("gemm failed");
+        if (gemm(m, tsc::KID_DWX_GEMM, true, tsc::EPI_NONE, (int)G, L.H, kL, (int)N, m->X1, N * L.H, L.H, 1, m->dHh, N * kL, kL, g + L.oWx,
+                 L.stride, kL, nullptr, 0, nullptr, 0, 0, nullptr, 0, g + L.obl, L.stride)) return tsc::fail("gemm failed");
+        if (gemm(m, tsc::KID_DX1_GEMM, false, tsc::EPI_MASK_POS, (int)G, (int)N, L.H, kL, m->dHh, N * kL, kL, 1, m->WxT, (long long)L.H * kL, L.H,
+                 m->X1, N * L.H, L.H, nullptr, 0, m->X1, N * L.H, L.H, nullptr, 0, nullptr, 0)) return tsc::fail("gemm failed");
+    } else {
     // forward with stored activations, from the backward state (agents/policies.py:144-152)
     if (dense_forward(m, m->r_obs, N, m->X1, m->Z)) return tsc::fail("gemm launch failed");
     tsc::ProfScope ps2(tsc::KID_LSTM_FWD, m->stream);
@@ -983,7 +1016,6 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
     hipLaunchKernelGGL(transpose_wx_kernel, dim3((unsigned)((G * L.H * kG4 + 255) / 256)), dim3(256), 0, st, m->params, L, m->WxT);
     ps9.stop();
     TSC_HIP(hipGetLastError());
-    float *g = m->grads;
     // dWo = Hh^T dL (+ dbo) ; dWh = Hp^T dZ (+ dbl) ; dWx = X1^T dZ
     if (gemm(m, tsc::KID_DWO_GEMM, true, tsc::EPI_NONE, (int)G, kL, kOut, (int)N, m->Hh, N * kL, kL, 1, m->dL, N * kOut, kOut, g + L.oWo,
              L.stride, kOut, nullptr, 0, nullptr, 0, 0, nullptr, 0, g + L.obo, L.stride)) return tsc::fail("gemm failed");
@@ -994,6 +1026,7 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
     // dX1 = (dZ Wx^T) * relu'(X1), in place over X1
     if (gemm(m, tsc::KID_DX1_GEMM, false, tsc::EPI_MASK_POS, (int)G, (int)N, L.H, kG4, m->Z, N * kG4, kG4, 1, m->WxT, (long long)L.H * kG4, L.H,
              m->X1, N * L.H, L.H, nullptr, 0, m->X1, N * L.H, L.H, nullptr, 0, nullptr, 0)) return tsc::fail("gemm failed");
+    }
     // dW1 = obs^T dX1 masked to the block-diagonal structure (+ db1)
     if (gemm(m, tsc::KID_DW1_GEMM, true, tsc::EPI_ROWRANGE, (int)G, L.SMAX, L.H, (int)N, m->r_obs, L.SMAX, AS, 2, m->X1, N * L.H, L.H, g + L.oW1,
              L.stride, L.H, nullptr, 0, nullptr, 0, 0, m->rowrange, L.SMAX, g + L.ob1, L.stride)) return tsc::fail("gemm failed");

@@ -129,6 +129,8 @@ typedef struct tsc_model_cfg {
     int32_t n_fc_wave, n_fc_wait, n_fc_fp, n_lstm;   /* num_fw, num_ft, num_fp, num_lstm  */
     int32_t n_step;           /* batch_size: control steps per update                     */
     double gamma, reward_norm, reward_clip, value_coef, max_grad_norm, rmsp_alpha, rmsp_epsilon;
+    int32_t policy_kind;      /* 0 = LstmACPolicy / FPLstmACPolicy (agents/policies.py:75-211),
+                                 1 = FcACPolicy (agents/policies.py:214-256; fingerprints unsupported there) */
 } tsc_model_cfg;
 
 typedef struct tsc_model tsc_model;
@@ -136,7 +138,7 @@ typedef struct tsc_model tsc_model;
 /* Parameter layout.  Agent-tower group g = 2*agent + tower (0 = pi, 1 = v); every group owns
  * `stride` consecutive floats: W1[s_max][H] (block-diagonal fcw|fcf|fct, obs rows in env order),
  * b1[H], Wx[H][4L], Wh[L][4L], bl[4L], Wo[L][8], bo[8]   (H = n_fc_wave+n_fc_fp+n_fc_wait,
- * L = n_lstm, LSTM gate order i,f,o,u as agents/utils.py:107).  out[] = {G, stride, H, L,
+ * L = n_lstm, LSTM gate order i,f,o,u as agents/utils.py:107).  FC policy: Wx -> Wfc[H][L], no Wh, bl -> bfc[L].  out[] = {G, stride, H, L,
  * off_W1, off_b1, off_Wx, off_Wh, off_bl, off_Wo, off_bo, out_pad(8)}. */
 int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, tsc_model **out);
 int tsc_model_destroy(tsc_model *m);

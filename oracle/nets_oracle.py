@@ -55,7 +55,10 @@ def tower(p, ob, dones, s, nw, nt, nf):
     if nt:
         hs.append(fc(ob[..., nw:nw + nt], p['fct_w'], p['fct_b']))
     h = torch.cat(hs, -1)
-    h, s_new = lstm(h, dones, s, p['lstm_wx'], p['lstm_wh'], p['lstm_b'])
+    if 'fc_w' in p:                                   # FcACPolicy._build_net (agents/policies.py:227-235)
+        h, s_new = fc(h, p['fc_w'], p['fc_b']), s
+    else:
+        h, s_new = lstm(h, dones, s, p['lstm_wx'], p['lstm_wh'], p['lstm_b'])
     out = h @ p['out_w'] + p['out_b']
     return out, s_new
 

@@ -81,13 +81,14 @@ def test_gemm_tn_colsum_rowrange(Kred, M, N, G, split):
     np.testing.assert_allclose(out2.cpu().numpy(), ref * mask, atol=tol, rtol=1e-4)
 
 
-def _make(agent, E, n_step, seed=0, **cfg):
+def _make(agent, E, n_step, seed=0, policy='lstm', **cfg):
     from deeprl_signal_control_amd.agents import VecA2C
     from oracle.nets_oracle import OracleA2C
     scn = build_large_grid(agent)
     mc = dict(batch_size=n_step)
     mc.update(cfg)
-    m = VecA2C(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, scn.n_f_ls, E, scn.s_max, 5, mc, device=0, seed=seed, name=agent)
+    m = VecA2C(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, scn.n_f_ls, E, scn.s_max, 5, mc, device=0, seed=seed, name=agent,
+               policy=policy)
     o = OracleA2C(m.get_tower_params(), m.n_wave_ls, m.n_w_ls, m.n_f_ls, m.n_a_ls, E,
                   gamma=m.cfg['gamma'], reward_norm=m.cfg['reward_norm'], reward_clip=m.cfg['reward_clip'],
                   value_coef=m.cfg['value_coef'], max_grad_norm=m.cfg['max_grad_norm'])
@@ -101,9 +102,9 @@ def _rand_obs(scn, E, rng):
     return obs
 
 
-@pytest.mark.parametrize('agent,E', [('ma2c', 5), ('ia2c', 70)])
-def test_forward_matches_oracle(agent, E):
-    scn, m, o = _make(agent, E, 4)
+@pytest.mark.parametrize('agent,E,policy', [('ma2c', 5, 'lstm'), ('ia2c', 70, 'lstm'), ('ia2c', 33, 'fc')])
+def test_forward_matches_oracle(agent, E, policy):
+    scn, m, o = _make(agent, E, 4, policy=policy)
     rng = np.random.RandomState(1)
     m.reset(); o.reset()
     for t in range(5):
@@ -167,9 +168,10 @@ def _fill(scn, m, o, E, T, rng, p_done=0.1, terminal=False):
     return obs, done
 
 
-@pytest.mark.parametrize('agent,E,T,terminal', [('ma2c', 3, 6, False), ('ma2c', 66, 8, True), ('ia2c', 4, 40, False)])
-def test_backward_matches_oracle(agent, E, T, terminal):
-    scn, m, o = _make(agent, E, T, seed=5)
+@pytest.mark.parametrize('agent,E,T,terminal,policy', [('ma2c', 3, 6, False, 'lstm'), ('ma2c', 66, 8, True, 'lstm'),
+                                                        ('ia2c', 4, 40, False, 'lstm'), ('ia2c', 37, 12, True, 'fc')])
+def test_backward_matches_oracle(agent, E, T, terminal, policy):
+    scn, m, o = _make(agent, E, T, seed=5, policy=policy)
     rng = np.random.RandomState(E * T)
     m.reset(); o.reset()
     from deeprl_signal_control_amd import _lib
