@@ -19,8 +19,8 @@ class TscScenario(C.Structure):
         ('k_max', C.c_int32), ('p_max', C.c_int32), ('l_max', C.c_int32), ('s_max', C.c_int32),
         ('nbr_max', C.c_int32),
         ('lane_len', _fp), ('lane_vmax', _fp), ('lane_det_start', _fp),
-        ('lane_node', _ip), ('lane_opp', _ip), ('lane_up', _ip),
-        ('mv_next', _ip), ('mv_link', _ip), ('route_entry', _ip), ('flows', _ip),
+        ('lane_node', _ip), ('lane_up', _ip),
+        ('mv_next', _ip), ('mv_link', _ip), ('mv_yield', _ip), ('mv_prio', _ip), ('route_entry', _ip), ('flows', _ip),
         ('agent_lanes', _ip), ('agent_nlane', _ip), ('agent_nlink', _ip), ('agent_nphase', _ip),
         ('green_tab', _bp), ('yellow_tab', _bp),
         ('nbr', _ip), ('obs_kind', _ip), ('obs_src', _ip),
@@ -103,9 +103,10 @@ def scenario_struct(scn):
         s_max=scn.s_max, nbr_max=nbr_max,
         lane_len=arr(scn.lane_len, np.float32, _fp), lane_vmax=arr(scn.lane_vmax, np.float32, _fp),
         lane_det_start=arr(scn.lane_det_start, np.float32, _fp),
-        lane_node=arr(scn.lane_node, np.int32, _ip), lane_opp=arr(scn.lane_opp, np.int32, _ip),
+        lane_node=arr(scn.lane_node, np.int32, _ip),
         lane_up=arr(scn.lane_up, np.int32, _ip), mv_next=arr(scn.mv_next, np.int32, _ip),
-        mv_link=arr(scn.mv_link, np.int32, _ip), route_entry=arr(scn.route_entry_lane, np.int32, _ip),
+        mv_link=arr(scn.mv_link, np.int32, _ip), mv_yield=arr(scn.mv_yield, np.int32, _ip),
+        mv_prio=arr(scn.mv_prio, np.int32, _ip), route_entry=arr(scn.route_entry_lane, np.int32, _ip),
         flows=arr(scn.flows, np.int32, _ip), agent_lanes=arr(scn.agent_lanes, np.int32, _ip),
         agent_nlane=arr(scn.agent_nlane, np.int32, _ip), agent_nlink=arr(scn.agent_nlink, np.int32, _ip),
         agent_nphase=arr(scn.agent_nphase, np.int32, _ip),

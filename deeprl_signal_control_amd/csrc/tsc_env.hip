@@ -32,16 +32,24 @@ constexpr float kLen = 5.0f, kS0 = 2.5f, kAcc = 5.0f, kDec = 10.0f, kTHead = 1.5
 constexpr float kCab = 14.142136f, kHalt = 0.1f, kYieldT = 3.0f, kYieldD = 10.0f;
 constexpr int kCap = TSC_LANE_CAP, kMaxCross = TSC_MAX_CROSS, kMaxUp = TSC_MAX_UP;
 
+constexpr int kMaxEntry = 4;           // routes that may share one entry lane
+// movement word of (lane, route):  [11:0] next lane (0xFFF = route ends here, 0xFFE = n/a)
+//   [17:12] signal link (63 = none)   [29:18] lane this movement yields to (0xFFF = none)   [30] priority movement
+__host__ __device__ __forceinline__ int mv_tl(int w) { const int t = w & 0xFFF; return t == 0xFFF ? -1 : t == 0xFFE ? -2 : t; }
+__host__ __device__ __forceinline__ int mv_k(int w) { const int k = (w >> 12) & 0x3F; return k == 63 ? -1 : k; }
+__host__ __device__ __forceinline__ int mv_yield(int w) { const int y = (w >> 18) & 0xFFF; return y == 0xFFF ? -1 : y; }
+__host__ __device__ __forceinline__ bool mv_prio(int w) { return (w >> 30) & 1; }
+
 struct EnvDev {
     int NL, NLP, NR, A, NF, KMAX, PMAX, LMAX, SMAX, NBR, E;
     int NU, NLA;                   // lanes that can ever hold a vehicle (prefix after load sorting); threads per workgroup
     const float *lane_len, *lane_vmax, *lane_det;
-    const int *lane_node, *lane_opp, *lane_up;
-    const int *mv;                 // [NL*NR] packed: low16 = next lane (int16), high16 = link (int16)
+    const int *lane_node, *lane_up;
+    const int *mv;                 // [NL*NR] packed movement word, see mv_* helpers
     const int *route_entry;        // [NR]
     const int *flow_ptr;           // [NR+1] CSR over flows sorted by route
     const int *flows;              // [NF*4] begin,end,vph,route (sorted by route, stable)
-    const int *lane_routes;        // [NL][2] routes whose entry lane this is (-1 pad)
+    const int *lane_routes;        // [NL][kMaxEntry] routes whose entry lane this is (-1 pad)
     const uint8_t *emit_tab;       // [NR][emit_len] vehicles each route's flows emit at second t
     int emit_len;
     const int *agent_lanes, *agent_nlane, *agent_nlink, *agent_nphase;
@@ -136,8 +144,10 @@ __device__ __forceinline__ void follow2(float v, float v0, bool has_lead, float 
 
 __device__ __forceinline__ bool sig_open(int tl, int k, int a, int w, float x, float v, float L,
                                          const uint8_t *link, int KMAX, int teleport) {
-    if (tl == -1) return true;
-    if (a < 0 || k < 0) return false;
+    if (tl == -1) return true;                      // route ends at the lane end
+    if (tl < -1) return false;                      // route n/a on this lane: hold
+    if (a < 0) return true;                         // uncontrolled junction: always open
+    if (k < 0) return false;
     if (w >= teleport) return true;
     uint8_t st = link[a * KMAX + k];
     if (st == 'G' || st == 'g') return true;
@@ -156,6 +166,8 @@ struct Smem {
     int *wave, *halt, *hwait;                   // detectors [NLP]
     double *r;                                  // local rewards [A] (+1 for global)
     uint8_t *link_y, *link_g;                   // [A*KMAX]
+    float *len; int *node;                      // lane length / downstream agent [NLP]
+    int *pend, *ser; uint8_t *emit;             // per-route insertion state [NR], emissions [NR*8]
 };
 
 __device__ __forceinline__ Smem carve(char *base, const EnvDev &P) {
@@ -172,13 +184,16 @@ __device__ __forceinline__ Smem carve(char *base, const EnvDev &P) {
     s.nout = (int *)take(4 * P.NLP);
     s.wave = (int *)take(4 * P.NLP); s.halt = (int *)take(4 * P.NLP); s.hwait = (int *)take(4 * P.NLP);
     s.link_y = (uint8_t *)take(P.A * P.KMAX); s.link_g = (uint8_t *)take(P.A * P.KMAX);
+    s.len = (float *)take(4 * P.NLP); s.node = (int *)take(4 * P.NLP);
+    s.pend = (int *)take(4 * P.NR); s.ser = (int *)take(4 * P.NR); s.emit = (uint8_t *)take(8 * P.NR);
     return s;
 }
 
 size_t smem_bytes(const EnvDev &P) {
     auto r16 = [](size_t b) { return (b + 15) & ~size_t(15); };
     size_t t = r16(sizeof(double) * (P.A + 1)) + r16(sizeof(int) * P.NL * P.NR) + 6 * r16(4 * P.NLP) +
-               5 * r16(4 * kMaxCross * P.NLP) + 4 * r16(4 * P.NLP) + 2 * r16(P.A * P.KMAX);
+               5 * r16(4 * kMaxCross * P.NLP) + 4 * r16(4 * P.NLP) + 2 * r16(P.A * P.KMAX) + 2 * r16(4 * P.NLP) +
+               2 * r16(4 * P.NR) + r16(8 * P.NR);
     return t;
 }
 
@@ -275,15 +290,16 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         for (int k = 0; k < P.KMAX; ++k) { s.link_y[a * P.KMAX + k] = y[k]; s.link_g[a * P.KMAX + k] = g[k]; }
     }
     for (int i = l; i < P.NL * NR; i += blockDim.x) s.mv[i] = P.mv[i];
+    for (int q = l; q < NLP; q += blockDim.x) { s.len[q] = q < P.NL ? P.lane_len[q] : 1.0f; s.node[q] = q < P.NL ? P.lane_node[q] : -1; }
 
     // ---- per-lane constants and the initial lane summary
-    int n = 0, my_node = -1, my_opp = -1;
+    int n = 0, my_node = -1;
     float L = 1.0f, vmax = 1.0f, det = 0.0f;
     float hx = 0, hv = 0, tx = 0, tv = 0; uint32_t hm = 0;
     if (lane) {
         n = P.N[(size_t)e * NLP + l];
         L = P.lane_len[l]; vmax = P.lane_vmax[l]; det = P.lane_det[l];
-        my_node = P.lane_node[l]; my_opp = P.lane_opp[l];
+        my_node = P.lane_node[l];
         if (n > 0) { hx = X[l]; hv = V[l]; hm = M[l]; tx = X[(n - 1) * NLP + l]; tv = V[(n - 1) * NLP + l]; }
     }
     s.n[l] = n; s.hx[l] = hx; s.hv[l] = hv; s.hm[l] = hm; s.tx[l] = tx; s.tv[l] = tv;
@@ -306,22 +322,19 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     unsigned arrived = 0;
     // everything the per-second loop needs from constant tables / per-route state is pulled into registers
     // here, so no dependent global load sits between two barriers
-    int up0 = -1, up1 = -1, up2 = -1, up3 = -1, opp_node = -1, myr0 = -1, myr1 = -1;
-    int pend0 = 0, pend1 = 0, ser0 = 0, ser1 = 0;
-    unsigned long long em0 = 0ull, em1 = 0ull;            // emissions of my routes, 8 bits per second of this step
-    float opp_len = 1.0f;
+    int up0 = -1, up1 = -1, up2 = -1, up3 = -1;
+    int myr[kMaxEntry];
+#pragma unroll
+    for (int q = 0; q < kMaxEntry; ++q) myr[q] = -1;
     if (lane) {
         up0 = P.lane_up[l * kMaxUp]; up1 = P.lane_up[l * kMaxUp + 1]; up2 = P.lane_up[l * kMaxUp + 2]; up3 = P.lane_up[l * kMaxUp + 3];
-        if (my_opp >= 0) { opp_len = P.lane_len[my_opp]; opp_node = P.lane_node[my_opp]; }
-        myr0 = P.lane_routes[l * 2]; myr1 = P.lane_routes[l * 2 + 1];
-        if (myr0 >= 0) {
-            pend0 = P.pending[(size_t)e * NR + myr0]; ser0 = P.serial[(size_t)e * NR + myr0];
-            for (int q = 0; q < P.ctrl; ++q) em0 |= (unsigned long long)P.emit_tab[(size_t)myr0 * P.emit_len + t + q] << (8 * q);
-        }
-        if (myr1 >= 0) {
-            pend1 = P.pending[(size_t)e * NR + myr1]; ser1 = P.serial[(size_t)e * NR + myr1];
-            for (int q = 0; q < P.ctrl; ++q) em1 |= (unsigned long long)P.emit_tab[(size_t)myr1 * P.emit_len + t + q] << (8 * q);
-        }
+#pragma unroll
+        for (int q = 0; q < kMaxEntry; ++q) myr[q] = P.lane_routes[l * kMaxEntry + q];
+    }
+    // per-route insertion state and this step's emissions live in LDS for the duration of the launch
+    for (int r = l; r < NR; r += blockDim.x) {
+        s.pend[r] = P.pending[(size_t)e * NR + r]; s.ser[r] = P.serial[(size_t)e * NR + r];
+        for (int q = 0; q < 8; ++q) s.emit[r * 8 + q] = q < P.ctrl ? P.emit_tab[(size_t)r * P.emit_len + t + q] : 0;
     }
     __syncthreads();
     TSC_STAMP();
@@ -339,7 +352,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             // tsc_env_debug_clock): deeper software pipelining (look-ups of vehicle i+1 one iteration ahead)
             // and 4-wide chunks were both measured SLOWER (more instructions / fewer resident workgroups).
             struct Raw { float x, v, sf; uint32_t m; };
-            struct Pre { int tl, k; bool open; float v0; };
+            struct Pre { int tl, k, y; bool open; float v0; };
             auto load_raw = [&](int i) {
                 Raw r; r.x = 0.f; r.v = 0.f; r.sf = 1.f; r.m = 0u;
                 if (i < n) { const int o = i * NLP + l; r.x = X[o]; r.v = V[o]; r.sf = SF[o]; r.m = M[o]; }
@@ -348,7 +361,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             auto stage1 = [&](const Raw &r) {
                 Pre q;
                 const int mvp = s.mv[l * NR + (int)(r.m >> 16)];
-                q.tl = (int)(short)(mvp & 0xFFFF); q.k = (int)(short)(mvp >> 16);
+                q.tl = mv_tl(mvp); q.k = mv_k(mvp); q.y = mv_yield(mvp);
                 q.v0 = vmax * r.sf;
                 q.open = sig_open(q.tl, q.k, my_node, (int)(r.m & 0xFFFFu), r.x, r.v, L, link, P.KMAX, P.teleport);
                 return q;
@@ -367,14 +380,14 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 bool can_cross = false;
                 if (all_crossed) {
                     can_cross = open;
-                    if (can_cross && k >= 0 && k % 3 == 2 && w < P.teleport && my_opp >= 0 && s.n[my_opp] > 0) {
-                        // left turns yield to the opposing head going right / through
-                        const uint32_t om = s.hm[my_opp];
-                        const int mo = s.mv[my_opp * NR + (int)(om >> 16)];
-                        const int tlo = (int)(short)(mo & 0xFFFF), ko = (int)(short)(mo >> 16);
-                        if (ko >= 0 && ko % 3 != 2) {
-                            const float xo = s.hx[my_opp], vo = s.hv[my_opp], Lo = opp_len;
-                            if (sig_open(tlo, ko, opp_node, (int)(om & 0xFFFFu), xo, vo, Lo, link, P.KMAX, P.teleport)) {
+                    if (can_cross && pc.y >= 0 && w < P.teleport && s.n[pc.y] > 0) {
+                        // right of way: wait while the yield lane's head has an open priority movement and is near
+                        const int y = pc.y;
+                        const uint32_t om = s.hm[y];
+                        const int mo = s.mv[y * NR + (int)(om >> 16)];
+                        if (mv_prio(mo)) {
+                            const float xo = s.hx[y], vo = s.hv[y], Lo = s.len[y];
+                            if (sig_open(mv_tl(mo), mv_k(mo), s.node[y], (int)(om & 0xFFFFu), xo, vo, Lo, link, P.KMAX, P.teleport)) {
                                 const float d = Lo - xo;
                                 if (d < vo * kYieldT + kYieldD) can_cross = false;
                             }
@@ -409,7 +422,8 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 if (can_cross && xn >= L) {
                     if (!sink) {
                         const int o = nsent * NLP + l;
-                        s.ox[o] = xn - L; s.ov[o] = vn; s.osf[o] = sf; s.om[o] = nmeta; s.oto[o] = tl;
+                        const float ex = xn - L, Lt = s.len[tl];          // lanes shorter than one step's travel
+                        s.ox[o] = ex > Lt ? Lt : ex; s.ov[o] = vn; s.osf[o] = sf; s.om[o] = nmeta; s.oto[o] = tl;
                         ++nsent;
                     } else {
                         ++arrived;
@@ -443,8 +457,13 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     const int o = j * NLP + src;
                     if (s.oto[o] == l && n < kCap) {
                         const int d = n * NLP + l;
-                        const float ax = s.ox[o], av = s.ov[o];
+                        float ax = s.ox[o];
+                        const float av = s.ov[o];
                         const uint32_t am = s.om[o];
+                        if (n > 0 && ax > tx - kLen) {                   // arrivals of two feeders in one second
+                            ax = tx - kLen;
+                            if (ax < 0.0f) ax = 0.0f;
+                        }
                         X[d] = ax; V[d] = av; SF[d] = s.osf[o]; M[d] = am;
                         if (n == 0) { hx = ax; hv = av; hm = am; }
                         tx = ax; tv = av;
@@ -453,11 +472,11 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {                       // my entry routes, ascending
-                const int r = q == 0 ? myr0 : myr1;
+            for (int q = 0; q < kMaxEntry; ++q) {               // my entry routes, ascending
+                const int r = myr[q];
                 if (r < 0) continue;
-                int pend = (q == 0 ? pend0 : pend1) + (int)(((q == 0 ? em0 : em1) >> (8 * sub)) & 0xFFull);
-                int ser = q == 0 ? ser0 : ser1;
+                int pend = s.pend[r] + (int)s.emit[r * 8 + sub];
+                int ser = s.ser[r];
                 if (pend > 0 && n < kCap) {
                     const float xt = n > 0 ? tx : (L + kLen) + kS0;
                     const float xmax = (xt - kLen) - kS0;
@@ -477,7 +496,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                         ++ser;
                     }
                 }
-                if (q == 0) { pend0 = pend; ser0 = ser; } else { pend1 = pend; ser1 = ser; }
+                s.pend[r] = pend; s.ser[r] = ser;               // a route has exactly one entry lane: no race
             }
             s.n[l] = n; s.hx[l] = hx; s.hv[l] = hv; s.hm[l] = hm; s.tx[l] = tx; s.tv[l] = tv;
         }
@@ -489,8 +508,6 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     // ---- K4: detectors (envs/env.py:325-407): wave, halting, wait of the front-most vehicle
     if (lane) {
         P.N[(size_t)e * NLP + l] = n;
-        if (myr0 >= 0) { P.pending[(size_t)e * NR + myr0] = pend0; P.serial[(size_t)e * NR + myr0] = ser0; }
-        if (myr1 >= 0) { P.pending[(size_t)e * NR + myr1] = pend1; P.serial[(size_t)e * NR + myr1] = ser1; }
         int wave = 0, halt = 0, hw = 0;
         for (int i = 0; i < n; ++i) {
             const float x = X[i * NLP + l];
@@ -504,6 +521,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     } else {
         s.wave[l] = 0; s.halt[l] = 0; s.hwait[l] = 0;
     }
+    for (int r = l; r < NR; r += blockDim.x) { P.pending[(size_t)e * NR + r] = s.pend[r]; P.serial[(size_t)e * NR + r] = s.ser[r]; }
     if (arrived) atomicAdd(&P.arrived[e], (unsigned long long)arrived);
     if (l == 0) { P.tsec[e] = t; done[e] = t >= P.episode ? 1 : 0; }
     TSC_STAMP();
@@ -673,13 +691,19 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     }
     UP(lane_len, float, sc->lane_len, NL); UP(lane_vmax, float, sc->lane_vmax, NL);
     UP(lane_det, float, sc->lane_det_start, NL);
-    UP(lane_node, int, sc->lane_node, NL); UP(lane_opp, int, sc->lane_opp, NL);
+    UP(lane_node, int, sc->lane_node, NL);
     UP(lane_up, int, sc->lane_up, NL * kMaxUp);
+    if (NL > 0xFFD) return tsc::fail("tsc_env_create: n_lane %d > 4093 unsupported", NL);
     std::vector<int> mv((size_t)NL * NR);
     for (int i = 0; i < NL * NR; ++i) {
-        int nx = sc->mv_next[i], lk = sc->mv_link[i];
-        if (nx > 32767 || lk > 32767) return tsc::fail("tsc_env_create: table overflow");
-        mv[i] = (int)(((uint32_t)(uint16_t)(int16_t)nx) | ((uint32_t)(uint16_t)(int16_t)lk << 16));
+        const int nx = sc->mv_next[i], lk = sc->mv_link[i], yl = sc->mv_yield[i], pr = sc->mv_prio[i];
+        if (lk > 62) return tsc::fail("tsc_env_create: signal link index %d > 62 unsupported", lk);
+        const unsigned a = nx == -1 ? 0xFFFu : nx < -1 ? 0xFFEu : (unsigned)nx;
+        const unsigned b = lk < 0 ? 63u : (unsigned)lk;
+        const unsigned c = yl < 0 ? 0xFFFu : (unsigned)yl;
+        mv[i] = (int)(a | (b << 12) | (c << 18) | ((pr ? 1u : 0u) << 30));
+        if (mv_tl(mv[i]) != (nx < -1 ? -2 : nx) || mv_k(mv[i]) != (lk < 0 ? -1 : lk) || mv_yield(mv[i]) != (yl < 0 ? -1 : yl))
+            return tsc::fail("tsc_env_create: movement table overflow");
     }
     UP(mv, int, mv.data(), NL * NR);
     UP(route_entry, int, sc->route_entry, NR);
@@ -694,13 +718,14 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     UP(flows, int, fl.data(), fl.size());
     UP(flow_ptr, int, ptr.data(), NR + 1);
     {   // per-lane entry routes (<= 2) and per-route emission table (DESIGN.md microsim spec, rule 6)
-        std::vector<int> lr((size_t)NL * 2, -1);
+        std::vector<int> lr((size_t)NL * kMaxEntry, -1);
         for (int r = 0; r < NR; ++r) {
             const int l = sc->route_entry[r];
             if (l < 0 || l >= NL) return tsc::fail("tsc_env_create: route %d has no entry lane", r);
-            if (lr[l * 2] < 0) lr[l * 2] = r;
-            else if (lr[l * 2 + 1] < 0) lr[l * 2 + 1] = r;
-            else return tsc::fail("tsc_env_create: more than 2 routes enter lane %d", l);
+            int q = 0;
+            while (q < kMaxEntry && lr[l * kMaxEntry + q] >= 0) ++q;
+            if (q == kMaxEntry) return tsc::fail("tsc_env_create: more than %d routes enter lane %d", kMaxEntry, l);
+            lr[l * kMaxEntry + q] = r;
         }
         UP(lane_routes, int, lr.data(), lr.size());
         P.emit_len = sc->episode_length_sec + 64;

@@ -52,12 +52,13 @@ class Scenario:
     lane_vmax: np.ndarray            # f32 [NL]
     lane_node: np.ndarray            # i32 [NL] agent index of downstream TL node or -1 (sink)
     lane_det_start: np.ndarray       # f32 [NL] detector start position (L-50, or 0 = whole lane)
-    lane_opp: np.ndarray             # i32 [NL] opposing approach lane (left-turn yield) or -1
     lane_up: np.ndarray              # i32 [NL, MAX_UP] feeder lanes (ascending) or -1
     # routes
     n_route: int
     mv_next: np.ndarray              # i32 [NL, NR] next lane, -1 = arrive at lane end, -2 = n/a
     mv_link: np.ndarray              # i32 [NL, NR] link index at downstream node (3*approach+mv) or -1
+    mv_yield: np.ndarray             # i32 [NL, NR] lane whose head this movement yields to, or -1
+    mv_prio: np.ndarray              # i32 [NL, NR] 1 = priority movement (others may have to yield to it)
     route_entry_lane: np.ndarray     # i32 [NR]
     route_names: List[Tuple[str, str]]
     # signals
@@ -432,16 +433,23 @@ def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: in
         assert len(ups) <= MAX_UP
         lane_up[l2, :len(ups)] = ups
 
+    # right of way (DESIGN.md microsim spec, rule 2): left turns yield to the opposing approach's lane-0 head
+    # when that head goes right / through -- the only merge conflict the five phases admit
     opp = {'N': 'S', 'S': 'N', 'E': 'W', 'W': 'E'}
-    lane_opp = np.full(NL, -1, np.int32)
+    mv_yield = np.full((NL, NR), -1, np.int32)
+    mv_prio = np.zeros((NL, NR), np.int32)
     for l in range(NL):
         e = lane_edge[l]
         if lane_node[l] < 0:
             continue
         to = edges[e][1]
-        serves_left = edges[e][2] == 1 or lane_k[l] == 1
-        if serves_left:
-            lane_opp[l] = lane_id['%s_0' % in_edge(to, opp[approach_of(e)])]
+        for r in range(NR):
+            if mv_link[l, r] < 0:
+                continue
+            if mv_link[l, r] % 3 == _LEFT:
+                mv_yield[l, r] = lane_id['%s_0' % in_edge(to, opp[approach_of(e)])]
+            else:
+                mv_prio[l, r] = 1
 
     nmap = large_grid_neighbor_map()
     neighbors = [[aidx[j] for j in nmap[n]] for n in node_names]
@@ -459,8 +467,8 @@ def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: in
     scn = Scenario(
         name='large_grid', agent=agent, node_names=node_names, n_agent=N * N,
         lane_names=lane_names, lane_len=lane_len, lane_vmax=lane_vmax, lane_node=lane_node,
-        lane_det_start=lane_det, lane_opp=lane_opp, lane_up=lane_up,
-        n_route=NR, mv_next=mv_next, mv_link=mv_link, route_entry_lane=route_entry,
+        lane_det_start=lane_det, lane_up=lane_up,
+        n_route=NR, mv_next=mv_next, mv_link=mv_link, mv_yield=mv_yield, mv_prio=mv_prio, route_entry_lane=route_entry,
         route_names=route_names,
         agent_lanes=agent_lanes, agent_nlane=np.array(nlane, np.int32),
         agent_nlink=np.full(N * N, 12, np.int32), agent_nphase=np.array(n_a_ls, np.int32),
@@ -502,7 +510,6 @@ def permute_lanes(scn: Scenario, order) -> Scenario:
     scn.lane_names = [scn.lane_names[i] for i in order]
     for k in ('lane_len', 'lane_vmax', 'lane_node', 'lane_det_start'):
         setattr(scn, k, getattr(scn, k)[order])
-    scn.lane_opp = remap(scn.lane_opp[order])
     up = remap(scn.lane_up[order])
     for i in range(len(up)):                                    # keep "ascending feeder index" order
         row = np.sort(up[i][up[i] >= 0])
@@ -511,6 +518,8 @@ def permute_lanes(scn: Scenario, order) -> Scenario:
     scn.lane_up = up
     scn.mv_next = remap(scn.mv_next[order])
     scn.mv_link = scn.mv_link[order]
+    scn.mv_yield = remap(scn.mv_yield[order])
+    scn.mv_prio = scn.mv_prio[order]
     scn.route_entry_lane = remap(scn.route_entry_lane)
     scn.agent_lanes = remap(scn.agent_lanes)
     scn.link_lane = remap(scn.link_lane)

@@ -48,9 +48,10 @@ typedef struct tsc_scenario {
     int32_t s_max;        /* observation width (padded)        */
     int32_t nbr_max;      /* neighbours per agent (padded)     */
     const float   *lane_len, *lane_vmax, *lane_det_start;      /* [n_lane] */
-    const int32_t *lane_node, *lane_opp;                       /* [n_lane] */
+    const int32_t *lane_node;                                  /* [n_lane] downstream agent or -1 */
     const int32_t *lane_up;                                    /* [n_lane, TSC_MAX_UP] */
     const int32_t *mv_next, *mv_link;                          /* [n_lane, n_route] */
+    const int32_t *mv_yield, *mv_prio;                         /* [n_lane, n_route] right of way */
     const int32_t *route_entry;                                /* [n_route] */
     const int32_t *flows;                                      /* [n_flow, 4] begin,end,vph,route */
     const int32_t *agent_lanes;                                /* [n_agent, l_max] */
