@@ -20,7 +20,7 @@ class TscScenario(C.Structure):
         ('nbr_max', C.c_int32),
         ('lane_len', _fp), ('lane_vmax', _fp), ('lane_det_start', _fp),
         ('lane_node', _ip), ('lane_up', _ip),
-        ('mv_next', _ip), ('mv_link', _ip), ('mv_yield', _ip), ('mv_prio', _ip), ('route_entry', _ip), ('flows', _ip),
+        ('mv_next', _ip), ('mv_link', _ip), ('mv_yield', _ip), ('mv_prio', _ip), ('mv_zip', _ip), ('route_entry', _ip), ('flows', _ip),
         ('agent_lanes', _ip), ('agent_nlane', _ip), ('agent_nlink', _ip), ('agent_nphase', _ip),
         ('green_tab', _bp), ('yellow_tab', _bp),
         ('nbr', _ip), ('obs_kind', _ip), ('obs_src', _ip),
@@ -106,7 +106,7 @@ def scenario_struct(scn):
         lane_node=arr(scn.lane_node, np.int32, _ip),
         lane_up=arr(scn.lane_up, np.int32, _ip), mv_next=arr(scn.mv_next, np.int32, _ip),
         mv_link=arr(scn.mv_link, np.int32, _ip), mv_yield=arr(scn.mv_yield, np.int32, _ip),
-        mv_prio=arr(scn.mv_prio, np.int32, _ip), route_entry=arr(scn.route_entry_lane, np.int32, _ip),
+        mv_prio=arr(scn.mv_prio, np.int32, _ip), mv_zip=arr(scn.mv_zip, np.int32, _ip), route_entry=arr(scn.route_entry_lane, np.int32, _ip),
         flows=arr(scn.flows, np.int32, _ip), agent_lanes=arr(scn.agent_lanes, np.int32, _ip),
         agent_nlane=arr(scn.agent_nlane, np.int32, _ip), agent_nlink=arr(scn.agent_nlink, np.int32, _ip),
         agent_nphase=arr(scn.agent_nphase, np.int32, _ip),

@@ -46,6 +46,7 @@ struct EnvDev {
     const float *lane_len, *lane_vmax, *lane_det;
     const int *lane_node, *lane_up;
     const int *mv;                 // [NL*NR] packed movement word, see mv_* helpers
+    const uint8_t *zip;            // [NL*NR] zipper-merge slot: rank | count << 4 (0 = none)
     const int *route_entry;        // [NR]
     const int *flow_ptr;           // [NR+1] CSR over flows sorted by route
     const int *flows;              // [NF*4] begin,end,vph,route (sorted by route, stable)
@@ -168,6 +169,7 @@ struct Smem {
     uint8_t *link_y, *link_g;                   // [A*KMAX]
     float *len; int *node;                      // lane length / downstream agent [NLP]
     int *pend, *ser; uint8_t *emit;             // per-route insertion state [NR], emissions [NR*8]
+    uint8_t *zip;                               // [NL*NR]
 };
 
 __device__ __forceinline__ Smem carve(char *base, const EnvDev &P) {
@@ -186,6 +188,7 @@ __device__ __forceinline__ Smem carve(char *base, const EnvDev &P) {
     s.link_y = (uint8_t *)take(P.A * P.KMAX); s.link_g = (uint8_t *)take(P.A * P.KMAX);
     s.len = (float *)take(4 * P.NLP); s.node = (int *)take(4 * P.NLP);
     s.pend = (int *)take(4 * P.NR); s.ser = (int *)take(4 * P.NR); s.emit = (uint8_t *)take(8 * P.NR);
+    s.zip = (uint8_t *)take(P.NL * P.NR);
     return s;
 }
 
@@ -193,7 +196,7 @@ size_t smem_bytes(const EnvDev &P) {
     auto r16 = [](size_t b) { return (b + 15) & ~size_t(15); };
     size_t t = r16(sizeof(double) * (P.A + 1)) + r16(sizeof(int) * P.NL * P.NR) + 6 * r16(4 * P.NLP) +
                5 * r16(4 * kMaxCross * P.NLP) + 4 * r16(4 * P.NLP) + 2 * r16(P.A * P.KMAX) + 2 * r16(4 * P.NLP) +
-               2 * r16(4 * P.NR) + r16(8 * P.NR);
+               2 * r16(4 * P.NR) + r16(8 * P.NR) + r16(P.NL * P.NR);
     return t;
 }
 
@@ -289,7 +292,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         const uint8_t *y = (prev < 0 || prev == act) ? g : P.yellow_tab + (((size_t)a * P.PMAX + prev) * P.PMAX + act) * P.KMAX;
         for (int k = 0; k < P.KMAX; ++k) { s.link_y[a * P.KMAX + k] = y[k]; s.link_g[a * P.KMAX + k] = g[k]; }
     }
-    for (int i = l; i < P.NL * NR; i += blockDim.x) s.mv[i] = P.mv[i];
+    for (int i = l; i < P.NL * NR; i += blockDim.x) { s.mv[i] = P.mv[i]; s.zip[i] = P.zip[i]; }
     for (int q = l; q < NLP; q += blockDim.x) { s.len[q] = q < P.NL ? P.lane_len[q] : 1.0f; s.node[q] = q < P.NL ? P.lane_node[q] : -1; }
 
     // ---- per-lane constants and the initial lane summary
@@ -352,7 +355,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             // tsc_env_debug_clock): deeper software pipelining (look-ups of vehicle i+1 one iteration ahead)
             // and 4-wide chunks were both measured SLOWER (more instructions / fewer resident workgroups).
             struct Raw { float x, v, sf; uint32_t m; };
-            struct Pre { int tl, k, y; bool open; float v0; };
+            struct Pre { int tl, k, y, z; bool open; float v0; };
             auto load_raw = [&](int i) {
                 Raw r; r.x = 0.f; r.v = 0.f; r.sf = 1.f; r.m = 0u;
                 if (i < n) { const int o = i * NLP + l; r.x = X[o]; r.v = V[o]; r.sf = SF[o]; r.m = M[o]; }
@@ -361,7 +364,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             auto stage1 = [&](const Raw &r) {
                 Pre q;
                 const int mvp = s.mv[l * NR + (int)(r.m >> 16)];
-                q.tl = mv_tl(mvp); q.k = mv_k(mvp); q.y = mv_yield(mvp);
+                q.tl = mv_tl(mvp); q.k = mv_k(mvp); q.y = mv_yield(mvp); q.z = s.zip[l * NR + (int)(r.m >> 16)];
                 q.v0 = vmax * r.sf;
                 q.open = sig_open(q.tl, q.k, my_node, (int)(r.m & 0xFFFFu), r.x, r.v, L, link, P.KMAX, P.teleport);
                 return q;
@@ -393,7 +396,10 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                             }
                         }
                     }
+                    // zipper merge: feeder `rank` of `count` may send in second t iff (t + rank) % count == 0
+                    if (can_cross && (pc.z >> 4) > 1 && ((t + (pc.z & 0xF)) % (pc.z >> 4)) != 0) can_cross = false;
                     if (can_cross && tl >= 0 && s.n[tl] + kMaxCross > kCap) can_cross = false;
+                    if (can_cross && tl >= 0 && s.n[tl] > 0 && s.tx[tl] < kLen) can_cross = false;   // no room behind the tail
                     if (can_cross && ncross >= kMaxCross) can_cross = false;
                     if (tl < -1) can_cross = false;
                 }
@@ -413,6 +419,10 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     const float lim = L + (s.tx[tl] - kLen);
                     if (xn > lim) { xn = lim; clamped = true; }
                 }
+                if (can_cross && !sink) {                          // target lane shorter than one step's travel
+                    const float far = L + s.len[tl];
+                    if (xn > far) { xn = far; clamped = true; }
+                }
                 if (!can_cross && xn > L) { xn = L; clamped = true; }
                 if (xn < x) { xn = x; clamped = true; }
                 if (clamped) vn = xn - x;
@@ -422,7 +432,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 if (can_cross && xn >= L) {
                     if (!sink) {
                         const int o = nsent * NLP + l;
-                        const float ex = xn - L, Lt = s.len[tl];          // lanes shorter than one step's travel
+                        const float ex = xn - L, Lt = s.len[tl];          // rounding of (L + Lt) - L
                         s.ox[o] = ex > Lt ? Lt : ex; s.ov[o] = vn; s.osf[o] = sf; s.om[o] = nmeta; s.oto[o] = tl;
                         ++nsent;
                     } else {
@@ -706,6 +716,15 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
             return tsc::fail("tsc_env_create: movement table overflow");
     }
     UP(mv, int, mv.data(), NL * NR);
+    {
+        std::vector<uint8_t> zp((size_t)NL * NR, 0);
+        for (int i = 0; i < NL * NR; ++i) {
+            const int z = sc->mv_zip[i], rank = z & 0xFF, cnt = z >> 8;
+            if (rank > 15 || cnt > 15) return tsc::fail("tsc_env_create: zipper slot overflow");
+            zp[i] = (uint8_t)(rank | (cnt << 4));
+        }
+        UP(zip, uint8_t, zp.data(), zp.size());
+    }
     UP(route_entry, int, sc->route_entry, NR);
     // flows sorted by route (stable) + CSR
     std::vector<int> fl; std::vector<int> ptr(NR + 1, 0);

@@ -59,6 +59,7 @@ class Scenario:
     mv_link: np.ndarray              # i32 [NL, NR] link index at downstream node (3*approach+mv) or -1
     mv_yield: np.ndarray             # i32 [NL, NR] lane whose head this movement yields to, or -1
     mv_prio: np.ndarray              # i32 [NL, NR] 1 = priority movement (others may have to yield to it)
+    mv_zip: np.ndarray               # i32 [NL, NR] zipper merge slot: rank | count << 8 (0 = no zipper)
     route_entry_lane: np.ndarray     # i32 [NR]
     route_names: List[Tuple[str, str]]
     # signals
@@ -468,7 +469,8 @@ def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: in
         name='large_grid', agent=agent, node_names=node_names, n_agent=N * N,
         lane_names=lane_names, lane_len=lane_len, lane_vmax=lane_vmax, lane_node=lane_node,
         lane_det_start=lane_det, lane_up=lane_up,
-        n_route=NR, mv_next=mv_next, mv_link=mv_link, mv_yield=mv_yield, mv_prio=mv_prio, route_entry_lane=route_entry,
+        n_route=NR, mv_next=mv_next, mv_link=mv_link, mv_yield=mv_yield, mv_prio=mv_prio,
+        mv_zip=np.zeros((NL, NR), np.int32), route_entry_lane=route_entry,
         route_names=route_names,
         agent_lanes=agent_lanes, agent_nlane=np.array(nlane, np.int32),
         agent_nlink=np.full(N * N, 12, np.int32), agent_nphase=np.array(n_a_ls, np.int32),
@@ -478,6 +480,153 @@ def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: in
         obs_kind=obs_kind, obs_src=obs_src, flows=flows, obs_len=lens,
         extra={'peak_flow1': peak_flow1, 'peak_flow2': peak_flow2, 'demand': demand},
         **env_kw)
+    return sort_lanes_by_load(scn) if sort_lanes else scn
+
+
+
+# ---------------------------------------------------------------------------
+# real_net (Monaco)
+# ---------------------------------------------------------------------------
+def build_real_net(agent: str = 'ma2c', flow_rate: int = 325, sort_lanes: bool = True, **env_kw) -> Scenario:
+    """Monaco scenario (envs/real_net_env.py) from the compiled table file
+    ``data/real_net.json`` (tools/compile_real_net.py: most.net.xml lanes / connections / signal links,
+    NODES + PHASES of envs/real_net_env.py:20-68, flows of real_net/data/build_file.py:27-104).
+
+    Reference semantics kept: agent order = sorted node ids (env.py:232); a node's lanes = dedup of
+    its signal links' incoming lanes in link order (env.py:219-230); wave-only state measured on
+    the whole lane (env.py:376-377, real_net_env.py:18); reward = -sum(min(10, halting))
+    (env.py:332-333, objective queue); rewards / ((1+deg)*20) (env.py:599-601,625-629);
+    --time-to-teleport 300 (env.py:283-284); every active flow at `flow_rate` veh/h.
+    Microsim-side choices: zero-length junctions, unsignalised junctions always open,
+    free lane choice at edge entry among the lanes that continue the route, no right-of-way table."""
+    import json
+    import os
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'real_net.json')))
+    node_names = sorted(d['nodes'])
+    aidx = {n: i for i, n in enumerate(node_names)}
+    A = len(node_names)
+    controlled = {}                                            # lane name -> agent
+    for n in node_names:
+        for lane in d['tl_links'][n].values():
+            controlled[lane] = aidx[n]
+    lane_names, lane_id = [], {}
+    for e in sorted(d['edges']):
+        for i, (ln, sp, ok) in enumerate(d['edges'][e]['lanes']):
+            nm = '%s_%d' % (e, i)
+            if ok or nm in controlled:
+                lane_id[nm] = len(lane_names)
+                lane_names.append(nm)
+    NL = len(lane_names)
+    lane_edge = [nm.rsplit('_', 1)[0] for nm in lane_names]
+    lane_k = [int(nm.rsplit('_', 1)[1]) for nm in lane_names]
+    lane_len = np.array([d['edges'][e]['lanes'][k][0] for e, k in zip(lane_edge, lane_k)], np.float32)
+    lane_vmax = np.array([d['edges'][e]['lanes'][k][1] for e, k in zip(lane_edge, lane_k)], np.float32)
+    lane_node = np.array([controlled.get(nm, -1) for nm in lane_names], np.int32)
+    conn = {}                                                   # (edge, lane) -> {to_edge: [(to_lane, node, link)]}
+    for f, fl, t, tl_, node, link in d['connections']:
+        conn.setdefault((f, fl), {}).setdefault(t, []).append((tl_, node, link))
+    routes = d['routes']
+    NR = len(routes)
+
+    def continues(e, k, nxt):
+        return nxt is None or nxt in conn.get((e, k), {})
+
+    mv_next = np.full((NL, NR), -2, np.int32)
+    mv_link = np.full((NL, NR), -1, np.int32)
+    route_entry = np.zeros(NR, np.int32)
+    for r, path in enumerate(routes):
+        assert len(set(path)) == len(path), 'route %d visits an edge twice' % r
+        for p, e in enumerate(path):
+            e2 = path[p + 1] if p + 1 < len(path) else None
+            e3 = path[p + 2] if p + 2 < len(path) else None
+            for k in range(len(d['edges'][e]['lanes'])):
+                nm = '%s_%d' % (e, k)
+                if nm not in lane_id:
+                    continue
+                l = lane_id[nm]
+                if e2 is None:
+                    mv_next[l, r] = -1
+                    continue
+                cs = sorted(conn.get((e, k), {}).get(e2, []))
+                if not cs:
+                    continue
+                good = [c for c in cs if continues(e2, c[0], e3)]
+                if good:
+                    tk, node, link = good[0]
+                else:                                           # free lane choice at edge entry
+                    cand = [k2 for k2 in range(len(d['edges'][e2]['lanes']))
+                            if '%s_%d' % (e2, k2) in lane_id and d['edges'][e2]['lanes'][k2][2] and continues(e2, k2, e3)]
+                    assert cand, 'route %d is not drivable at %s -> %s' % (r, e, e2)
+                    tk, (node, link) = cand[0], cs[0][1:]
+                mv_next[l, r] = lane_id['%s_%d' % (e2, tk)]
+                mv_link[l, r] = link if node in aidx else -1
+        first = [k for k in range(len(d['edges'][path[0]]['lanes']))
+                 if '%s_%d' % (path[0], k) in lane_id and d['edges'][path[0]]['lanes'][k][2] and continues(path[0], k, path[1])]
+        route_entry[r] = lane_id['%s_%d' % (path[0], first[0])]
+        l, hops = int(route_entry[r]), 0                        # every route must reach its last edge
+        while mv_next[l, r] >= 0:
+            l, hops = int(mv_next[l, r]), hops + 1
+        assert mv_next[l, r] == -1 and hops == len(path) - 1, 'route %d broken' % r
+    lane_up = np.full((NL, MAX_UP), -1, np.int32)
+    for l2 in range(NL):
+        ups = sorted({l for l in range(NL) if (mv_next[l] == l2).any()})
+        assert len(ups) <= MAX_UP, 'lane %s has %d feeders' % (lane_names[l2], len(ups))
+        lane_up[l2, :len(ups)] = ups
+    # zipper merge (DESIGN.md microsim spec): a lane with several feeders takes arrivals from feeder `rank`
+    # only in seconds with (t + rank) % count == 0
+    mv_zip = np.zeros((NL, NR), np.int32)
+    for l in range(NL):
+        for r in range(NR):
+            t2 = mv_next[l, r]
+            if t2 >= 0:
+                ups = [u for u in lane_up[t2] if u >= 0]
+                if len(ups) > 1:
+                    mv_zip[l, r] = ups.index(l) | (len(ups) << 8)
+    phases = [d['phases'][d['nodes'][n]['phase']] for n in node_names]
+    kmax = max(len(p[0]) for p in phases)
+    lmax = 0
+    link_lane = np.full((A, kmax), -1, np.int32)
+    lanes_per_agent = []
+    for a, n in enumerate(node_names):
+        links = d['tl_links'][n]
+        assert len(links) == len(phases[a][0])                  # env.py:159
+        seq = [lane_id[links[str(k)]] for k in range(len(links))]
+        link_lane[a, :len(seq)] = seq
+        ded = []
+        for l in seq:
+            if l not in ded:
+                ded.append(l)
+        lanes_per_agent.append(ded)
+        lmax = max(lmax, len(ded))
+    agent_lanes = np.full((A, lmax), -1, np.int32)
+    for a, ded in enumerate(lanes_per_agent):
+        agent_lanes[a, :len(ded)] = ded
+    nlane = [len(x) for x in lanes_per_agent]
+    neighbors = [[aidx[j] for j in d['nodes'][n]['neighbors']] for n in node_names]
+    n_a_ls = [len(p) for p in phases]
+    a_max = max(n_a_ls)
+    n_s, n_w, n_f = _state_dims(agent, nlane, n_a_ls, neighbors, False)
+    obs_kind, obs_src, lens = _obs_table(agent, agent_lanes, nlane, n_a_ls, neighbors, False, a_max)
+    if agent not in ('greedy', 'a2c'):
+        assert lens == n_s
+    green, yellow = _signal_tables(phases, kmax)
+    flows = np.array([[b, e, flow_rate, r] for r, b, e in d['flows']], np.int32)
+    kw = dict(objective='queue', coef_wait=0.0, norm_wait=30.0, has_wait_state=False, queue_cap=10,
+              reward_scale_realnet=True, teleport_sec=300)
+    kw.update(env_kw)
+    scn = Scenario(
+        name='real_net', agent=agent, node_names=node_names, n_agent=A,
+        lane_names=lane_names, lane_len=lane_len, lane_vmax=lane_vmax, lane_node=lane_node,
+        lane_det_start=np.zeros(NL, np.float32), lane_up=lane_up,
+        n_route=NR, mv_next=mv_next, mv_link=mv_link, mv_yield=np.full((NL, NR), -1, np.int32),
+        mv_prio=np.zeros((NL, NR), np.int32), mv_zip=mv_zip, route_entry_lane=route_entry,
+        route_names=[(p[0], p[-1]) for p in routes],
+        agent_lanes=agent_lanes, agent_nlane=np.array(nlane, np.int32),
+        agent_nlink=np.array([len(p[0]) for p in phases], np.int32), agent_nphase=np.array(n_a_ls, np.int32),
+        link_lane=link_lane, phases=phases, green_tab=green, yellow_tab=yellow,
+        neighbors=neighbors, n_s_ls=n_s, n_w_ls=n_w, n_f_ls=n_f, n_a_ls=n_a_ls,
+        obs_kind=obs_kind, obs_src=obs_src, flows=flows, obs_len=lens,
+        extra={'flow_rate': flow_rate, 'routes': routes}, **kw)
     return sort_lanes_by_load(scn) if sort_lanes else scn
 
 
@@ -520,6 +669,7 @@ def permute_lanes(scn: Scenario, order) -> Scenario:
     scn.mv_link = scn.mv_link[order]
     scn.mv_yield = remap(scn.mv_yield[order])
     scn.mv_prio = scn.mv_prio[order]
+    scn.mv_zip = scn.mv_zip[order]
     scn.route_entry_lane = remap(scn.route_entry_lane)
     scn.agent_lanes = remap(scn.agent_lanes)
     scn.link_lane = remap(scn.link_lane)
@@ -539,5 +689,6 @@ def sort_lanes_by_load(scn: Scenario) -> Scenario:
 def build_scenario(name: str, agent: str = 'ma2c', **kw) -> Scenario:
     if name == 'large_grid':
         return build_large_grid(agent, **kw)
-    raise ValueError('unknown scenario %r (large_grid is built in; real_net comes from '
-                     'tools/compile_real_net.py tables)' % name)
+    if name == 'real_net':
+        return build_real_net(agent, **kw)
+    raise ValueError('unknown scenario %r (large_grid, real_net)' % name)

@@ -52,6 +52,7 @@ typedef struct tsc_scenario {
     const int32_t *lane_up;                                    /* [n_lane, TSC_MAX_UP] */
     const int32_t *mv_next, *mv_link;                          /* [n_lane, n_route] */
     const int32_t *mv_yield, *mv_prio;                         /* [n_lane, n_route] right of way */
+    const int32_t *mv_zip;                                     /* [n_lane, n_route] zipper slot: rank | count << 8 */
     const int32_t *route_entry;                                /* [n_route] */
     const int32_t *flows;                                      /* [n_flow, 4] begin,end,vph,route */
     const int32_t *agent_lanes;                                /* [n_agent, l_max] */

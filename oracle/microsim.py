@@ -26,7 +26,7 @@ def lib():
         L = C.CDLL(build())
         fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
         L.ms_create.restype = C.c_void_p
-        L.ms_create.argtypes = [C.c_int] * 7 + [fp, fp, ip, ip, ip, ip, ip, ip, ip, ip]
+        L.ms_create.argtypes = [C.c_int] * 7 + [fp, fp, ip, ip, ip, ip, ip, ip, ip, ip, ip]
         L.ms_destroy.argtypes = [C.c_void_p]
         L.ms_reset.argtypes = [C.c_void_p, C.c_uint32]
         L.ms_set_links.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int]
@@ -60,7 +60,7 @@ class MicroSim:
         L = lib()
         self._keep = [_f(scn.lane_len), _f(scn.lane_vmax), _i(scn.lane_node),
                       _i(scn.lane_up), _i(scn.mv_next), _i(scn.mv_link), _i(scn.mv_yield), _i(scn.mv_prio),
-                      _i(scn.route_entry_lane), _i(scn.flows)]
+                      _i(scn.mv_zip), _i(scn.route_entry_lane), _i(scn.flows)]
         fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int32)
         ptrs = [a.ctypes.data_as(fp if a.dtype == np.float32 else ip) for a in self._keep]
         self.kmax = int(scn.green_tab.shape[2])

@@ -55,6 +55,68 @@ def rollout(env, T, rng, p_greedy, with_fp, resets=1, test_ind=None):
     return {k: np.array(v) for k, v in rec.items()}
 
 
+def rollout_general(env, T, rng, p_keep, with_fp, test_ind=None):
+    """Any scenario: sticky random actions (keep the previous action with probability p_keep), per-agent
+    action counts, Dirichlet fingerprints padded to the widest action set."""
+    n_a = [int(x) for x in env.n_a_ls]
+    amax = max(n_a)
+    rec = dict(actions=[], policies=[], obs=[], reward=[], global_reward=[], done=[])
+    ob = env.reset() if test_ind is None else env.reset(test_ind=test_ind)
+    rec['obs'].append(np.concatenate(ob))
+    act = [0] * len(n_a)
+    for _ in range(T):
+        pol = np.zeros((len(n_a), amax), np.float32)
+        if with_fp:
+            pl = [rng.dirichlet(np.ones(n)).astype(np.float32) for n in n_a]
+            env.update_fingerprint(pl)
+            for a, p in enumerate(pl):
+                pol[a, :len(p)] = p
+        act = [act[a] if rng.rand() < p_keep else int(rng.randint(0, n_a[a])) for a in range(len(n_a))]
+        ob, r, done, g = env.step(act)
+        rec['actions'].append(act); rec['policies'].append(pol); rec['obs'].append(np.concatenate(ob))
+        rec['reward'].append(np.asarray(r, np.float64)); rec['global_reward'].append(float(g)); rec['done'].append(bool(done))
+        if done:
+            break
+    env.terminate()
+    return {k: np.array(v) for k, v in rec.items()}
+
+
+def real_net_fixtures():
+    """envs/real_net_env.py RealNetEnv unmodified over the fake TraCI + Monaco tables."""
+    from deeprl_signal_control_amd.scenario import build_real_net
+    env = fake_traci.ref_env('real_net', 'ma2c', scn=build_real_net('ma2c'))
+    g = rollout_general(env, 720, np.random.RandomState(21), 0.8, True)
+    np.savez_compressed(os.path.join(OUT, 'real_net_ma2c.npz'), **g)
+    static = dict(node_names=env.node_names, n_s_ls=[int(x) for x in env.n_s_ls], n_a_ls=[int(x) for x in env.n_a_ls],
+                  n_w_ls=[int(x) for x in env.n_w_ls], n_f_ls=[int(x) for x in env.n_f_ls], T=float(env.T),
+                  neighbors={n: list(env.nodes[n].neighbor) for n in env.node_names},
+                  ilds_in={n: list(env.nodes[n].ilds_in) for n in env.node_names},
+                  lanes_in={n: list(env.nodes[n].lanes_in) for n in env.node_names},
+                  phase_id={n: env.nodes[n].phase_id for n in env.node_names})
+    ys = {}
+    for n in env.node_names:                                   # yellow strings of every node's phase set
+        k = env.nodes[n].n_a
+        for p in range(k):
+            for q in range(k):
+                env.nodes[n].prev_action = p
+                ys['%s:%d->%d' % (n, p, q)] = env._get_node_phase(q, n, 'yellow')
+    static['yellow'] = ys
+    rou = open(os.path.join(env.data_path, 'in', 'most_0.rou.xml')).read()
+    static['flows'] = [[m.group(1), m.group(2), m.group(3), int(m.group(4)), int(m.group(5)), int(m.group(6))]
+                       for m in re.finditer(r'from="(\S+)" to="(\S+)" via="([^"]*)" begin="(\d+)" end="(\d+)" '
+                                            r'vehsPerHour="(\d+)"', rou)]
+    env = fake_traci.ref_env('real_net', 'ia2c', scn=build_real_net('ia2c'))
+    g = rollout_general(env, 150, np.random.RandomState(22), 0.7, False)
+    np.savez_compressed(os.path.join(OUT, 'real_net_ia2c.npz'), **g)
+    static['ia2c_n_s_ls'] = [int(x) for x in env.n_s_ls]
+    env = fake_traci.ref_env('real_net', 'ma2c', scn=build_real_net('ma2c'))
+    env.train_mode = False
+    g = rollout_general(env, 60, np.random.RandomState(23), 0.8, True, test_ind=2)
+    np.savez_compressed(os.path.join(OUT, 'real_net_ma2c_test.npz'), **g)
+    with open(os.path.join(OUT, 'real_net_static.json'), 'w') as f:
+        json.dump(static, f, indent=1)
+
+
 def env_fixtures():
     # 1. MA2C, full episode (720 control steps), then a second short episode (seed += 1)
     env = fake_traci.ref_env('large_grid', 'ma2c')
@@ -138,6 +200,7 @@ def learner_fixtures():
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     env_fixtures()
+    real_net_fixtures()
     learner_fixtures()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
