@@ -34,6 +34,18 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (profiles/r01_pmc.json: separate
+    FETCH_SIZE / WRITE_SIZE passes, KB units; the gfx950 x2 FETCH correction only applies to 16 B/lane streams and
+    is NOT applied to these dword-per-lane kernels) or None."""
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')))
+        k = d['kernels'][kernel]
+        return (k['fetch_kb'] + k['write_kb']) * 1024.0
+    except Exception:
+        return None
+
+
 def algorithmic_flops(model, rows):
     """Per-launch ALGORITHMIC flops of every dense kernel for `rows` samples per agent-tower
     (per agent-tower MACs = n_wave*128 + n_fp*64 + n_wait*32 + H*256 + 64*256 + 64*n_out)."""
@@ -47,7 +59,7 @@ def algorithmic_flops(model, rows):
             'dwo_gemm': out * rows}
 
 
-def cpu_baseline(n_env=2, n_step=120):
+def cpu_baseline(n_env=4, n_step=120, threads=8):
     """Same iteration on the host: oracle/ (test infrastructure) = C microsim + NumPy restatement of
     envs/env.py + torch-CPU restatement of agents/policies.py.  Bounded sample: n_env env instances,
     one iteration (n_step control steps + update)."""
@@ -56,6 +68,7 @@ def cpu_baseline(n_env=2, n_step=120):
     from oracle.env_oracle import OracleEnv
     from oracle.nets_oracle import OracleA2C, choice_from_uniform
     from deeprl_signal_control_amd.agents import ortho_init
+    torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))   # 128 threads on 64-wide matmuls is slower than 8
     scn = build_large_grid('ma2c')
     rng = np.random.RandomState(0)
     nw = [s - w - f for s, w, f in zip(scn.n_s_ls, scn.n_w_ls, scn.n_f_ls)]
@@ -101,9 +114,21 @@ def cpu_baseline(n_env=2, n_step=120):
     model.apply_grads(grads, 5e-4)
     dt = time.perf_counter() - t0
     steps = scn.n_agent * n_env * n_step * scn.control_interval_sec
+    # for scale: the C microsim alone (no env wrapper, no nets), one instance, one core, one full episode
+    from oracle.microsim import MicroSim
+    ms = MicroSim(scn)
+    ms.reset(12)
+    t1 = time.perf_counter()
+    for t in range(0, 3600, 5):
+        for a in range(scn.n_agent):
+            ms.set_links(a, scn.phases[a][(t // 30) % 5])
+        ms.step(5)
+    sim_dt = time.perf_counter() - t1
     return {'value': steps / dt, 'unit': 'env-steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': 'oracle/ (C microsim + NumPy env wrapper + float64 torch-CPU nets): %d env instances x %d control '
-                      'steps + 1 update, %.1f s' % (n_env, n_step, dt)}
+                      'steps + 1 update, %.1f s' % (n_env, n_step, dt),
+            'sim_only_value': scn.n_agent * 3600 / sim_dt,
+            'sim_only_sample': 'oracle/microsim.c alone, 1 instance, 1 core, 3600 simulated seconds, %.2f s' % sim_dt}
 
 
 def main():
@@ -113,6 +138,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--envs', type=int, default=1024, help='env instances per GPU')
     ap.add_argument('--agent', default='ma2c', choices=['ma2c', 'ia2c'])
+    ap.add_argument('--scenario', default='large_grid', choices=['large_grid', 'real_net'])
+    ap.add_argument('--policy', default='lstm', choices=['lstm', 'fc'], help='fc = FcACPolicy (BASELINE configs[1], ia2c only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     args = ap.parse_args()
@@ -131,15 +158,18 @@ def main():
     from deeprl_signal_control_amd import _lib
     from deeprl_signal_control_amd.agents import VecA2C
     from deeprl_signal_control_amd.env import VecTrafficEnv
-    from deeprl_signal_control_amd.scenario import build_large_grid
+    from deeprl_signal_control_amd.scenario import build_scenario
     from deeprl_signal_control_amd.trainer import VecTrainer
 
     E = args.envs
-    scn = build_large_grid(args.agent)
-    mcfg = dict(reward_norm=2000.0 if args.agent == 'ma2c' else 3000.0)
-    env = VecTrafficEnv(scn, E, device=local, seed=12 + rank * E, seed_stride=E * world)
-    model = VecA2C(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, scn.n_f_ls, E, scn.s_max, 5, mcfg, device=local, seed=0,
-                   name=args.agent)
+    scn = build_scenario(args.scenario, args.agent)
+    if args.scenario == 'large_grid':        # config/config_{ma2c,ia2c}_large.ini
+        mcfg, seed0, tseeds = dict(reward_norm=2000.0 if args.agent == 'ma2c' else 3000.0, batch_size=120), 12, (10000, 20000)
+    else:                                    # config/config_{ma2c,ia2c}_real.ini
+        mcfg, seed0, tseeds = dict(reward_norm=1.0, batch_size=40), 42, (10000, 20000, 30000)
+    env = VecTrafficEnv(scn, E, device=local, seed=seed0 + rank * E, seed_stride=E * world, test_seeds=tseeds)
+    model = VecA2C(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, scn.n_f_ls, E, scn.s_max, int(scn.green_tab.shape[1]), mcfg,
+                   device=local, seed=0, name=args.agent, policy=args.policy)
     model.sample_seed = 1000 + rank
     tr = VecTrainer(env, model)
 
@@ -170,14 +200,16 @@ def main():
     if rank == 0:
         n_step, ctrl = model.n_step, scn.control_interval_sec
         env_steps = scn.n_agent * E * world * n_step * ctrl * args.steps
-        out = {'metric': 'env-steps/s (agents x envs x sim-steps/s), large_grid %s' % args.agent.upper(),
+        out = {'metric': 'env-steps/s (agents x envs x sim-steps/s), %s %s' % (args.scenario, args.agent.upper()),
                'value': env_steps / dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
                'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-               'config': {'workload': 'large_grid 5x5 (25 agents), %s LSTM (neighbour fingerprint gather), %d env '
-                                      'instances per GPU; step = %d control steps (x%d sim-steps) of every instance + 1 '
-                                      'A2C update (BPTT, clip, RMSProp%s)'
-                                      % (args.agent.upper(), E, n_step, ctrl, ', RCCL grad all-reduce' if world > 1 else ''),
+               'config': {'workload': '%s (%d agents), %s %s policy%s, %d env instances per GPU; step = %d control steps '
+                                      '(x%d sim-steps) of every instance + 1 A2C update (%sclip, RMSProp%s)'
+                                      % ('large_grid 5x5' if args.scenario == 'large_grid' else 'real_net Monaco', scn.n_agent,
+                                         args.agent.upper(), args.policy.upper(),
+                                         ' (neighbour fingerprint gather)' if args.agent == 'ma2c' else '', E, n_step, ctrl,
+                                         'BPTT, ' if args.policy == 'lstm' else '', ', RCCL grad all-reduce' if world > 1 else ''),
                           'envs_per_gpu': E, 'n_step': n_step, 'agents': scn.n_agent,
                           'parallelism': 'env-sharded x%d' % world, 'mean_live_vehicles_per_env': live[-1],
                           'mean_step_reward': tr.mean_step_reward()}}
@@ -192,7 +224,7 @@ def main():
                 bytes_launch = (32.0 * V + 16.0 * Ln + A * 52.0 / 5.0) * ctrl * E
                 ach = bytes_launch / avg_s / 1e9
                 roof = {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                        'frac': ach / PEAK_HBM_GBS, 'traffic': None}
+                        'frac': ach / PEAK_HBM_GBS, 'traffic': pmc_traffic(dom)}
             else:
                 rows = E * n_step if dom not in ('fc_gemm', 'zx_gemm', 'lstm_fwd') else None
                 fl = algorithmic_flops(model, E * n_step)
@@ -204,7 +236,7 @@ def main():
                 else:
                     ach = fl.get(dom, 0.0) / avg_s / 1e12
                 roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
-                        'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None}
+                        'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(dom)}
             roof['avg_launch_ms'] = ms / cnt
             roof['share_of_kernel_time'] = ms / total
             roof['kernel_time_ms_total'] = total
