@@ -173,6 +173,7 @@ def _setup_lib(L):
     L.tsc_model_reset.argtypes = [vp]
     L.tsc_model_forward.argtypes = [vp, vp, vp, vp, vp, C.c_int32]
     L.tsc_model_sample.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64]
+    L.tsc_model_forward_sample.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64]
     L.tsc_model_add_transition.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp]
     L.tsc_model_compute_grads.argtypes = [vp, vp, C.c_double]
     L.tsc_model_grad_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
@@ -335,6 +336,16 @@ class VecA2C:
         if out_type == 'pv':
             return self.pi, self.v
         return self.pi if out_type == 'p' else v_out
+
+    def forward_sample(self, obs, done):
+        """forward(obs, done, 'pv') + sample() in one launch -> (pi, v, action)."""
+        if not torch.is_tensor(done):
+            done = torch.full((self.E,), int(bool(done)), dtype=torch.uint8, device=self.device)
+        _lib.check(self._L.tsc_model_forward_sample(
+            self._h, C.c_void_p(obs.data_ptr()), C.c_void_p(done.data_ptr()), C.c_void_p(self.pi.data_ptr()),
+            C.c_void_p(self.v.data_ptr()), C.c_void_p(self.action.data_ptr()), self.sample_seed, self.sample_step))
+        self.sample_step += 1
+        return self.pi, self.v, self.action
 
     def sample(self, pi=None):
         """np.random.choice per agent (utils.py:155-157), counter-based RNG."""

@@ -67,6 +67,8 @@ struct EnvDev {
     int *prev_action;              // [E][A]
     float *fp;                     // [E][A][PMAX]
     unsigned long long *arrived;   // [E]
+    double *reward_acc;            // [E] running sum of the global reward (training-curve logging, utils.py:161,296-305)
+    const float *fp_bound;         // zero-copy fingerprint source (tsc_env_bind_fingerprint) or null
     long long *dbg;                // optional: shader-clock stamps of workgroup 0 / thread 0 (tsc_env_debug_clock)
 };
 
@@ -232,7 +234,7 @@ __device__ void emit_obs(const EnvDev &P, const Smem &s, int e, float *obs) {
         if (kind == 1) o = (float)norm_clip((double)s.wave[src], P.norm_wave, P.clip_wave);
         else if (kind == 2) o = (float)(norm_clip((double)s.wave[src], P.norm_wave, P.clip_wave) * P.coop_gamma);
         else if (kind == 3) o = (float)norm_clip((double)s.hwait[src], P.norm_wait, P.clip_wait);
-        else if (kind == 4) o = P.fp[(size_t)e * P.A * P.PMAX + src];
+        else if (kind == 4) o = (P.fp_bound ? P.fp_bound : P.fp)[(size_t)e * P.A * P.PMAX + src];
         obs[(size_t)e * tot + idx] = o;
     }
 }
@@ -560,7 +562,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         s.r[a] = r;
     }
     __syncthreads();
-    if (l == 0) { double g = np_sum(s.r, P.A); s.r[P.A] = g; greward[e] = g; }
+    if (l == 0) { double g = np_sum(s.r, P.A); s.r[P.A] = g; greward[e] = g; P.reward_acc[e] += g; }
     __syncthreads();
     for (int a = l; a < P.A; a += blockDim.x) {
         const double g = s.r[P.A];
@@ -779,6 +781,8 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     ALLOC(prev_action, int, (size_t)n_env * A);
     ALLOC(fp, float, (size_t)n_env * A * P.PMAX);
     ALLOC(arrived, unsigned long long, n_env);
+    ALLOC(reward_acc, double, n_env);
+    P.fp_bound = nullptr;
     P.dbg = nullptr;
     TSC_HIP(hipMalloc((void **)&h->d_seeds, sizeof(uint32_t) * n_env));
     h->allocs.push_back(h->d_seeds);
@@ -807,6 +811,7 @@ int tsc_env_set_stream(tsc_env *h, void *hip_stream) {
 
 int tsc_env_reset(tsc_env *h, const uint32_t *seeds_host, float *obs_dev) {
     if (!h || !seeds_host || !obs_dev) return tsc::fail("tsc_env_reset: bad arguments");
+    h->P.fp_bound = nullptr;                     // reset(): fingerprints <- uniform policy (envs/env.py:556-557)
     TSC_HIP(hipMemcpyAsync(h->d_seeds, seeds_host, sizeof(uint32_t) * h->P.E, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(reset_kernel, dim3(h->P.E), dim3(h->P.NLP), h->smem, h->stream, h->P, h->d_seeds, obs_dev);
     TSC_HIP(hipGetLastError());
@@ -814,8 +819,27 @@ int tsc_env_reset(tsc_env *h, const uint32_t *seeds_host, float *obs_dev) {
     return 0;
 }
 
+int tsc_env_bind_fingerprint(tsc_env *h, const float *pi_dev) {
+    if (!h) return tsc::fail("null handle");
+    h->P.fp_bound = pi_dev;                      // null: back to the copied fingerprints
+    return 0;
+}
+
+int tsc_env_reward_sum(tsc_env *h, double *sum_host, int32_t reset) {
+    if (!h || !sum_host) return tsc::fail("tsc_env_reward_sum: bad arguments");
+    TSC_HIP(hipStreamSynchronize(h->stream));
+    std::vector<double> acc(h->P.E);
+    TSC_HIP(hipMemcpy(acc.data(), h->P.reward_acc, sizeof(double) * h->P.E, hipMemcpyDeviceToHost));
+    double t = 0;
+    for (double v : acc) t += v;
+    *sum_host = t;
+    if (reset) TSC_HIP(hipMemset(h->P.reward_acc, 0, sizeof(double) * h->P.E));
+    return 0;
+}
+
 int tsc_env_set_fingerprint(tsc_env *h, const float *pi_dev) {
     if (!h || !pi_dev) return tsc::fail("tsc_env_set_fingerprint: bad arguments");
+    h->P.fp_bound = nullptr;
     size_t tot = (size_t)h->P.E * h->P.A * h->P.PMAX;
     tsc::ProfScope ps(tsc::KID_FINGERPRINT, h->stream);
     hipLaunchKernelGGL(fingerprint_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->P, pi_dev);

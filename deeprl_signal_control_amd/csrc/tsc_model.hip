@@ -424,6 +424,24 @@ __global__ void __launch_bounds__(64) head_bwd_kernel(const float *__restrict__ 
     }
 }
 
+// np.random.choice(n, p=pi): cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, u, 'right')
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ int sample_action(const float *pi, int na, unsigned long long seed, unsigned long long step, long long idx) {
+    const unsigned long long h = splitmix64(splitmix64(seed ^ (step * 0xD1B54A32D192ED03ull)) + (unsigned long long)idx);
+    const double u = (double)(h >> 11) * (1.0 / 9007199254740992.0);
+    double cdf[kOut], sacc = 0.0;
+    for (int k = 0; k < na; ++k) { sacc += (double)pi[k]; cdf[k] = sacc; }
+    int ans = na - 1;
+    for (int k = 0; k < na; ++k)
+        if (u < cdf[k] / sacc) { ans = k; break; }
+    return ans;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fused rollout forward (one control step, IA2C.forward agents/models.py:185-200): for one agent-tower
 // and a tile of 64 env instances, in ONE launch:
@@ -439,7 +457,8 @@ constexpr int kXLd = 68;
 __global__ void __launch_bounds__(256, 2)
 policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int *__restrict__ n_act,
                         const float *__restrict__ obs, const uint8_t *__restrict__ done, float *state, int advance,
-                        int E, int n_tiles, float *__restrict__ pi_out, float *__restrict__ v_out, long long *dbg) {
+                        int E, int n_tiles, float *__restrict__ pi_out, float *__restrict__ v_out, int *action_out,
+                        unsigned long long seed, unsigned long long step, long long *dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float *XH = (float *)smem_raw;
     const bool stamp = dbg && blockIdx.x == 8 && threadIdx.x == 0;      // a block that does real work
@@ -603,7 +622,11 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
             float pk[kOut], sum = 0.f;
 #pragma unroll
             for (int k = 0; k < kOut; ++k) { pk[k] = k < na ? expf(lg[k] - mx) : 0.f; sum += pk[k]; }
-            for (int k = 0; k < lay.AMAX; ++k) pi_out[idx * lay.AMAX + k] = k < kOut ? pk[k] / sum : 0.f;
+            float pn[kOut];
+#pragma unroll
+            for (int k = 0; k < kOut; ++k) pn[k] = pk[k] / sum;
+            for (int k = 0; k < lay.AMAX; ++k) pi_out[idx * lay.AMAX + k] = k < kOut ? pn[k] : 0.f;
+            if (action_out) action_out[idx] = sample_action(pn, na, seed, step, idx);   // utils.py:155-157
         } else {
             v_out[idx] = lg[0];
         }
@@ -647,25 +670,12 @@ __global__ void add_transition_kernel(int E, int A, int SMAX, const float *obs, 
     if (i < E) { done_t[i] = done_pre[i]; done_t1[i] = done_post[i]; }
 }
 
-// np.random.choice(n, p=pi): cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, u, 'right')
-__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
 __global__ void sample_kernel(const float *pi, const int *n_act, int E, int A, int AMAX, unsigned long long seed,
                               unsigned long long step, int *action) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= E * A) return;
     const int a = idx % A, na = n_act[a];
-    const unsigned long long h = splitmix64(splitmix64(seed ^ (step * 0xD1B54A32D192ED03ull)) + (unsigned long long)idx);
-    const double u = (double)(h >> 11) * (1.0 / 9007199254740992.0);
-    double cdf[kOut], s = 0.0;
-    for (int k = 0; k < na; ++k) { s += (double)pi[(long long)idx * AMAX + k]; cdf[k] = s; }
-    int ans = na - 1;
-    for (int k = 0; k < na; ++k)
-        if (u < cdf[k] / s) { ans = k; break; }
+    const int ans = sample_action(pi + (long long)idx * AMAX, na, seed, step, idx);
     action[idx] = ans;
 }
 
@@ -907,7 +917,8 @@ int tsc_model_reset(tsc_model *m) {
     return 0;
 }
 
-int tsc_model_forward(tsc_model *m, const float *obs, const uint8_t *done, float *pi, float *v, int32_t advance) {
+static int model_forward(tsc_model *m, const float *obs, const uint8_t *done, float *pi, float *v, int32_t advance,
+                         int32_t *action, uint64_t seed, uint64_t step) {
     if (!m || !obs || !done || !pi || !v) return tsc::fail("tsc_model_forward: bad arguments");
     const Layout &L = m->lay;
     const int E = m->E;
@@ -915,7 +926,8 @@ int tsc_model_forward(tsc_model *m, const float *obs, const uint8_t *done, float
         const int n_tiles = (E + 63) / 64, per_xcd = (L.G + 7) / 8;
         tsc::ProfScope ps(tsc::KID_FUSED_FWD, m->stream);
         hipLaunchKernelGGL(policy_fwd_fused_kernel, dim3(8 * per_xcd * n_tiles), dim3(256), m->lds_fused, m->stream, m->params,
-                           L, m->n_act, obs, done, m->state_fw, (int)advance, E, n_tiles, pi, v, m->dbg);
+                           L, m->n_act, obs, done, m->state_fw, (int)advance, E, n_tiles, pi, v, action,
+                           (unsigned long long)seed, (unsigned long long)step, m->dbg);
         ps.stop();
         TSC_HIP(hipGetLastError());
         return 0;
@@ -928,7 +940,7 @@ int tsc_model_forward(tsc_model *m, const float *obs, const uint8_t *done, float
                            m->n_act, m->Hh, E, pi, v);
         psh.stop();
         TSC_HIP(hipGetLastError());
-        return 0;
+        return action ? tsc_model_sample(m, pi, action, seed, step) : 0;
     }
     tsc::ProfScope ps1(tsc::KID_LSTM_FWD, m->stream);
     hipLaunchKernelGGL(lstm_fwd_kernel<false>, dim3(L.G, (E + 63) / 64), dim3(256), m->lds_fwd, m->stream, m->params, L, m->Z,
@@ -939,7 +951,17 @@ int tsc_model_forward(tsc_model *m, const float *obs, const uint8_t *done, float
                        m->n_act, m->Hh, E, pi, v);
     ps3.stop();
     TSC_HIP(hipGetLastError());
-    return 0;
+    return action ? tsc_model_sample(m, pi, action, seed, step) : 0;
+}
+
+int tsc_model_forward(tsc_model *m, const float *obs, const uint8_t *done, float *pi, float *v, int32_t advance) {
+    return model_forward(m, obs, done, pi, v, advance, nullptr, 0, 0);
+}
+
+int tsc_model_forward_sample(tsc_model *m, const float *obs, const uint8_t *done, float *pi, float *v, int32_t *action,
+                             uint64_t seed, uint64_t step) {
+    if (!action) return tsc::fail("tsc_model_forward_sample: bad arguments");
+    return model_forward(m, obs, done, pi, v, 1, action, seed, step);
 }
 
 int tsc_model_sample(tsc_model *m, const float *pi, int32_t *action, uint64_t seed, uint64_t step) {

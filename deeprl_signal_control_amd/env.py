@@ -99,10 +99,18 @@ class VecTrafficEnv:
         self.cur_episode += 1
         return self.obs
 
-    def update_fingerprint(self, pi):
-        """envs/env.py:633-635; pi float32 [E, A, AMAX] on the device."""
+    def update_fingerprint(self, pi, zero_copy=False):
+        """envs/env.py:633-635; pi float32 [E, A, AMAX] on the device.  zero_copy=True lets the env read
+        `pi` in place at the next step() (the caller must not overwrite it before that)."""
         assert pi.dtype == torch.float32 and pi.is_contiguous() and tuple(pi.shape) == (self.E, self.A, self.AMAX)
-        _lib.check(self._L.tsc_env_set_fingerprint(self._h, C.c_void_p(pi.data_ptr())))
+        fn = self._L.tsc_env_bind_fingerprint if zero_copy else self._L.tsc_env_set_fingerprint
+        _lib.check(fn(self._h, C.c_void_p(pi.data_ptr())))
+
+    def reward_sum(self, reset=False):
+        """Sum of the global reward over instances and control steps since the accumulator was reset."""
+        v = C.c_double()
+        _lib.check(self._L.tsc_env_reward_sum(self._h, C.byref(v), int(reset)))
+        return v.value
 
     def step(self, action):
         """envs/env.py:566-631; action int32 [E, A] on the device.  Returns the env's own

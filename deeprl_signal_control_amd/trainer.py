@@ -43,7 +43,6 @@ class VecTrainer:
         self.ob = None
         self.done = True
         self.episode_step = 0
-        self.reward_sum = torch.zeros((), dtype=torch.float64, device=env.device)
         self.zero_R = torch.zeros(env.E, env.A, dtype=torch.float32, device=env.device)
 
     def start_episode(self):
@@ -59,12 +58,11 @@ class VecTrainer:
         ob, done = self.ob, self.done
         finished = False
         for _ in range(self.n_step):
-            pi, v = model.forward(ob, done, 'pv')
+            pi, v, action = model.forward_sample(ob, done)      # forward + np.random.choice (utils.py:148-157)
             if self.agent == 'ma2c':
-                env.update_fingerprint(pi)                       # before step (utils.py:149-151)
-            action = model.sample(pi)
+                env.update_fingerprint(pi, zero_copy=True)       # before step (utils.py:149-151); pi is not
+                                                                 # touched again until the next forward
             next_ob, reward, done_post, global_reward = env.step(action)
-            self.reward_sum += global_reward.sum()
             self.global_counter.next()
             self.episode_step += 1
             model.add_transition(ob, done, action, reward, v, done_post)
@@ -98,7 +96,7 @@ class VecTrainer:
 
     def mean_step_reward(self):
         steps = max(1, self.global_counter.cur_step)
-        return float(self.reward_sum.item()) / (steps * self.env.E)
+        return self.env.reward_sum() / (steps * self.env.E)
 
 
 def greedy_actions_large_grid(obs):

@@ -97,6 +97,16 @@ int tsc_env_reset(tsc_env *h, const uint32_t *seeds_host, float *obs_dev);
  * entries k >= n_a - 1 are ignored. */
 int tsc_env_set_fingerprint(tsc_env *h, const float *pi_dev);
 
+/* Zero-copy variant of update_fingerprint: the env gathers fingerprints straight from the caller's policy
+ * buffer (dev float32 [E, A, AMAX]) at the next step(), which is when the reference reads them; the buffer
+ * must stay untouched until then (true for Trainer.explore, utils.py:148-160).  reset() and
+ * tsc_env_set_fingerprint() unbind. */
+int tsc_env_bind_fingerprint(tsc_env *h, const float *pi_dev);
+
+/* Sum over instances and control steps of the global reward since the last reset of the accumulator
+ * (what Trainer logs per episode, utils.py:161,296-305).  Synchronises. */
+int tsc_env_reward_sum(tsc_env *h, double *sum_host, int32_t reset);
+
 /* step(action), envs/env.py:566-631: yellow FSM -> 2 sim-steps -> green -> 3 sim-steps
  * -> detectors -> obs -> reward -> shaping.  action: dev int32 [E, A];
  * obs: dev float32 [E, A, SMAX]; reward: dev float64 [E, A]; global_reward: dev float64 [E];
@@ -160,6 +170,10 @@ int tsc_model_reset(tsc_model *m);
  * advance = 0 <=> out_type 'v' (bootstrap value, state untouched, policies.py:127-135). */
 int tsc_model_forward(tsc_model *m, const float *obs_dev, const uint8_t *done_dev, float *pi_dev,
                       float *v_dev, int32_t advance);
+
+/* forward(out_type='pv') + tsc_model_sample in one call (the action is drawn inside the fused forward). */
+int tsc_model_forward_sample(tsc_model *m, const float *obs_dev, const uint8_t *done_dev, float *pi_dev,
+                             float *v_dev, int32_t *action_dev, uint64_t seed, uint64_t step);
 
 /* np.random.choice(n_a, p=pi) per agent (utils.py:155-157) with a counter-based generator:
  * u = U(seed, step, e, a); action = searchsorted(cumsum(pi)/sum, u, right). action: dev i32 [E,A]. */

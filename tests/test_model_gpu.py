@@ -237,3 +237,17 @@ def test_returns_match_reference_buffer_on_gpu(golden_dir):
             np.testing.assert_allclose(Rs[:, 0, 7], g[c + '_Rs'], rtol=1e-6)
             np.testing.assert_allclose(Advs[:, 0, 7], g[c + '_Advs'], rtol=1e-5, atol=1e-6)
         m.close()
+
+
+def test_forward_sample_equals_forward_then_sample():
+    scn, m, o = _make('ma2c', 40, 4, seed=3)
+    rng = np.random.RandomState(9)
+    obs = torch.from_numpy(_rand_obs(scn, 40, rng)).cuda()
+    m.reset()
+    pi, v, act = m.forward_sample(obs, True)
+    pi, v, act = pi.clone(), v.clone(), act.clone()
+    m.reset(); m.sample_step -= 1
+    pi2, v2 = m.forward(obs, True, 'pv')
+    act2 = m.sample(pi2)
+    assert torch.equal(pi, pi2) and torch.equal(v, v2) and torch.equal(act, act2)
+    m.close()
