@@ -173,7 +173,7 @@ def _setup_lib(L):
     L.tsc_model_reset.argtypes = [vp]
     L.tsc_model_forward.argtypes = [vp, vp, vp, vp, vp, C.c_int32]
     L.tsc_model_sample.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64]
-    L.tsc_model_forward_sample.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64]
+    L.tsc_model_forward_sample.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_int32]
     L.tsc_model_add_transition.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp]
     L.tsc_model_compute_grads.argtypes = [vp, vp, C.c_double]
     L.tsc_model_grad_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
@@ -337,13 +337,15 @@ class VecA2C:
             return self.pi, self.v
         return self.pi if out_type == 'p' else v_out
 
-    def forward_sample(self, obs, done):
-        """forward(obs, done, 'pv') + sample() in one launch -> (pi, v, action)."""
+    def forward_sample(self, obs, done, cache=True):
+        """forward(obs, done, 'pv') + sample() in one launch -> (pi, v, action).  cache=True keeps this step's
+        activations (slot = the transition add_transition fills next) so backward() skips the re-forward."""
         if not torch.is_tensor(done):
             done = torch.full((self.E,), int(bool(done)), dtype=torch.uint8, device=self.device)
         _lib.check(self._L.tsc_model_forward_sample(
             self._h, C.c_void_p(obs.data_ptr()), C.c_void_p(done.data_ptr()), C.c_void_p(self.pi.data_ptr()),
-            C.c_void_p(self.v.data_ptr()), C.c_void_p(self.action.data_ptr()), self.sample_seed, self.sample_step))
+            C.c_void_p(self.v.data_ptr()), C.c_void_p(self.action.data_ptr()), self.sample_seed, self.sample_step,
+            self.cur_t if cache else -1))
         self.sample_step += 1
         return self.pi, self.v, self.action
 

@@ -458,7 +458,9 @@ __global__ void __launch_bounds__(256, 2)
 policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int *__restrict__ n_act,
                         const float *__restrict__ obs, const uint8_t *__restrict__ done, float *state, int advance,
                         int E, int n_tiles, float *__restrict__ pi_out, float *__restrict__ v_out, int *action_out,
-                        unsigned long long seed, unsigned long long step, long long *dbg) {
+                        unsigned long long seed, unsigned long long step, long long *dbg,
+                        // activation cache for the update (slot tslot of the n_step batch; tslot < 0: off)
+                        int tslot, long long Ntot, float *X1c, float *Zc, float *Hhc, float *Ccc, float *Hpc) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float *XH = (float *)smem_raw;
     const bool stamp = dbg && blockIdx.x == 8 && threadIdx.x == 0;      // a block that does real work
@@ -528,9 +530,15 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const float v0 = acc0[r] + bias, v1 = acc1[r] + bias;
-                XH[col * kXLd + row] = v0 > 0.f ? v0 : 0.f;
-                XH[col * kXLd + 32 + row] = v1 > 0.f ? v1 : 0.f;
+                float v0 = acc0[r] + bias, v1 = acc1[r] + bias;
+                v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f;
+                XH[col * kXLd + row] = v0;
+                XH[col * kXLd + 32 + row] = v1;
+                if (tslot >= 0) {                                  // X1 of this step, in the training layout [g][n][H]
+                    const long long nb = (long long)g * Ntot + (long long)tslot * E + e0;
+                    if (e0 + row < E) X1c[(nb + row) * H + col] = v0;
+                    if (e0 + 32 + row < E) X1c[(nb + 32 + row) * H + col] = v1;
+                }
             }
         }
     }
@@ -538,7 +546,11 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
     FSTAMP();
     // ---- phase 1.5: h (loaded at kernel entry, done-masked) -> LDS rows [H, H+64)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Hs[j * kXLd + erow[r]] = h0v[r];
+    for (int r = 0; r < 16; ++r) {
+        Hs[j * kXLd + erow[r]] = h0v[r];
+        if (tslot >= 0 && e0 + erow[r] < E)              // masked h_{t-1}: the operand of dWh in the update
+            Hpc[((long long)g * Ntot + (long long)tslot * E + e0 + erow[r]) * kL + j] = h0v[r];
+    }
     __syncthreads();
     FSTAMP();
     // ---- phase 2: gates = bl + [X1 | h] [Wx ; Wh]   (K = H + 64)
@@ -592,6 +604,11 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
         if (advance && e < E) {
             float *st = state + ((long long)g * E + e) * 2 * kL;
             st[j] = cn; st[kL + j] = hn;
+        }
+        if (tslot >= 0 && e < E) {                                 // what lstm_fwd_kernel<true> would store
+            const long long n = (long long)g * Ntot + (long long)tslot * E + e;
+            Zc[n * kG4 + j] = ig; Zc[n * kG4 + 64 + j] = fg; Zc[n * kG4 + 128 + j] = og; Zc[n * kG4 + 192 + j] = ug;
+            Ccc[n * kL + j] = cn; Hhc[n * kL + j] = hn;
         }
         XH[j * kXLd + erow[r]] = hn;
     }
@@ -748,6 +765,7 @@ struct tsc_model {
     size_t ws_floats, wsc_floats;
     size_t lds_fwd, lds_bwd, lds_fused;
     int fused_fwd;
+    int cached_next;            // next rollout slot whose activations the fused forward will cache; T = all cached
     long long *dbg;
     long long nparam;
 };
@@ -849,6 +867,7 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fwd));
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bwd));
     m->dbg = nullptr;
+    m->cached_next = 0;
     m->lds_fused = sizeof(float) * (size_t)(L.H + 64) * kXLd;
     m->fused_fwd = !L.fc && (L.H % 32 == 0) && (L.SMAX <= 64) && (L.SMAX % 4 == 0) && ((L.H + 64) % 16 == 0) && m->lds_fused <= 160 * 1024;
     if (const char *ev = getenv("TSC_UNFUSED_FWD")) if (atoi(ev)) m->fused_fwd = 0;
@@ -884,6 +903,7 @@ int tsc_model_layout(tsc_model *m, int64_t out[12]) {
 
 int tsc_model_set_params(tsc_model *m, const float *h) {
     if (!m || !h) return tsc::fail("tsc_model_set_params: bad arguments");
+    m->cached_next = -1;                              // activations cached under the old parameters are stale
     TSC_HIP(hipStreamSynchronize(m->stream));
     TSC_HIP(hipMemcpy(m->params, h, sizeof(float) * m->nparam, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((m->nparam + 255) / 256)), dim3(256), 0, m->stream, m->ms, m->nparam, 1.0f);
@@ -918,16 +938,24 @@ int tsc_model_reset(tsc_model *m) {
 }
 
 static int model_forward(tsc_model *m, const float *obs, const uint8_t *done, float *pi, float *v, int32_t advance,
-                         int32_t *action, uint64_t seed, uint64_t step) {
+                         int32_t *action, uint64_t seed, uint64_t step, int32_t tslot) {
     if (!m || !obs || !done || !pi || !v) return tsc::fail("tsc_model_forward: bad arguments");
     const Layout &L = m->lay;
     const int E = m->E;
+    // activation cache: valid only if slots 0..T-1 are filled in order by advancing forwards
+    if (advance) {
+        if (m->fused_fwd && tslot >= 0 && tslot == m->cached_next && tslot < m->T) m->cached_next = tslot + 1;
+        else { m->cached_next = -1; tslot = -1; }
+    } else {
+        tslot = -1;
+    }
     if (m->fused_fwd) {
         const int n_tiles = (E + 63) / 64, per_xcd = (L.G + 7) / 8;
         tsc::ProfScope ps(tsc::KID_FUSED_FWD, m->stream);
         hipLaunchKernelGGL(policy_fwd_fused_kernel, dim3(8 * per_xcd * n_tiles), dim3(256), m->lds_fused, m->stream, m->params,
                            L, m->n_act, obs, done, m->state_fw, (int)advance, E, n_tiles, pi, v, action,
-                           (unsigned long long)seed, (unsigned long long)step, m->dbg);
+                           (unsigned long long)seed, (unsigned long long)step, m->dbg, (int)tslot, (long long)m->T * E,
+                           m->X1, m->Z, m->Hh, m->Cc, m->Hp);
         ps.stop();
         TSC_HIP(hipGetLastError());
         return 0;
@@ -955,13 +983,13 @@ static int model_forward(tsc_model *m, const float *obs, const uint8_t *done, fl
 }
 
 int tsc_model_forward(tsc_model *m, const float *obs, const uint8_t *done, float *pi, float *v, int32_t advance) {
-    return model_forward(m, obs, done, pi, v, advance, nullptr, 0, 0);
+    return model_forward(m, obs, done, pi, v, advance, nullptr, 0, 0, -1);
 }
 
 int tsc_model_forward_sample(tsc_model *m, const float *obs, const uint8_t *done, float *pi, float *v, int32_t *action,
-                             uint64_t seed, uint64_t step) {
+                             uint64_t seed, uint64_t step, int32_t t_slot) {
     if (!action) return tsc::fail("tsc_model_forward_sample: bad arguments");
-    return model_forward(m, obs, done, pi, v, 1, action, seed, step);
+    return model_forward(m, obs, done, pi, v, 1, action, seed, step, t_slot);
 }
 
 int tsc_model_sample(tsc_model *m, const float *pi, int32_t *action, uint64_t seed, uint64_t step) {
@@ -1020,12 +1048,16 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
         if (gemm(m, tsc::KID_DX1_GEMM, false, tsc::EPI_MASK_POS, (int)G, (int)N, L.H, kL, m->dHh, N * kL, kL, 1, m->WxT, (long long)L.H * kL, L.H,
                  m->X1, N * L.H, L.H, nullptr, 0, m->X1, N * L.H, L.H, nullptr, 0, nullptr, 0)) return tsc::fail("gemm failed");
     } else {
-    // forward with stored activations, from the backward state (agents/policies.py:144-152)
-    if (dense_forward(m, m->r_obs, N, m->X1, m->Z)) return tsc::fail("gemm launch failed");
-    tsc::ProfScope ps2(tsc::KID_LSTM_FWD, m->stream);
-    hipLaunchKernelGGL(lstm_fwd_kernel<true>, dim3((unsigned)G, (unsigned)((E + 63) / 64)), dim3(256), m->lds_fwd, st, m->params, L,
-                       m->Z, m->state_bw, (float *)nullptr, m->Hh, m->Cc, m->Hp, m->r_done, (int)T, (int)E, 1);
-    ps2.stop();
+    // forward with stored activations, from the backward state (agents/policies.py:144-152).  The rollout
+    // ran with these very parameters from this very state, so when the fused forward cached all n_step
+    // slots (X1, gates, c, h, masked h_prev) the graph does not have to be evaluated a second time.
+    if (m->cached_next != (int)T) {
+        if (dense_forward(m, m->r_obs, N, m->X1, m->Z)) return tsc::fail("gemm launch failed");
+        tsc::ProfScope ps2(tsc::KID_LSTM_FWD, m->stream);
+        hipLaunchKernelGGL(lstm_fwd_kernel<true>, dim3((unsigned)G, (unsigned)((E + 63) / 64)), dim3(256), m->lds_fwd, st, m->params, L,
+                           m->Z, m->state_bw, (float *)nullptr, m->Hh, m->Cc, m->Hp, m->r_done, (int)T, (int)E, 1);
+        ps2.stop();
+    }
     tsc::ProfScope ps7(tsc::KID_HEAD_BWD, m->stream);
     hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)A), dim3(64), 0, st, m->params, L, m->n_act,
                        m->Hh, m->r_act, m->Rs, m->Advs, N, (float)m->vcoef, (float)beta, m->dL, m->dHh, m->stats);
@@ -1052,6 +1084,7 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
     // dW1 = obs^T dX1 masked to the block-diagonal structure (+ db1)
     if (gemm(m, tsc::KID_DW1_GEMM, true, tsc::EPI_ROWRANGE, (int)G, L.SMAX, L.H, (int)N, m->r_obs, L.SMAX, AS, 2, m->X1, N * L.H, L.H, g + L.oW1,
              L.stride, L.H, nullptr, 0, nullptr, 0, 0, m->rowrange, L.SMAX, g + L.ob1, L.stride)) return tsc::fail("gemm failed");
+    m->cached_next = 0;                               // the update consumes the cache
     TSC_HIP(hipGetLastError());
     return 0;
 }

@@ -171,9 +171,13 @@ int tsc_model_reset(tsc_model *m);
 int tsc_model_forward(tsc_model *m, const float *obs_dev, const uint8_t *done_dev, float *pi_dev,
                       float *v_dev, int32_t advance);
 
-/* forward(out_type='pv') + tsc_model_sample in one call (the action is drawn inside the fused forward). */
+/* forward(out_type='pv') + tsc_model_sample in one call (the action is drawn inside the fused forward).
+ * t_slot = index of the transition this forward belongs to (0 .. n_step-1, the slot the following
+ * tsc_model_add_transition fills) lets the kernel keep the step's activations for the update, so that
+ * tsc_model_compute_grads need not re-evaluate the forward graph (agents/policies.py:94-96 builds it twice);
+ * t_slot = -1 disables that.  The cache is used only if all n_step slots were filled in order. */
 int tsc_model_forward_sample(tsc_model *m, const float *obs_dev, const uint8_t *done_dev, float *pi_dev,
-                             float *v_dev, int32_t *action_dev, uint64_t seed, uint64_t step);
+                             float *v_dev, int32_t *action_dev, uint64_t seed, uint64_t step, int32_t t_slot);
 
 /* np.random.choice(n_a, p=pi) per agent (utils.py:155-157) with a counter-based generator:
  * u = U(seed, step, e, a); action = searchsorted(cumsum(pi)/sum, u, right). action: dev i32 [E,A]. */

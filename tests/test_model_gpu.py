@@ -149,11 +149,14 @@ def test_sampling_is_numpy_choice_on_documented_uniform():
     m.close()
 
 
-def _fill(scn, m, o, E, T, rng, p_done=0.1, terminal=False):
+def _fill(scn, m, o, E, T, rng, p_done=0.1, terminal=False, use_cache=False):
     obs = _rand_obs(scn, E, rng)
     done = np.ones(E, np.uint8)
     for t in range(T):
-        pi, v = m.forward(torch.from_numpy(obs).cuda(), torch.from_numpy(done).cuda(), 'pv')
+        if use_cache:      # the trainer's path: fused forward + sampling, activations cached for the update
+            pi, v, _ = m.forward_sample(torch.from_numpy(obs).cuda(), torch.from_numpy(done).cuda())
+        else:
+            pi, v = m.forward(torch.from_numpy(obs).cuda(), torch.from_numpy(done).cuda(), 'pv')
         v = v.cpu().numpy()
         o.forward(obs, done, 'pv')
         act = rng.randint(0, 5, (E, scn.n_agent)).astype(np.int32)
@@ -168,15 +171,16 @@ def _fill(scn, m, o, E, T, rng, p_done=0.1, terminal=False):
     return obs, done
 
 
-@pytest.mark.parametrize('agent,E,T,terminal,policy', [('ma2c', 3, 6, False, 'lstm'), ('ma2c', 66, 8, True, 'lstm'),
-                                                        ('ia2c', 4, 40, False, 'lstm'), ('ia2c', 37, 12, True, 'fc')])
-def test_backward_matches_oracle(agent, E, T, terminal, policy):
+@pytest.mark.parametrize('agent,E,T,terminal,policy,use_cache', [
+    ('ma2c', 3, 6, False, 'lstm', False), ('ma2c', 66, 8, True, 'lstm', False), ('ia2c', 4, 40, False, 'lstm', False),
+    ('ia2c', 37, 12, True, 'fc', False), ('ma2c', 70, 7, True, 'lstm', True), ('ia2c', 5, 30, False, 'lstm', True)])
+def test_backward_matches_oracle(agent, E, T, terminal, policy, use_cache):
     scn, m, o = _make(agent, E, T, seed=5, policy=policy)
     rng = np.random.RandomState(E * T)
     m.reset(); o.reset()
     from deeprl_signal_control_amd import _lib
     for it in range(2):                                       # second round exercises states_bw / carried done
-        obs, done = _fill(scn, m, o, E, T, rng, terminal=terminal and it == 0)
+        obs, done = _fill(scn, m, o, E, T, rng, terminal=terminal and it == 0, use_cache=use_cache)
         Rb = m.forward(torch.from_numpy(obs).cuda(), False, 'v').clone()
         _, oRb = o.forward(obs, np.zeros(E), 'v')
         Rb_np = Rb.cpu().numpy()
