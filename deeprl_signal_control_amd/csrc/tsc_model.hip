@@ -527,6 +527,8 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
                 }
             }
             const float bias = b1[col];
+            int eb1 = e0;
+            asm volatile("" : "+v"(eb1));                   // form the store addresses here, not at kernel entry
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
@@ -535,9 +537,9 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
                 XH[col * kXLd + row] = v0;
                 XH[col * kXLd + 32 + row] = v1;
                 if (tslot >= 0) {                                  // X1 of this step, in the training layout [g][n][H]
-                    const long long nb = (long long)g * Ntot + (long long)tslot * E + e0;
-                    if (e0 + row < E) X1c[(nb + row) * H + col] = v0;
-                    if (e0 + 32 + row < E) X1c[(nb + 32 + row) * H + col] = v1;
+                    const long long nb = (long long)g * Ntot + (long long)tslot * E + eb1;
+                    if (eb1 + row < E) X1c[(nb + row) * H + col] = v0;
+                    if (eb1 + 32 + row < E) X1c[(nb + 32 + row) * H + col] = v1;
                 }
             }
         }
@@ -545,11 +547,13 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
     __syncthreads();
     FSTAMP();
     // ---- phase 1.5: h (loaded at kernel entry, done-masked) -> LDS rows [H, H+64)
+    int eb15 = e0;
+    asm volatile("" : "+v"(eb15));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         Hs[j * kXLd + erow[r]] = h0v[r];
-        if (tslot >= 0 && e0 + erow[r] < E)              // masked h_{t-1}: the operand of dWh in the update
-            Hpc[((long long)g * Ntot + (long long)tslot * E + e0 + erow[r]) * kL + j] = h0v[r];
+        if (tslot >= 0 && eb15 + erow[r] < E)            // masked h_{t-1}: the operand of dWh in the update
+            Hpc[((long long)g * Ntot + (long long)tslot * E + eb15 + erow[r]) * kL + j] = h0v[r];
     }
     __syncthreads();
     FSTAMP();
@@ -564,19 +568,20 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
             for (int r = 0; r < 16; ++r) acc[q][r] = bv;
         }
         const float *B = P + lay.oWx;                  // [H + 64][256] (Wx then Wh)
-        const int nchunk = (H + 64) >> 4;              // 16 k rows per chunk
-        float bA[8][4], bB[8][4];
+        constexpr int CS = 8;                          // k-steps (2 k rows each) per register chunk
+        const int nchunk = (H + 64) / (2 * CS);
+        float bA[CS][4], bB[CS][4];
         auto loadB = [&](float (*dst)[4], int chunk) {
-            const float *src = B + (long long)(chunk * 16 + kh) * kG4 + j;
+            const float *src = B + (long long)(chunk * 2 * CS + kh) * kG4 + j;
 #pragma unroll
-            for (int s2 = 0; s2 < 8; ++s2)
+            for (int s2 = 0; s2 < CS; ++s2)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) dst[s2][q] = src[(long long)(2 * s2) * kG4 + 64 * q];
         };
         auto compute = [&](float (*bv)[4], int chunk) {
-            const float *As = XH + (chunk * 16 + kh) * kXLd + r0 + li;
+            const float *As = XH + (chunk * 2 * CS + kh) * kXLd + r0 + li;
 #pragma unroll
-            for (int s2 = 0; s2 < 8; ++s2) {
+            for (int s2 = 0; s2 < CS; ++s2) {
                 const float av = As[(2 * s2) * kXLd];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s2][q], acc[q], 0, 0, 0);
@@ -594,9 +599,13 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
     __syncthreads();                                   // everyone is done reading XH
     FSTAMP();
     // ---- phase 3: cell update, state write-back, h -> LDS rows [0, 64)
+    // (the row offset goes through an opaque register so that the ~100 store addresses of this phase are formed
+    //  here and not hoisted to kernel entry, where they cost 200 B/lane of scratch spills)
+    int row_base = e0;
+    asm volatile("" : "+v"(row_base));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int e = e0 + erow[r];
+        const int e = row_base + erow[r];
         const float ig = sigmoidf_(acc[0][r]), fg = sigmoidf_(acc[1][r]);
         const float og = sigmoidf_(acc[2][r]), ug = tanhf_(acc[3][r]);
         const float cn = fg * c[r] + ig * ug;
@@ -869,7 +878,7 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     m->dbg = nullptr;
     m->cached_next = 0;
     m->lds_fused = sizeof(float) * (size_t)(L.H + 64) * kXLd;
-    m->fused_fwd = !L.fc && (L.H % 32 == 0) && (L.SMAX <= 64) && (L.SMAX % 4 == 0) && ((L.H + 64) % 16 == 0) && m->lds_fused <= 160 * 1024;
+    m->fused_fwd = !L.fc && (L.H % 32 == 0) && (L.SMAX <= 64) && (L.SMAX % 4 == 0) && ((L.H + 64) % 8 == 0) && m->lds_fused <= 160 * 1024;
     if (const char *ev = getenv("TSC_UNFUSED_FWD")) if (atoi(ev)) m->fused_fwd = 0;
     if (m->fused_fwd)
         TSC_HIP(hipFuncSetAttribute((const void *)policy_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fused));
