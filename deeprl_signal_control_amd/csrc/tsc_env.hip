@@ -105,46 +105,6 @@ __device__ __forceinline__ float follow(float v, float v0, bool has_lead, float 
     return vn;
 }
 
-// Both car-following candidates of one vehicle at once: against its leader (or free road) and against
-// the stop line.  Same operations in the same order as two follow() calls (the free-road term is shared,
-// it is the same value), but branch-free so the div / sqrt chains of the two candidates overlap.
-__device__ __forceinline__ void follow2(float v, float v0, bool has_lead, float g, float vl, float gline,
-                                        float &vn_lead, float &vn_line) {
-    const float ratio = v / v0;
-    const float r2 = ratio * ratio;
-    const float afree = kAcc * (1.0f - r2 * r2);
-    const float base = kS0 + v * kTHead;
-    // leader
-    float sstar1 = base + (v * (v - vl)) / kCab;
-    if (sstar1 < kS0) sstar1 = kS0;
-    const float s1 = g < 0.5f ? 0.5f : g;
-    const float q1 = sstar1 / s1;
-    float acc1 = afree - kAcc * (q1 * q1);
-    float gs1 = g - kS0;
-    if (gs1 < 0.0f) gs1 = 0.0f;
-    float vsafe1 = sqrtf((kDec * kDec + vl * vl) + (2.0f * kDec) * gs1) - kDec;
-    if (!has_lead) { acc1 = afree; vsafe1 = INFINITY; }
-    // stop line (leader speed 0, no min gap)
-    float sstar2 = base + (v * (v - 0.0f)) / kCab;
-    if (sstar2 < kS0) sstar2 = kS0;
-    const float s2 = gline < 0.5f ? 0.5f : gline;
-    const float q2 = sstar2 / s2;
-    float acc2 = afree - kAcc * (q2 * q2);
-    float gs2 = gline - 0.0f;
-    if (gs2 < 0.0f) gs2 = 0.0f;
-    const float vsafe2 = sqrtf((kDec * kDec + 0.0f * 0.0f) + (2.0f * kDec) * gs2) - kDec;
-    if (acc1 < -kDec) acc1 = -kDec;
-    if (acc2 < -kDec) acc2 = -kDec;
-    float a1 = v + acc1, a2 = v + acc2;
-    if (a1 > vsafe1) a1 = vsafe1;
-    if (a2 > vsafe2) a2 = vsafe2;
-    if (a1 > v0 && v <= v0) a1 = v0;
-    if (a2 > v0 && v <= v0) a2 = v0;
-    if (a1 < 0.0f) a1 = 0.0f;
-    if (a2 < 0.0f) a2 = 0.0f;
-    vn_lead = a1; vn_line = a2;
-}
-
 __device__ __forceinline__ bool sig_open(int tl, int k, int a, int w, float x, float v, float L,
                                          const uint8_t *link, int KMAX, int teleport) {
     if (tl == -1) return true;                      // route ends at the lane end
@@ -190,7 +150,7 @@ __device__ __forceinline__ Smem carve(char *base, const EnvDev &P) {
     s.link_y = (uint8_t *)take(P.A * P.KMAX); s.link_g = (uint8_t *)take(P.A * P.KMAX);
     s.len = (float *)take(4 * P.NLP); s.node = (int *)take(4 * P.NLP);
     s.pend = (int *)take(4 * P.NR); s.ser = (int *)take(4 * P.NR); s.emit = (uint8_t *)take(8 * P.NR);
-    s.zip = (uint8_t *)take(P.NL * P.NR);
+    s.zip = (uint8_t *)take((P.NL * P.NR + 3) / 4 * 4);
     return s;
 }
 
@@ -198,7 +158,7 @@ size_t smem_bytes(const EnvDev &P) {
     auto r16 = [](size_t b) { return (b + 15) & ~size_t(15); };
     size_t t = r16(sizeof(double) * (P.A + 1)) + r16(sizeof(int) * P.NL * P.NR) + 6 * r16(4 * P.NLP) +
                5 * r16(4 * kMaxCross * P.NLP) + 4 * r16(4 * P.NLP) + 2 * r16(P.A * P.KMAX) + 2 * r16(4 * P.NLP) +
-               2 * r16(4 * P.NR) + r16(8 * P.NR) + r16(P.NL * P.NR);
+               2 * r16(4 * P.NR) + r16(8 * P.NR) + r16(P.NL * P.NR + 4);
     return t;
 }
 
@@ -228,6 +188,7 @@ __device__ __forceinline__ double norm_clip(double x, double norm, double clip) 
 // K5: float32(state) for every agent of env e (envs/env.py:163-205)
 __device__ void emit_obs(const EnvDev &P, const Smem &s, int e, float *obs) {
     const int tot = P.A * P.SMAX;
+#pragma unroll 4
     for (int idx = threadIdx.x; idx < tot; idx += blockDim.x) {
         int kind = P.obs_kind[idx], src = P.obs_src[idx];
         float o = 0.0f;
@@ -294,7 +255,8 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         const uint8_t *y = (prev < 0 || prev == act) ? g : P.yellow_tab + (((size_t)a * P.PMAX + prev) * P.PMAX + act) * P.KMAX;
         for (int k = 0; k < P.KMAX; ++k) { s.link_y[a * P.KMAX + k] = y[k]; s.link_g[a * P.KMAX + k] = g[k]; }
     }
-    for (int i = l; i < P.NL * NR; i += blockDim.x) { s.mv[i] = P.mv[i]; s.zip[i] = P.zip[i]; }
+    for (int i = l; i < P.NL * NR; i += blockDim.x) s.mv[i] = P.mv[i];
+    for (int i = l; i < (P.NL * NR + 3) / 4; i += blockDim.x) ((uint32_t *)s.zip)[i] = ((const uint32_t *)P.zip)[i];   // padded to 4 B
     for (int q = l; q < NLP; q += blockDim.x) { s.len[q] = q < P.NL ? P.lane_len[q] : 1.0f; s.node[q] = q < P.NL ? P.lane_node[q] : -1; }
 
     // ---- per-lane constants and the initial lane summary
@@ -344,8 +306,10 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     __syncthreads();
     TSC_STAMP();
 
+    int d_wave = 0, d_halt = 0;                     // detector counts, taken during the last simulated second
     for (int sub = 0; sub < P.ctrl; ++sub, ++t) {
         const uint8_t *link = sub < P.yellow ? s.link_y : s.link_g;
+        const bool last = sub == P.ctrl - 1;
         // ================= phase A (K2): advance own vehicles from the OLD state =================
         int kept = 0, nsent = 0;
         if (lane) {
@@ -407,13 +371,17 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 }
                 const bool line_block = all_crossed ? !can_cross : !open;
                 const bool tgt_lead = can_cross && !sink && s.n[tl] > 0;
-                // leader: vehicle ahead (old state), else the old tail of the target lane, else free road
+                // leader: vehicle ahead (old state), else the old tail of the target lane, else free road; the stop line
+                // is a second leader when the link is closed (evaluating both branch-free was measured no faster and
+                // costs 40 VGPRs)
                 const bool has_lead = i > 0 || tgt_lead;
                 const float lg = i > 0 ? (pox - kLen) - x : (L - x) + (s.tx[tgt_lead ? tl : 0] - kLen);
                 const float lvl = i > 0 ? pov : s.tv[tgt_lead ? tl : 0];
-                float vn, v2;
-                follow2(v, v0, has_lead, lg, lvl, L - x, vn, v2);
-                if (line_block && v2 < vn) vn = v2;
+                float vn = follow(v, v0, has_lead, lg, lvl, kS0);
+                if (line_block) {
+                    const float v2 = follow(v, v0, true, L - x, 0.0f, 0.0f);
+                    if (v2 < vn) vn = v2;
+                }
                 float xn = x + vn;
                 bool clamped = false;
                 if (xn > pnx - kLen) { xn = pnx - kLen; clamped = true; }
@@ -448,6 +416,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     if (kept == 0) { hx = xn; hv = vn; hm = nmeta; }
                     tx = xn; tv = vn;
                     ++kept;
+                    if (last && xn >= det) { ++d_wave; if (vn < kHalt) ++d_halt; }
                 }
                 cur = nxt;
             }
@@ -480,6 +449,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                         if (n == 0) { hx = ax; hv = av; hm = am; }
                         tx = ax; tv = av;
                         ++n;
+                        if (last && ax >= det) { ++d_wave; if (av < kHalt) ++d_halt; }
                     }
                 }
             }
@@ -504,6 +474,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                         if (n == 0) { hx = ax; hv = 0.0f; hm = am; }
                         tx = ax; tv = 0.0f;
                         ++n;
+                        if (last && ax >= det) { ++d_wave; ++d_halt; }
                         --pend;
                         ++ser;
                     }
@@ -520,16 +491,9 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     // ---- K4: detectors (envs/env.py:325-407): wave, halting, wait of the front-most vehicle
     if (lane) {
         P.N[(size_t)e * NLP + l] = n;
-        int wave = 0, halt = 0, hw = 0;
-        for (int i = 0; i < n; ++i) {
-            const float x = X[i * NLP + l];
-            if (x >= det) {
-                ++wave;
-                if (V[i * NLP + l] < kHalt) ++halt;
-                if (i == 0 && x > 0.0f) hw = (int)(M[l] & 0xFFFFu);
-            }
-        }
-        s.wave[l] = wave; s.halt[l] = halt; s.hwait[l] = hw;
+        // counts were taken while the last simulated second wrote the vehicles; the front-most vehicle is slot 0
+        const int hw = (n > 0 && hx >= det && hx > 0.0f) ? (int)(hm & 0xFFFFu) : 0;
+        s.wave[l] = d_wave; s.halt[l] = d_halt; s.hwait[l] = hw;
     } else {
         s.wave[l] = 0; s.halt[l] = 0; s.hwait[l] = 0;
     }
@@ -719,7 +683,7 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     }
     UP(mv, int, mv.data(), NL * NR);
     {
-        std::vector<uint8_t> zp((size_t)NL * NR, 0);
+        std::vector<uint8_t> zp(((size_t)NL * NR + 3) / 4 * 4, 0);
         for (int i = 0; i < NL * NR; ++i) {
             const int z = sc->mv_zip[i], rank = z & 0xFF, cnt = z >> 8;
             if (rank > 15 || cnt > 15) return tsc::fail("tsc_env_create: zipper slot overflow");
