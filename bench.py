@@ -140,6 +140,7 @@ def main():
     ap.add_argument('--agent', default='ma2c', choices=['ma2c', 'ia2c'])
     ap.add_argument('--scenario', default='large_grid', choices=['large_grid', 'real_net'])
     ap.add_argument('--policy', default='lstm', choices=['lstm', 'fc'], help='fc = FcACPolicy (BASELINE configs[1], ia2c only)')
+    ap.add_argument('--batches', type=int, default=1, help='independent half-batches per GPU on separate HIP streams')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     args = ap.parse_args()
@@ -159,7 +160,7 @@ def main():
     from deeprl_signal_control_amd.agents import VecA2C
     from deeprl_signal_control_amd.env import VecTrafficEnv
     from deeprl_signal_control_amd.scenario import build_scenario
-    from deeprl_signal_control_amd.trainer import VecTrainer
+    from deeprl_signal_control_amd.trainer import MultiBatchTrainer, VecTrainer
 
     E = args.envs
     scn = build_scenario(args.scenario, args.agent)
@@ -167,11 +168,19 @@ def main():
         mcfg, seed0, tseeds = dict(reward_norm=2000.0 if args.agent == 'ma2c' else 3000.0, batch_size=120), 12, (10000, 20000)
     else:                                    # config/config_{ma2c,ia2c}_real.ini
         mcfg, seed0, tseeds = dict(reward_norm=1.0, batch_size=40), 42, (10000, 20000, 30000)
-    env = VecTrafficEnv(scn, E, device=local, seed=seed0 + rank * E, seed_stride=E * world, test_seeds=tseeds)
-    model = VecA2C(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, scn.n_f_ls, E, scn.s_max, int(scn.green_tab.shape[1]), mcfg,
-                   device=local, seed=0, name=args.agent, policy=args.policy)
-    model.sample_seed = 1000 + rank
-    tr = VecTrainer(env, model)
+    B = max(1, args.batches)
+    assert E % B == 0
+    Eb = E // B
+    envs, models = [], []
+    for b in range(B):
+        envs.append(VecTrafficEnv(scn, Eb, device=local, seed=seed0 + rank * E + b * Eb, seed_stride=E * world,
+                                  test_seeds=tseeds))
+        mdl = VecA2C(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, scn.n_f_ls, Eb, scn.s_max, int(scn.green_tab.shape[1]), mcfg,
+                     device=local, seed=0, name=args.agent, policy=args.policy)
+        mdl.sample_seed = 1000 + rank * B + b
+        models.append(mdl)
+    env, model = envs[0], models[0]
+    tr = VecTrainer(env, model) if B == 1 else MultiBatchTrainer(envs, models)
 
     def sync():
         torch.cuda.synchronize()
@@ -191,7 +200,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = {} if args.no_profile else _lib.profile()
     _lib.profile(enable=False)
-    live.append(env.mean_live_vehicles())
+    live.append(float(np.mean([e_.mean_live_vehicles() for e_ in envs])))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -211,7 +220,7 @@ def main():
                                          ' (neighbour fingerprint gather)' if args.agent == 'ma2c' else '', E, n_step, ctrl,
                                          'BPTT, ' if args.policy == 'lstm' else '', ', RCCL grad all-reduce' if world > 1 else ''),
                           'envs_per_gpu': E, 'n_step': n_step, 'agents': scn.n_agent,
-                          'parallelism': 'env-sharded x%d' % world, 'mean_live_vehicles_per_env': live[-1],
+                          'parallelism': 'env-sharded x%d%s' % (world, ', %d half-batches on separate streams' % B if B > 1 else ''), 'mean_live_vehicles_per_env': live[-1],
                           'mean_step_reward': tr.mean_step_reward()}}
         if prof:
             total = sum(ms for ms, _ in prof.values())

@@ -312,12 +312,15 @@ class VecA2C:
 
     def grad_tensor(self):
         """The contiguous fp32 gradient buffer as a torch tensor view (for RCCL all-reduce)."""
+        if getattr(self, '_grad_t', None) is not None:
+            return self._grad_t
         class _Holder:
             pass
         hold = _Holder()
         hold.__cuda_array_interface__ = {'shape': (self.n_param,), 'typestr': '<f4', 'data': (self._grad_ptr, False),
                                          'version': 3, 'strides': None}
-        return torch.as_tensor(hold, device=self.device)
+        self._grad_t = torch.as_tensor(hold, device=self.device)
+        return self._grad_t
 
     # ---- reference API (batched) ------------------------------------------------------------
     def reset(self):
@@ -367,20 +370,32 @@ class VecA2C:
             C.c_void_p(done_post.data_ptr())))
         self.cur_t += 1
 
-    def backward(self, R, summary_writer=None, global_step=None, want_stats=False):
-        """agents/models.py:174-183.  R: bootstrap values f32 [E,A] (zeros where terminal)."""
+    def use_stream(self, stream):
+        self.stream = stream
+        _lib.check(self._L.tsc_model_set_stream(self._h, C.c_void_p(stream.cuda_stream)))
+
+    def compute_grads(self, R):
+        """First half of IA2C.backward (agents/models.py:174-183): returns + loss + BPTT -> flat gradient buffer."""
         assert self.cur_t == self.n_step, 'backward() needs a full n_step buffer (T %% n_step == 0, utils.py:121)'
-        cur_lr = self.lr_scheduler.get(self.n_step)
+        self._cur_lr = self.lr_scheduler.get(self.n_step)
         cur_beta = self.beta_scheduler.get(self.n_step)
         _lib.check(self._L.tsc_model_compute_grads(self._h, C.c_void_p(R.data_ptr()), float(cur_beta)))
-        scale = 1.0
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            scale = allreduce_grads_(self.grad_tensor(), self.pg)   # RCCL over xGMI, one flat buffer
+
+    def apply_grads(self, scale=1.0, want_stats=False):
+        """Second half: per-agent clip on grad * scale, TF1 RMSProp, states_bw <- states_fw, buffer reset."""
         stats = np.zeros((self.n_agent, 4), np.float64) if want_stats else None
-        _lib.check(self._L.tsc_model_apply_grads(self._h, float(cur_lr), scale,
+        _lib.check(self._L.tsc_model_apply_grads(self._h, float(self._cur_lr), float(scale),
                                                  stats.ctypes.data_as(C.c_void_p) if want_stats else None))
         self.cur_t = 0
         return stats
+
+    def backward(self, R, summary_writer=None, global_step=None, want_stats=False):
+        """agents/models.py:174-183.  R: bootstrap values f32 [E,A] (zeros where terminal)."""
+        self.compute_grads(R)
+        scale = 1.0
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            scale = allreduce_grads_(self.grad_tensor(), self.pg)   # RCCL over xGMI, one flat buffer
+        return self.apply_grads(scale, want_stats)
 
     # ---- checkpoints (agents/models.py:83-108: `checkpoint-<step>`, highest step wins) -------
     def save(self, model_dir, global_step):

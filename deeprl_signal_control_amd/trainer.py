@@ -99,6 +99,93 @@ class VecTrainer:
         return self.env.reward_sum() / (steps * self.env.E)
 
 
+class MultiBatchTrainer:
+    """The same iteration with the env instances of one GPU split into B independent half-batches, each on
+    its own HIP stream with its own (env, model) handles and identical parameters.  Within a half-batch the
+    rollout is a strict chain (forward -> step -> forward ...); the latency-bound microsimulator step of one
+    half-batch runs under the MFMA-bound policy forward of the other.  The update is what N ranks would do
+    on N GPUs: every half computes the gradient of its own samples, the flat buffers are summed, every
+    handle applies the same averaged gradient (so the replicas stay bit-identical)."""
+
+    def __init__(self, envs, models):
+        assert len(envs) == len(models) and len(envs) >= 1
+        self.envs, self.models = envs, models
+        self.parts = [VecTrainer(e, m) for e, m in zip(envs, models)]
+        dev = envs[0].device
+        self.streams = [torch.cuda.Stream(device=dev) for _ in envs]
+        for e, m, st in zip(envs, models, self.streams):
+            e.use_stream(st)
+            m.use_stream(st)
+        self.n_step = models[0].n_step
+
+    def _each(self, fn):
+        out = []
+        for part, st in zip(self.parts, self.streams):
+            with torch.cuda.stream(st):
+                out.append(fn(part))
+        return out
+
+    def run_iteration(self):
+        for part in self.parts:
+            if part.ob is None:
+                with torch.cuda.stream(self.streams[self.parts.index(part)]):
+                    part.start_episode()
+        # rollout: interleave the half-batches control step by control step so both chains stay fed
+        state = [dict(ob=p.ob, done=p.done, fin=False) for p in self.parts]
+        for _ in range(self.n_step):
+            for p, st, s in zip(self.parts, self.streams, state):
+                if s['fin']:
+                    continue
+                with torch.cuda.stream(st):
+                    env, model = p.env, p.model
+                    pi, v, action = model.forward_sample(s['ob'], s['done'])
+                    if p.agent == 'ma2c':
+                        env.update_fingerprint(pi, zero_copy=True)
+                    next_ob, reward, done_post, _ = env.step(action)
+                    p.global_counter.next()
+                    model.add_transition(s['ob'], s['done'], action, reward, v, done_post)
+                    s['fin'] = env.cur_sec >= env.scn.episode_length_sec
+                    s['ob'], s['done'] = next_ob, done_post
+        finished = state[0]['fin']
+        for p, st, s in zip(self.parts, self.streams, state):
+            with torch.cuda.stream(st):
+                p.ob, p.done = s['ob'], s['done']
+                R = p.zero_R if s['fin'] else p.model.forward(s['ob'], False, 'v')
+                p.model.compute_grads(R)
+        # gradient exchange between the half-batches (and, with several GPUs, between ranks)
+        g0 = self.models[0].grad_tensor()
+        main = self.streams[0]
+        for m, st in zip(self.models[1:], self.streams[1:]):
+            main.wait_stream(st)
+        with torch.cuda.stream(main):
+            for m in self.models[1:]:
+                g0.add_(m.grad_tensor())
+            scale = 1.0 / len(self.models)
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                from .agents import allreduce_grads_
+                scale *= allreduce_grads_(g0, self.models[0].pg)
+            for m in self.models[1:]:
+                m.grad_tensor().copy_(g0)
+        for st in self.streams[1:]:
+            st.wait_stream(main)
+        self._each(lambda p: p.model.apply_grads(scale))
+        if finished:
+            def restart(p):
+                p.env.terminate()
+                p.start_episode()
+            self._each(restart)
+        return finished, None
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
+
+    def mean_step_reward(self):
+        tot = sum(p.env.reward_sum() for p in self.parts)
+        steps = max(1, self.parts[0].global_counter.cur_step)
+        return tot / (steps * sum(p.env.E for p in self.parts))
+
+
 def greedy_actions_large_grid(obs):
     """envs/large_grid_env.py:56-60 on the batched obs tensor [E,A,SMAX] (first 6 entries = own
     wave).  Host-side helper for sim-only benchmarks; plain indexing, no learned compute."""
