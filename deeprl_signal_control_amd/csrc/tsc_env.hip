@@ -42,7 +42,8 @@ __host__ __device__ __forceinline__ bool mv_prio(int w) { return (w >> 30) & 1; 
 
 struct EnvDev {
     int NL, NLP, NR, A, NF, KMAX, PMAX, LMAX, SMAX, NBR, E;
-    int NU, NLA;                   // lanes that can ever hold a vehicle (prefix after load sorting); threads per workgroup
+    int NU, NLA;                   // lanes that can ever hold a vehicle (prefix after load sorting), rounded up to wavefronts
+    int help;                      // phase A1 enabled (step_kernel)
     const float *lane_len, *lane_vmax, *lane_det;
     const int *lane_node, *lane_up;
     const int *mv;                 // [NL*NR] packed movement word, see mv_* helpers
@@ -59,6 +60,7 @@ struct EnvDev {
     int ctrl, yellow, episode, teleport, queue_cap, objective, agent_kind, realnet_scale;
     double coop_gamma, norm_wave, norm_wait, clip_wave, clip_wait, coef_wait;
     float *X, *V, *SF;
+    float *C;                      // [E][kCap][NLP] scratch of step_kernel's phase A1 (same indexing as X)
     uint32_t *M;                   // w | route << 16
     int *N;                        // [E][NLP]
     int *pending, *serial;         // [E][NR]
@@ -80,6 +82,14 @@ __device__ __forceinline__ uint32_t hash32(uint32_t seed, uint32_t route, uint32
     return h;
 }
 __device__ __forceinline__ float u01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
+
+// base + 32-bit byte offset: lets the compiler use the scalar-base addressing mode (one VGPR per address)
+template <class T> __device__ __forceinline__ T ldg(const T *base, unsigned byte_off) {
+    return *(const T *)((const char *)base + byte_off);
+}
+template <class T> __device__ __forceinline__ void stg(T *base, unsigned byte_off, T v) {
+    *(T *)((char *)base + byte_off) = v;
+}
 
 // one car-following evaluation against one leader (DESIGN.md "follow")
 __device__ __forceinline__ float follow(float v, float v0, bool has_lead, float g, float vl, float s0gap) {
@@ -122,44 +132,50 @@ __device__ __forceinline__ bool sig_open(int tl, int k, int a, int w, float x, f
 }
 
 struct Smem {
-    int *mv;                                   // [NL*NR]
-    int *n; float *tx, *tv, *hx, *hv; uint32_t *hm;   // lane summaries [NLP]
-    float *ox, *ov, *osf; uint32_t *om; int *oto;     // outbox [kMaxCross*NLP]
-    int *nout;                                  // [NLP]
+    int *mv;                                   // [NU*NR]
+    int *n; float *tx, *tv, *hx, *hv; uint32_t *hm;   // lane summaries [NLA]
+    float *ox, *ov, *osf; uint32_t *om; int *oto;     // outbox [kMaxCross*NLA]
+    int *nout;                                  // [NLA]
     int *wave, *halt, *hwait;                   // detectors [NLP]
     double *r;                                  // local rewards [A] (+1 for global)
     uint8_t *link_y, *link_g;                   // [A*KMAX]
-    float *len; int *node;                      // lane length / downstream agent [NLP]
+    float *len, *vmax; int *node;               // lane length / speed limit / downstream agent [NLA]
     int *pend, *ser; uint8_t *emit;             // per-route insertion state [NR], emissions [NR*8]
-    uint8_t *zip;                               // [NL*NR]
+    uint8_t *zip;                               // [NU*NR]
+    int *pre, *wtot;                            // wave-local inclusive scan of queued vehicles [NLA], wave totals [16]
 };
+
+// One layout for the step and the reset kernel.
+template <class Take>
+__host__ __device__ __forceinline__ void smem_layout(Smem &s, const EnvDev &P, Take take) {
+    s.r = (double *)take(sizeof(double) * (P.A + 1));
+    s.mv = (int *)take(sizeof(int) * P.NU * P.NR);
+    s.n = (int *)take(4 * P.NLA); s.tx = (float *)take(4 * P.NLA); s.tv = (float *)take(4 * P.NLA);
+    s.hx = (float *)take(4 * P.NLA); s.hv = (float *)take(4 * P.NLA); s.hm = (uint32_t *)take(4 * P.NLA);
+    s.ox = (float *)take(4 * kMaxCross * P.NLA); s.ov = (float *)take(4 * kMaxCross * P.NLA);
+    s.osf = (float *)take(4 * kMaxCross * P.NLA); s.om = (uint32_t *)take(4 * kMaxCross * P.NLA);
+    s.oto = (int *)take(4 * kMaxCross * P.NLA);
+    s.nout = (int *)take(4 * P.NLA);
+    s.wave = (int *)take(4 * P.NLP); s.halt = (int *)take(4 * P.NLP); s.hwait = (int *)take(4 * P.NLP);
+    s.link_y = (uint8_t *)take(P.A * P.KMAX); s.link_g = (uint8_t *)take(P.A * P.KMAX);
+    s.len = (float *)take(4 * P.NLA); s.vmax = (float *)take(4 * P.NLA); s.node = (int *)take(4 * P.NLA);
+    s.pend = (int *)take(4 * P.NR); s.ser = (int *)take(4 * P.NR); s.emit = (uint8_t *)take(8 * P.NR);
+    s.zip = (uint8_t *)take((P.NU * P.NR + 3) / 4 * 4);
+    s.pre = (int *)take(4 * P.NLA); s.wtot = (int *)take(4 * 16);
+}
 
 __device__ __forceinline__ Smem carve(char *base, const EnvDev &P) {
     Smem s;
     char *p = base;
-    auto take = [&](size_t bytes) { char *q = p; p += (bytes + 15) & ~size_t(15); return q; };
-    s.r = (double *)take(sizeof(double) * (P.A + 1));
-    s.mv = (int *)take(sizeof(int) * P.NL * P.NR);
-    s.n = (int *)take(4 * P.NLP); s.tx = (float *)take(4 * P.NLP); s.tv = (float *)take(4 * P.NLP);
-    s.hx = (float *)take(4 * P.NLP); s.hv = (float *)take(4 * P.NLP); s.hm = (uint32_t *)take(4 * P.NLP);
-    s.ox = (float *)take(4 * kMaxCross * P.NLP); s.ov = (float *)take(4 * kMaxCross * P.NLP);
-    s.osf = (float *)take(4 * kMaxCross * P.NLP); s.om = (uint32_t *)take(4 * kMaxCross * P.NLP);
-    s.oto = (int *)take(4 * kMaxCross * P.NLP);
-    s.nout = (int *)take(4 * P.NLP);
-    s.wave = (int *)take(4 * P.NLP); s.halt = (int *)take(4 * P.NLP); s.hwait = (int *)take(4 * P.NLP);
-    s.link_y = (uint8_t *)take(P.A * P.KMAX); s.link_g = (uint8_t *)take(P.A * P.KMAX);
-    s.len = (float *)take(4 * P.NLP); s.node = (int *)take(4 * P.NLP);
-    s.pend = (int *)take(4 * P.NR); s.ser = (int *)take(4 * P.NR); s.emit = (uint8_t *)take(8 * P.NR);
-    s.zip = (uint8_t *)take((P.NL * P.NR + 3) / 4 * 4);
+    smem_layout(s, P, [&](size_t bytes) { char *q = p; p += (bytes + 15) & ~size_t(15); return q; });
     return s;
 }
 
 size_t smem_bytes(const EnvDev &P) {
-    auto r16 = [](size_t b) { return (b + 15) & ~size_t(15); };
-    size_t t = r16(sizeof(double) * (P.A + 1)) + r16(sizeof(int) * P.NL * P.NR) + 6 * r16(4 * P.NLP) +
-               5 * r16(4 * kMaxCross * P.NLP) + 4 * r16(4 * P.NLP) + 2 * r16(P.A * P.KMAX) + 2 * r16(4 * P.NLP) +
-               2 * r16(4 * P.NR) + r16(8 * P.NR) + r16(P.NL * P.NR + 4);
-    return t;
+    Smem s;
+    size_t tot = 0;
+    smem_layout(s, P, [&](size_t bytes) { tot += (bytes + 15) & ~size_t(15); return (char *)nullptr; });
+    return tot;
 }
 
 // numpy's float64 pairwise sum for n <= 128 (np.sum at envs/env.py:580)
@@ -226,25 +242,37 @@ __global__ void fingerprint_kernel(EnvDev P, const float *pi) {
     if (i < tot) P.fp[i] = pi[i];                                  // pi[:-1] is applied at gather time
 }
 
+// Work decomposition of one workgroup (= one env instance):
+//   * lane threads (l < NLA) own one lane each: the front-to-back walk (phase A2), the gather (phase B);
+//   * with HELP, phase A1 first evaluates the car-following law of every queued vehicle (slot >= 1) with ALL
+//     threads of the workgroup, one vehicle per thread in a flat, load-balanced order (prefix sum over the lane
+//     counts + a 6-step binary search).  A queued vehicle that is not the head of a platoon crossing in this very
+//     second cannot cross, so its new speed depends only on OLD state (itself, the vehicle ahead, the signal):
+//     min(follow(leader), follow(stop line) if the link is closed).  The walk then only applies the clamps and
+//     the bookkeeping (~50 instructions per vehicle instead of ~500); heads and vehicles right behind a vehicle
+//     that crossed this second are still evaluated inline.  Lanes are very unevenly loaded (a wavefront walks as
+//     long as its fullest lane while most of its 64 threads idle), so this halves the VALU work of the kernel.
 // Register budget: the 256-thread instantiation is capped at 128 VGPRs (4 waves / SIMD).  With 155 VGPRs the
 // grid fits the chip with no slack, and whenever another kernel ran in between (i.e. always, in the training
 // loop) XCD 0 admitted ~30 workgroups one full round late -> 178 us became 316 us per step
 // (tools/bench_env.py, tsc_env_debug_clock).  The cap costs ~120 B of scratch per lane and 8 % in isolation.
-template <int MAXT>
+template <int MAXT, bool HELP>
 __global__ void __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1)
 step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, double *__restrict__ reward,
             double *__restrict__ greward, uint8_t *__restrict__ done, int train_mode) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     Smem s = carve(smem_raw, P);
-    const int e = blockIdx.x, l = threadIdx.x, NLP = P.NLP, NR = P.NR;
-    const bool lane = l < P.NU;             // lanes >= NU are never entered by any route: no thread, always empty
+    const int e = blockIdx.x, l = threadIdx.x, NLP = P.NLP, NLA = P.NLA, NR = P.NR;
+    const bool lane = l < P.NU;             // lanes >= NU are never entered by any route: always empty
+    const bool lthr = l < NLA;              // threads >= NLA only help in phase A1 and in the strided loops
     const bool stamp = P.dbg && blockIdx.x == 0 && threadIdx.x == 0;
     int nstamp = 0;
-#define TSC_STAMP() do { if (stamp) P.dbg[nstamp++] = clock64(); } while (0)
+#define TSC_STAMP() do { if (stamp && nstamp < 62) P.dbg[nstamp++] = clock64(); } while (0)
     TSC_STAMP();
     if (P.dbg && threadIdx.x == 0) P.dbg[64 + 2 * blockIdx.x] = wall_clock64();
     float *X = P.X + (size_t)e * kCap * NLP, *V = P.V + (size_t)e * kCap * NLP, *SF = P.SF + (size_t)e * kCap * NLP;
     uint32_t *M = P.M + (size_t)e * kCap * NLP;
+    float *C = P.C + (size_t)e * kCap * NLP;   // phase A1 -> A2: new speed of a queued vehicle that cannot cross
 
     // ---- K1: signal FSM (envs/env.py:128-152) -> link chars for the yellow and the green interval
     for (int a = l; a < P.A; a += blockDim.x) {
@@ -255,9 +283,13 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         const uint8_t *y = (prev < 0 || prev == act) ? g : P.yellow_tab + (((size_t)a * P.PMAX + prev) * P.PMAX + act) * P.KMAX;
         for (int k = 0; k < P.KMAX; ++k) { s.link_y[a * P.KMAX + k] = y[k]; s.link_g[a * P.KMAX + k] = g[k]; }
     }
-    for (int i = l; i < P.NL * NR; i += blockDim.x) s.mv[i] = P.mv[i];
-    for (int i = l; i < (P.NL * NR + 3) / 4; i += blockDim.x) ((uint32_t *)s.zip)[i] = ((const uint32_t *)P.zip)[i];   // padded to 4 B
-    for (int q = l; q < NLP; q += blockDim.x) { s.len[q] = q < P.NL ? P.lane_len[q] : 1.0f; s.node[q] = q < P.NL ? P.lane_node[q] : -1; }
+    for (int i = l; i < P.NU * NR; i += blockDim.x) s.mv[i] = P.mv[i];
+    for (int i = l; i < (P.NU * NR + 3) / 4; i += blockDim.x) ((uint32_t *)s.zip)[i] = ((const uint32_t *)P.zip)[i];   // padded to 4 B
+    for (int q = l; q < NLA; q += blockDim.x) {
+        const bool in = q < P.NU;
+        s.len[q] = in ? P.lane_len[q] : 1.0f; s.node[q] = in ? P.lane_node[q] : -1; s.vmax[q] = in ? P.lane_vmax[q] : 1.0f;
+    }
+    for (int q = l; q < NLP; q += blockDim.x) { s.wave[q] = 0; s.halt[q] = 0; s.hwait[q] = 0; }
 
     // ---- per-lane constants and the initial lane summary
     int n = 0, my_node = -1;
@@ -269,21 +301,24 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         my_node = P.lane_node[l];
         if (n > 0) { hx = X[l]; hv = V[l]; hm = M[l]; tx = X[(n - 1) * NLP + l]; tv = V[(n - 1) * NLP + l]; }
     }
-    s.n[l] = n; s.hx[l] = hx; s.hv[l] = hv; s.hm[l] = hm; s.tx[l] = tx; s.tv[l] = tv;
-    for (int q = blockDim.x + l; q < NLP; q += blockDim.x) { s.n[q] = 0; s.nout[q] = 0; s.wave[q] = 0; s.halt[q] = 0; s.hwait[q] = 0; }
-    // Warm the cache hierarchy with this lane's live slots: between two control steps the policy kernels
-    // evict the vehicle state from L2, and the front-to-back walk below is a dependent chain that would pay
-    // the full HBM latency per vehicle (measured: 178 -> 310 us per step).  All loads are issued back to back
-    // here and overlap with the rest of the prologue.
-    {
-        float sink = 0.0f;
-#pragma unroll 4
-        for (int i = 1; i < n; ++i) {
-            const int o = i * NLP + l;
-            sink += X[o] + V[o] + SF[o] + __uint_as_float(M[o]);
+    // publishes a lane's summary for the next second; with HELP also the wave-local inclusive scan of the number
+    // of queued vehicles (slots >= 1) that phase A1 distributes over the workgroup
+    auto publish = [&]() {
+        if (!lthr) return;
+        s.n[l] = n; s.hx[l] = hx; s.hv[l] = hv; s.hm[l] = hm; s.tx[l] = tx; s.tv[l] = tv;
+        if constexpr (HELP) {
+            int inc = n > 1 ? n - 1 : 0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl_up(inc, d, 64);
+                if ((l & 63) >= d) inc += up;
+            }
+            s.pre[l] = inc;
+            if ((l & 63) == 63) s.wtot[l >> 6] = inc;
         }
-        if (sink == 1.2345e-37f) s.hv[l] = sink;                  // never true; keeps the loads alive
-    }
+    };
+    publish();
+    if (lthr) s.nout[l] = 0;
     int t = P.tsec[e];
     const uint32_t seed = P.seed[e];
     unsigned arrived = 0;
@@ -310,48 +345,105 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     for (int sub = 0; sub < P.ctrl; ++sub, ++t) {
         const uint8_t *link = sub < P.yellow ? s.link_y : s.link_g;
         const bool last = sub == P.ctrl - 1;
-        // ================= phase A (K2): advance own vehicles from the OLD state =================
+        // ================= phase A1: car-following of the queued vehicles, one per thread =================
+        if constexpr (HELP) {
+            const int nseg = NLA >> 6;
+            int total = 0;
+            for (int w = 0; w < nseg; ++w) total += s.wtot[w];
+            // kA1 vehicles per thread and round: all locates and loads are issued before the first evaluation
+            // (consecutive k = consecutive slots of one lane: the loads are strided, ~64 lines per instruction,
+            // which still costs far less than the latency of doing them one vehicle at a time)
+            constexpr int kA1 = 4;
+            for (int k0 = l; k0 < total; k0 += kA1 * (int)blockDim.x) {
+                int ql[kA1], qo[kA1];
+                float x[kA1], v[kA1], sf[kA1], px[kA1], pv[kA1];
+                uint32_t m[kA1];
+#pragma unroll
+                for (int u = 0; u < kA1; ++u) {
+                    const int k = k0 + u * (int)blockDim.x;
+                    int w = 0, kk = k < total ? k : total - 1;    // clamped: locate and load unconditionally
+                    for (; w < nseg - 1; ++w) {
+                        const int c = s.wtot[w];
+                        if (kk < c) break;
+                        kk -= c;
+                    }
+                    const int *pre = s.pre + (w << 6);
+                    int lo = 0;                                   // smallest j with pre[j] > kk
+#pragma unroll
+                    for (int st = 32; st; st >>= 1) if (pre[lo + st - 1] <= kk) lo += st;
+                    const int q = (w << 6) + lo;
+                    const int i = kk - (lo ? pre[lo - 1] : 0) + 1;
+                    const unsigned ob = (unsigned)(i * NLP + q) * 4u, pb = ob - (unsigned)NLP * 4u;
+                    qo[u] = (int)ob;
+                    x[u] = ldg(X, ob); v[u] = ldg(V, ob); sf[u] = ldg(SF, ob); m[u] = ldg(M, ob);
+                    px[u] = ldg(X, pb); pv[u] = ldg(V, pb);
+                    ql[u] = k < total ? q : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < kA1; ++u) {
+                    if (ql[u] < 0) continue;
+                    const int q = ql[u];
+                    const float Lq = s.len[q];
+                    const int mvp = s.mv[q * NR + (int)(m[u] >> 16)];
+                    const float v0 = s.vmax[q] * sf[u];
+                    const bool open = sig_open(mv_tl(mvp), mv_k(mvp), s.node[q], (int)(m[u] & 0xFFFFu), x[u], v[u], Lq, link, P.KMAX, P.teleport);
+                    float vn = follow(v[u], v0, true, (px[u] - kLen) - x[u], pv[u], kS0);
+                    if (!open) {
+                        const float v2 = follow(v[u], v0, true, Lq - x[u], 0.0f, 0.0f);
+                        if (v2 < vn) vn = v2;
+                    }
+                    stg(C, (unsigned)qo[u], vn);
+                }
+            }
+            TSC_STAMP();
+            __syncthreads();
+            TSC_STAMP();
+        }
+        // ================= phase A2 (K2): advance own vehicles from the OLD state =================
         int kept = 0, nsent = 0;
         if (lane) {
             int ncross = 0;
             bool all_crossed = true;
             float pnx = INFINITY, pox = 0.0f, pov = 0.0f;
-            // Front-to-back walk; the raw state of vehicle i+1 is loaded while vehicle i is advanced.  The
-            // busiest lane's wavefront is instruction-issue bound (~500 instructions per vehicle, measured with
-            // tsc_env_debug_clock): deeper software pipelining (look-ups of vehicle i+1 one iteration ahead)
-            // and 4-wide chunks were both measured SLOWER (more instructions / fewer resident workgroups).
+            // a vehicle that stays on the lane: compact it to slot `kept`, refresh the summary, count detectors
+            auto keep = [&](float xn, float vn, float sf, uint32_t nmeta) {
+                const unsigned ob = (unsigned)(kept * NLP + l) * 4u;
+                stg(X, ob, xn); stg(V, ob, vn); stg(SF, ob, sf); stg(M, ob, nmeta);
+                if (kept == 0) { hx = xn; hv = vn; hm = nmeta; }
+                tx = xn; tv = vn;
+                ++kept;
+                if (last && xn >= det) { ++d_wave; if (vn < kHalt) ++d_halt; }
+            };
+            // ---- head walk: full evaluation.  Without HELP it covers the whole lane; with HELP only the platoon
+            // that is crossing in this second plus the first vehicle that stays (everything behind it is phase A1).
             struct Raw { float x, v, sf; uint32_t m; };
-            struct Pre { int tl, k, y, z; bool open; float v0; };
+            // Loads are UNCONDITIONAL (slot index clamped; every slot is allocated): the compiler can only keep a
+            // load in flight across the evaluation of the previous vehicle (s_waitcnt vmcnt(N > 0)) when the
+            // number of younger memory operations is known, which a load under `if (i < n)` destroys.
             auto load_raw = [&](int i) {
-                Raw r; r.x = 0.f; r.v = 0.f; r.sf = 1.f; r.m = 0u;
-                if (i < n) { const int o = i * NLP + l; r.x = X[o]; r.v = V[o]; r.sf = SF[o]; r.m = M[o]; }
+                const unsigned ob = (unsigned)((i < kCap ? i : kCap - 1) * NLP + l) * 4u;
+                Raw r; r.x = ldg(X, ob); r.v = ldg(V, ob); r.sf = ldg(SF, ob); r.m = ldg(M, ob);
                 return r;
             };
-            auto stage1 = [&](const Raw &r) {
-                Pre q;
-                const int mvp = s.mv[l * NR + (int)(r.m >> 16)];
-                q.tl = mv_tl(mvp); q.k = mv_k(mvp); q.y = mv_yield(mvp); q.z = s.zip[l * NR + (int)(r.m >> 16)];
-                q.v0 = vmax * r.sf;
-                q.open = sig_open(q.tl, q.k, my_node, (int)(r.m & 0xFFFFu), r.x, r.v, L, link, P.KMAX, P.teleport);
-                return q;
-            };
+            int i = 0;
             Raw cur = load_raw(0);
-            for (int i = 0; i < n; ++i) {
+            for (; i < n; ++i) {
+                if (HELP && !all_crossed) break;
                 const Raw nxt = load_raw(i + 1);
-                const Pre pc = stage1(cur);
-                const float x = cur.x, v = cur.v, sf = cur.sf, v0 = pc.v0;
+                const float x = cur.x, v = cur.v, sf = cur.sf;
                 const uint32_t meta = cur.m;
                 int w = (int)(meta & 0xFFFFu);
                 const int r = (int)(meta >> 16);
-                const int tl = pc.tl, k = pc.k;
+                const int mvp = s.mv[l * NR + r];
+                const int tl = mv_tl(mvp), k = mv_k(mvp), y = mv_yield(mvp), z = s.zip[l * NR + r];
+                const float v0 = vmax * sf;
                 const bool sink = tl == -1;
-                const bool open = pc.open;
+                const bool open = sig_open(tl, k, my_node, w, x, v, L, link, P.KMAX, P.teleport);
                 bool can_cross = false;
                 if (all_crossed) {
                     can_cross = open;
-                    if (can_cross && pc.y >= 0 && w < P.teleport && s.n[pc.y] > 0) {
+                    if (can_cross && y >= 0 && w < P.teleport && s.n[y] > 0) {
                         // right of way: wait while the yield lane's head has an open priority movement and is near
-                        const int y = pc.y;
                         const uint32_t om = s.hm[y];
                         const int mo = s.mv[y * NR + (int)(om >> 16)];
                         if (mv_prio(mo)) {
@@ -363,7 +455,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                         }
                     }
                     // zipper merge: feeder `rank` of `count` may send in second t iff (t + rank) % count == 0
-                    if (can_cross && (pc.z >> 4) > 1 && ((t + (pc.z & 0xF)) % (pc.z >> 4)) != 0) can_cross = false;
+                    if (can_cross && (z >> 4) > 1 && ((t + (z & 0xF)) % (z >> 4)) != 0) can_cross = false;
                     if (can_cross && tl >= 0 && s.n[tl] + kMaxCross > kCap) can_cross = false;
                     if (can_cross && tl >= 0 && s.n[tl] > 0 && s.tx[tl] < kLen) can_cross = false;   // no room behind the tail
                     if (can_cross && ncross >= kMaxCross) can_cross = false;
@@ -401,7 +493,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 const uint32_t nmeta = (uint32_t)w | ((uint32_t)r << 16);
                 if (can_cross && xn >= L) {
                     if (!sink) {
-                        const int o = nsent * NLP + l;
+                        const int o = nsent * NLA + l;
                         const float ex = xn - L, Lt = s.len[tl];          // rounding of (L + Lt) - L
                         s.ox[o] = ex > Lt ? Lt : ex; s.ov[o] = vn; s.osf[o] = sf; s.om[o] = nmeta; s.oto[o] = tl;
                         ++nsent;
@@ -411,18 +503,56 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     ++ncross;
                 } else {
                     all_crossed = false;
-                    const int o = kept * NLP + l;
-                    X[o] = xn; V[o] = vn; SF[o] = sf; M[o] = nmeta;
+                    keep(xn, vn, sf, nmeta);
+                }
+                cur = nxt;
+            }
+            // ---- tail walk (HELP): the new speed comes from phase A1; only the clamps and the bookkeeping are
+            // sequential (~50 instructions per vehicle).  The state is fetched in chunks of four vehicles, one chunk
+            // ahead (a register ring rotated every vehicle makes each iteration wait for the youngest load), and
+            // every memory operation in the loop is unconditional so that the compiler can wait with vmcnt(N > 0).
+            if constexpr (HELP) {
+                struct Lite { float x, sf, c; uint32_t m; };
+                const unsigned rowb = (unsigned)NLP * 4u, lb = (unsigned)l * 4u;
+                auto load_lite = [&](int j) {
+                    const unsigned ob = (unsigned)(j < kCap ? j : kCap - 1) * rowb + lb;
+                    Lite r; r.x = ldg(X, ob); r.sf = ldg(SF, ob); r.c = ldg(C, ob); r.m = ldg(M, ob);
+                    return r;
+                };
+                unsigned sb = (unsigned)kept * rowb + lb;             // byte offset of slot `kept`
+                auto step = [&](const Lite &c) {
+                    const float x = c.x;
+                    float vn = c.c, xn = x + vn;
+                    bool clamped = false;
+                    if (xn > pnx - kLen) { xn = pnx - kLen; clamped = true; }
+                    if (xn > L) { xn = L; clamped = true; }
+                    if (xn < x) { xn = x; clamped = true; }
+                    if (clamped) vn = xn - x;
+                    const uint32_t w = (vn < kHalt) ? (c.m & 0xFFFFu) + 1u : 0u;
+                    const uint32_t nmeta = w | (c.m & 0xFFFF0000u);
+                    pnx = xn;
+                    stg(X, sb, xn); stg(V, sb, vn); stg(SF, sb, c.sf); stg(M, sb, nmeta);
+                    sb += rowb;
                     if (kept == 0) { hx = xn; hv = vn; hm = nmeta; }
                     tx = xn; tv = vn;
                     ++kept;
                     if (last && xn >= det) { ++d_wave; if (vn < kHalt) ++d_halt; }
+                };
+                Lite c0 = load_lite(i), c1 = load_lite(i + 1), c2 = load_lite(i + 2), c3 = load_lite(i + 3);
+                for (; i + 4 <= n; i += 4) {
+                    const Lite n0 = load_lite(i + 4), n1 = load_lite(i + 5), n2 = load_lite(i + 6), n3 = load_lite(i + 7);
+                    step(c0); step(c1); step(c2); step(c3);
+                    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
                 }
-                cur = nxt;
+                if (i < n) {
+                    step(c0);
+                    if (i + 1 < n) {
+                        step(c1);
+                        if (i + 2 < n) step(c2);
+                    }
+                }
             }
             s.nout[l] = nsent;
-        } else {
-            s.nout[l] = 0;
         }
         TSC_STAMP();
         __syncthreads();
@@ -435,7 +565,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 if (src < 0) continue;
                 const int cnt = s.nout[src];
                 for (int j = 0; j < cnt; ++j) {
-                    const int o = j * NLP + src;
+                    const int o = j * NLA + src;
                     if (s.oto[o] == l && n < kCap) {
                         const int d = n * NLP + l;
                         float ax = s.ox[o];
@@ -481,8 +611,8 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 }
                 s.pend[r] = pend; s.ser[r] = ser;               // a route has exactly one entry lane: no race
             }
-            s.n[l] = n; s.hx[l] = hx; s.hv[l] = hv; s.hm[l] = hm; s.tx[l] = tx; s.tv[l] = tv;
         }
+        publish();
         TSC_STAMP();
         __syncthreads();
         TSC_STAMP();
@@ -494,8 +624,6 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         // counts were taken while the last simulated second wrote the vehicles; the front-most vehicle is slot 0
         const int hw = (n > 0 && hx >= det && hx > 0.0f) ? (int)(hm & 0xFFFFu) : 0;
         s.wave[l] = d_wave; s.halt[l] = d_halt; s.hwait[l] = hw;
-    } else {
-        s.wave[l] = 0; s.halt[l] = 0; s.hwait[l] = 0;
     }
     for (int r = l; r < NR; r += blockDim.x) { P.pending[(size_t)e * NR + r] = s.pend[r]; P.serial[(size_t)e * NR + r] = s.ser[r]; }
     if (arrived) atomicAdd(&P.arrived[e], (unsigned long long)arrived);
@@ -571,6 +699,7 @@ struct tsc_env {
     hipStream_t stream;
     std::vector<void *> allocs;
     size_t smem;
+    int threads;                    // workgroup size of step_kernel
     uint32_t *d_seeds;
 };
 
@@ -738,7 +867,7 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     UP(obs_kind, int, sc->obs_kind, A * P.SMAX); UP(obs_src, int, sc->obs_src, A * P.SMAX);
 
     const size_t slots = (size_t)n_env * kCap * P.NLP;
-    ALLOC(X, float, slots); ALLOC(V, float, slots); ALLOC(SF, float, slots); ALLOC(M, uint32_t, slots);
+    ALLOC(X, float, slots); ALLOC(C, float, slots); ALLOC(V, float, slots); ALLOC(SF, float, slots); ALLOC(M, uint32_t, slots);
     ALLOC(N, int, (size_t)n_env * P.NLP);
     ALLOC(pending, int, (size_t)n_env * NR); ALLOC(serial, int, (size_t)n_env * NR);
     ALLOC(tsec, int, n_env); ALLOC(seed, uint32_t, n_env);
@@ -750,10 +879,21 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     P.dbg = nullptr;
     TSC_HIP(hipMalloc((void **)&h->d_seeds, sizeof(uint32_t) * n_env));
     h->allocs.push_back(h->d_seeds);
+    {   // phase A1 (helper threads) unless switched off for A/B measurements
+        const char *ev = getenv("TSC_ENV_HELP");
+        P.help = (ev && ev[0] == '0') ? 0 : 1;
+    }
     h->smem = smem_bytes(P);
     if (h->smem > 160 * 1024) return tsc::fail("tsc_env_create: LDS need %zu B > 160 KiB", h->smem);
-    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
-    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    h->threads = (P.help && P.NLA < 256) ? 256 : P.NLA;
+    if (const char *ev = getenv("TSC_ENV_THREADS")) {       // measurement knob: extra helper wavefronts
+        const int tv = atoi(ev);
+        if (tv >= P.NLA && tv <= 1024 && tv % 64 == 0) h->threads = tv;
+    }
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     *out = h;
     return 0;
@@ -816,12 +956,12 @@ int tsc_env_step(tsc_env *h, const int32_t *action_dev, float *obs_dev, double *
     if (!h || !action_dev || !obs_dev || !reward_dev || !global_reward_dev || !done_dev)
         return tsc::fail("tsc_env_step: bad arguments");
     tsc::ProfScope ps(tsc::KID_ENV_STEP, h->stream);
-    if (h->P.NLA <= 256)
-        hipLaunchKernelGGL((step_kernel<256>), dim3(h->P.E), dim3(h->P.NLA), h->smem, h->stream, h->P, action_dev, obs_dev,
-                           reward_dev, global_reward_dev, done_dev, (int)train_mode);
-    else
-        hipLaunchKernelGGL((step_kernel<1024>), dim3(h->P.E), dim3(h->P.NLA), h->smem, h->stream, h->P, action_dev, obs_dev,
-                           reward_dev, global_reward_dev, done_dev, (int)train_mode);
+#define TSC_STEP(MAXT, HELP)                                                                                       \
+    hipLaunchKernelGGL((step_kernel<MAXT, HELP>), dim3(h->P.E), dim3(h->threads), h->smem, h->stream, h->P, action_dev, \
+                       obs_dev, reward_dev, global_reward_dev, done_dev, (int)train_mode)
+    if (h->threads <= 256) { if (h->P.help) TSC_STEP(256, true); else TSC_STEP(256, false); }
+    else { if (h->P.help) TSC_STEP(1024, true); else TSC_STEP(1024, false); }
+#undef TSC_STEP
     TSC_HIP(hipGetLastError());
     return 0;
 }

@@ -13,6 +13,16 @@ from deeprl_signal_control_amd.env import VecTrafficEnv
 from deeprl_signal_control_amd.scenario import build_large_grid
 from deeprl_signal_control_amd.trainer import greedy_actions_large_grid
 
+
+
+def phase_names(n):
+    """Labels of the shader-clock stamps of step_kernel (with / without phase A1)."""
+    per = ['A1_%d', 'bar', 'A2_%d', 'bar', 'B%d', 'bar'] if n >= 1 + 5 * 6 + 4 else ['A%d', 'bar', 'B%d', 'bar']
+    names = ['prologue'] + sum([[p % k if '%' in p else p for p in per] for k in range(5)], [])
+    names += ['detectors', 'bar', 'obs', 'reward']
+    return names + ['?'] * max(0, n - len(names))
+
+
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 scn = build_large_grid('ma2c')
@@ -36,9 +46,9 @@ for chunk in ('1',):
     _lib.check(env._L.tsc_env_debug_clock(env._h, 1, st))
     n = st[63]
     d = [st[i + 1] - st[i] for i in range(n - 1)]
-    names = ['prologue'] + sum([['A%d' % k, 'barrier', 'B%d' % k, 'barrier'] for k in range(5)], []) + ['detectors', 'barrier', 'obs', 'reward']
+    names = phase_names(len(d))
     print('workgroup 0 / thread 0 shader-clock cycles per phase (total %d):' % (st[n - 1] - st[0]))
-    print('  ' + ', '.join('%s=%d' % (names[i] if i < len(names) else '?', d[i]) for i in range(len(d))))
+    print('  ' + ', '.join('%s=%d' % (names[i], d[i]) for i in range(len(d)) if names[i] != 'bar'))
     env.close()
 
 # --- cache / interference experiment: how much slower is env_step when other kernels run in between?
@@ -61,7 +71,6 @@ for label, fn in (('nothing between', lambda: None), ('256 MB memset between', l
 import ctypes as C
 st = (C.c_int64 * 64)()
 _l.check(env._L.tsc_env_debug_clock(env._h, 1, None))
-names = ['prologue'] + sum([['A%d' % k, 'bar', 'B%d' % k, 'bar'] for k in range(5)], []) + ['detectors', 'bar', 'obs', 'reward']
 for label, fn in (('nothing between', lambda: None), ('16 MB memset between', lambda: big[:4 << 20].zero_())):
     for i in range(4):
         env.step(acts[i]); fn()
@@ -69,6 +78,7 @@ for label, fn in (('nothing between', lambda: None), ('16 MB memset between', la
     _l.check(env._L.tsc_env_debug_clock(env._h, 1, st))
     n = st[63]
     d = [st[i + 1] - st[i] for i in range(n - 1)]
+    names = phase_names(len(d))
     print('%s: total %d cycles: ' % (label, st[n - 1] - st[0]) + ', '.join('%s=%d' % (names[i], d[i]) for i in range(len(d)) if names[i] != 'bar'))
 
 # --- per-workgroup wall-clock (100 MHz) start/end: is it the blocks or the dispatch that gets slower?
