@@ -53,7 +53,8 @@ def algorithmic_flops(model, rows):
     fc = sum(2 * (nw * fw + nf * fp + nt * ft) for nw, nf, nt in zip(model.n_wave_ls, model.n_f_ls, model.n_w_ls)) * 2
     H, L, G = model.H, model.Lh, model.G
     out = sum(2 * L * (na + 1) for na in model.n_a_ls)
-    return {'fc_gemm': fc * rows, 'zx_gemm': G * 2 * H * 4 * L * rows, 'lstm_fwd': G * 2 * L * 4 * L * rows,
+    fused = fc + G * 2 * H * 4 * L + G * 2 * L * 4 * L + out           # one rollout forward of every tower
+    return {'policy_fwd_fused': fused * rows, 'fc_gemm': fc * rows, 'zx_gemm': G * 2 * H * 4 * L * rows, 'lstm_fwd': G * 2 * L * 4 * L * rows,
             'lstm_bwd': G * 2 * L * 4 * L * rows, 'dwx_gemm': G * 2 * H * 4 * L * rows,
             'dx1_gemm': G * 2 * H * 4 * L * rows, 'dwh_gemm': G * 2 * L * 4 * L * rows, 'dw1_gemm': fc * rows,
             'dwo_gemm': out * rows}
@@ -237,7 +238,9 @@ def main():
             else:
                 rows = E * n_step if dom not in ('fc_gemm', 'zx_gemm', 'lstm_fwd') else None
                 fl = algorithmic_flops(model, E * n_step)
-                if dom in ('fc_gemm', 'zx_gemm', 'lstm_fwd'):
+                if dom == 'policy_fwd_fused':                         # one launch per control step, rows = E
+                    ach = algorithmic_flops(model, E)[dom] / avg_s / 1e12
+                elif dom in ('fc_gemm', 'zx_gemm', 'lstm_fwd'):
                     # launched both per control step (rows = E) and once per update (rows = E * n_step)
                     calls_small = args.steps * (n_step + 1) if dom != 'lstm_fwd' else args.steps * (n_step + 1)
                     tot_fl = fl[dom] * args.steps + algorithmic_flops(model, E)[dom] * (cnt - args.steps)

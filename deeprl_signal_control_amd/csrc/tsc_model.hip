@@ -754,6 +754,129 @@ __global__ void fill_kernel(float *p, long long n, float v) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
+
+// ------------------------------------------------------------------------------------------------
+// LSTM weight gradients of one tower in ONE pass over the n-step batch (tf.gradients of
+// agents/utils.py:88-116 w.r.t. wx, wh, b):   [dWx ; dWh] = [X1 | h_prev]^T dZ,   dbl = colsum(dZ).
+// The output of a tower is only (H+64) x 256, so one workgroup (8 waves, one 32-column strip each, NT = (H+64)/32
+// accumulator tiles per wave) keeps ALL of it in registers and streams its share of the rows exactly once:
+//   * [X1 | h_prev] rows (the A operand, shared by all waves) are fetched once per workgroup with 16-byte loads,
+//     staged through registers into a double-buffered LDS chunk of 16 rows;
+//   * dZ (the B operand, private to a wave's column strip) goes from HBM straight into MFMA operand registers
+//     (a 32x32x2 operand is two coalesced 128-byte row segments), one chunk ahead;
+//   * every global load is unconditional (rows clamped; rows past the split contribute through a zeroed dZ).
+// Deterministic: the row range of a tower is cut into S fixed splits (S x G workgroups ~ one per CU), partial
+// sums go to the workspace and are added in split order by dwxh_reduce_kernel.  Replaces two grouped GEMM
+// launches that each re-read dZ twice.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(512, 1)
+dwxh_kernel(const float *__restrict__ X1, const float *__restrict__ Hp, const float *__restrict__ dZ, long long N, int G,
+            int S, long long rows_per_split, float *__restrict__ ws) {
+    constexpr int HT = NT - 2, H = 32 * HT, KC = 16, LDA = NT * 32 + 4;     // +4: the two k rows of a step hit different banks
+    constexpr int XQ = H / 4, NX = KC * XQ, NQ = NX + KC * (kL / 4), NLD = (NQ + 511) / 512;
+    __shared__ __attribute__((aligned(16))) float As[2][KC][LDA];
+    const int g = blockIdx.x % G, sp = blockIdx.x / G;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
+    const int col0 = 32 * wave;
+    const long long n0 = (long long)sp * rows_per_split;
+    long long n1 = n0 + rows_per_split;
+    if (n1 > N) n1 = N;
+    const float *x1 = X1 + (long long)g * N * H, *hp = Hp + (long long)g * N * kL;
+    const float *dz = dZ + (long long)g * N * kG4 + col0 + li;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bsum = 0.f;
+    // staging slots of this thread: (row in chunk, float4 column, source).  Kept in named scalars: as arrays
+    // the compiler parks the staged float4s in scratch and waits for every global load right after issuing it.
+    static_assert(NLD <= 3, "staging slots");
+    struct Slot { int row, col; bool x, ok; };
+    auto slot = [&](int q) {
+        Slot o;
+        int idx = tid + 512 * q;
+        o.ok = idx < NQ;
+        if (!o.ok) idx = NQ - 1;
+        o.x = idx < NX;
+        const int j = o.x ? idx : idx - NX, w = o.x ? XQ : kL / 4;
+        o.row = j / w; o.col = 4 * (j % w);
+        return o;
+    };
+    const Slot s0 = slot(0), s1 = slot(1), s2 = slot(2);
+    float4 g0, g1, g2;
+    auto fetch1 = [&](const Slot &o, long long row0) {
+        long long row = row0 + o.row;
+        if (row >= n1) row = n1 - 1;
+        const float *src = o.x ? x1 + row * H + o.col : hp + row * kL + o.col;
+        return *reinterpret_cast<const float4 *>(src);
+    };
+    auto commit1 = [&](const Slot &o, int buf, const float4 &v) {
+        if (o.ok) *reinterpret_cast<float4 *>(&As[buf][o.row][(o.x ? 0 : H) + o.col]) = v;
+    };
+#define DWXH_FETCH(row0) do { g0 = fetch1(s0, row0); if (NLD > 1) g1 = fetch1(s1, row0); if (NLD > 2) g2 = fetch1(s2, row0); } while (0)
+#define DWXH_COMMIT(buf) do { commit1(s0, buf, g0); if (NLD > 1) commit1(s1, buf, g1); if (NLD > 2) commit1(s2, buf, g2); } while (0)
+    float bcur[KC / 2], bnxt[KC / 2];
+    auto fetch_b = [&](float *b, long long row0) {
+#pragma unroll
+        for (int ks = 0; ks < KC / 2; ++ks) {
+            const long long row = row0 + 2 * ks + kh;
+            const float z = dz[(row < n1 ? row : n1 - 1) * kG4];
+            b[ks] = row < n1 ? z : 0.f;
+        }
+    };
+    if (n0 < n1) {
+        DWXH_FETCH(n0); fetch_b(bcur, n0);
+        DWXH_COMMIT(0);
+        DWXH_FETCH(n0 + KC);
+        __syncthreads();
+        int buf = 0;
+        for (long long row = n0; row < n1; row += KC, buf ^= 1) {
+            fetch_b(bnxt, row + KC);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KC / 2; ++ks) {
+                float av[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) av[t] = As[buf][2 * ks + kh][32 * t + li];
+                bsum += bcur[ks];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bcur[ks], acc[t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            DWXH_COMMIT(buf ^ 1);                               // chunk row+KC (fetched one iteration ago)
+            DWXH_FETCH(row + 2 * KC);
+#pragma unroll
+            for (int ks = 0; ks < KC / 2; ++ks) bcur[ks] = bnxt[ks];
+            __syncthreads();
+        }
+    }
+    float *w = ws + ((long long)sp * G + g) * ((long long)(NT * 32 + 1) * kG4);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            w[(long long)row * kG4 + col0 + li] = acc[t][r];
+        }
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (kh == 0) w[(long long)NT * 32 * kG4 + col0 + li] = bsum;
+#undef DWXH_FETCH
+#undef DWXH_COMMIT
+}
+
+// grads[g][oWx .. oWx + (H+64+1)*256) = sum over splits, in split order
+__global__ void dwxh_reduce_kernel(const float *__restrict__ ws, int G, int S, long long per, float *__restrict__ grads,
+                                   long long stride, long long off) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per * G) return;
+    const long long g = i / per, j = i % per;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += ws[((long long)s * G + g) * per + j];
+    grads[g * stride + off + j] = acc;
+}
+
 struct tsc_model {
     Layout lay;
     int E, T, device;
@@ -774,6 +897,7 @@ struct tsc_model {
     size_t ws_floats, wsc_floats;
     size_t lds_fwd, lds_bwd, lds_fused;
     int fused_fwd;
+    int fused_dw;               // dWx | dWh | dbl in one pass (dwxh_kernel)
     int cached_next;            // next rollout slot whose activations the fused forward will cache; T = all cached
     long long *dbg;
     long long nparam;
@@ -880,6 +1004,8 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     m->lds_fused = sizeof(float) * (size_t)(L.H + 64) * kXLd;
     m->fused_fwd = !L.fc && (L.H % 32 == 0) && (L.SMAX <= 64) && (L.SMAX % 4 == 0) && ((L.H + 64) % 8 == 0) && m->lds_fused <= 160 * 1024;
     if (const char *ev = getenv("TSC_UNFUSED_FWD")) if (atoi(ev)) m->fused_fwd = 0;
+    m->fused_dw = !L.fc && (L.H == 224 || L.H == 160);
+    if (const char *ev = getenv("TSC_UNFUSED_DW")) if (atoi(ev)) m->fused_dw = 0;
     if (m->fused_fwd)
         TSC_HIP(hipFuncSetAttribute((const void *)policy_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fused));
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((m->nparam + 255) / 256)), dim3(256), 0, 0, m->ms, m->nparam, 1.0f);
@@ -1082,10 +1208,31 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
     // dWo = Hh^T dL (+ dbo) ; dWh = Hp^T dZ (+ dbl) ; dWx = X1^T dZ
     if (gemm(m, tsc::KID_DWO_GEMM, true, tsc::EPI_NONE, (int)G, kL, kOut, (int)N, m->Hh, N * kL, kL, 1, m->dL, N * kOut, kOut, g + L.oWo,
              L.stride, kOut, nullptr, 0, nullptr, 0, 0, nullptr, 0, g + L.obo, L.stride)) return tsc::fail("gemm failed");
+    const int NT = (L.H + kL) / 32;
+    int S = 256 / (int)G;                       // ~ one workgroup per CU
+    if (S < 1) S = 1;
+    const long long per = (long long)(NT * 32 + 1) * kG4;
+    if (m->fused_dw && (size_t)((long long)S * G * per) <= m->ws_floats && L.oWh == L.oWx + (long long)L.H * kG4 &&
+        L.obl == L.oWh + (long long)kL * kG4) {
+        long long rps = (N + S - 1) / S;
+        rps += rps & 1;                           // a k-step is two rows
+        {
+            tsc::ProfScope ps(tsc::KID_DWX_GEMM, m->stream);
+            if (NT == 9) hipLaunchKernelGGL(dwxh_kernel<9>, dim3((unsigned)(S * G)), dim3(512), 0, st, m->X1, m->Hp, m->Z, N, (int)G, S, rps, m->ws);
+            else hipLaunchKernelGGL(dwxh_kernel<7>, dim3((unsigned)(S * G)), dim3(512), 0, st, m->X1, m->Hp, m->Z, N, (int)G, S, rps, m->ws);
+        }
+        {
+            tsc::ProfScope ps(tsc::KID_DWH_GEMM, m->stream);
+            hipLaunchKernelGGL(dwxh_reduce_kernel, dim3((unsigned)((per * G + 255) / 256)), dim3(256), 0, st, m->ws, (int)G, S, per, g,
+                               L.stride, L.oWx);
+        }
+        TSC_HIP(hipGetLastError());
+    } else {
     if (gemm(m, tsc::KID_DWH_GEMM, true, tsc::EPI_NONE, (int)G, kL, kG4, (int)N, m->Hp, N * kL, kL, 1, m->Z, N * kG4, kG4, g + L.oWh, L.stride,
              kG4, nullptr, 0, nullptr, 0, 0, nullptr, 0, g + L.obl, L.stride)) return tsc::fail("gemm failed");
     if (gemm(m, tsc::KID_DWX_GEMM, true, tsc::EPI_NONE, (int)G, L.H, kG4, (int)N, m->X1, N * L.H, L.H, 1, m->Z, N * kG4, kG4, g + L.oWx, L.stride,
              kG4, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, 0)) return tsc::fail("gemm failed");
+    }
     // dX1 = (dZ Wx^T) * relu'(X1), in place over X1
     if (gemm(m, tsc::KID_DX1_GEMM, false, tsc::EPI_MASK_POS, (int)G, (int)N, L.H, kG4, m->Z, N * kG4, kG4, 1, m->WxT, (long long)L.H * kG4, L.H,
              m->X1, N * L.H, L.H, nullptr, 0, m->X1, N * L.H, L.H, nullptr, 0, nullptr, 0)) return tsc::fail("gemm failed");
