@@ -75,3 +75,12 @@ struct ProfScope {
 };
 
 }  // namespace tsc
+
+// base + 32-bit byte offset: with a workgroup-uniform base the compiler uses the scalar-base addressing mode
+// (one VGPR per address instead of a 64-bit pair that tends to be spilled when many addresses are live)
+template <class T> __device__ __forceinline__ T ldg(const T *base, unsigned byte_off) {
+    return *(const T *)((const char *)base + byte_off);
+}
+template <class T> __device__ __forceinline__ void stg(T *base, unsigned byte_off, T v) {
+    *(T *)((char *)base + byte_off) = v;
+}

@@ -83,14 +83,6 @@ __device__ __forceinline__ uint32_t hash32(uint32_t seed, uint32_t route, uint32
 }
 __device__ __forceinline__ float u01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
 
-// base + 32-bit byte offset: lets the compiler use the scalar-base addressing mode (one VGPR per address)
-template <class T> __device__ __forceinline__ T ldg(const T *base, unsigned byte_off) {
-    return *(const T *)((const char *)base + byte_off);
-}
-template <class T> __device__ __forceinline__ void stg(T *base, unsigned byte_off, T v) {
-    *(T *)((char *)base + byte_off) = v;
-}
-
 // one car-following evaluation against one leader (DESIGN.md "follow")
 __device__ __forceinline__ float follow(float v, float v0, bool has_lead, float g, float vl, float s0gap) {
     float ratio = v / v0;

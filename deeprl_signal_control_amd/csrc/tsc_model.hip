@@ -460,7 +460,8 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
                         int E, int n_tiles, float *__restrict__ pi_out, float *__restrict__ v_out, int *action_out,
                         unsigned long long seed, unsigned long long step, long long *dbg,
                         // activation cache for the update (slot tslot of the n_step batch; tslot < 0: off)
-                        int tslot, long long Ntot, float *X1c, float *Zc, float *Hhc, float *Ccc, float *Hpc) {
+                        int tslot, long long Ntot, float *X1c, float *Zc, float *Hhc, float *Ccc, float *Hpc,
+                        const float *__restrict__ Wg) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float *XH = (float *)smem_raw;
     const bool stamp = dbg && blockIdx.x == 8 && threadIdx.x == 0;      // a block that does real work
@@ -567,16 +568,20 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][r] = bv;
         }
-        const float *B = P + lay.oWx;                  // [H + 64][256] (Wx then Wh)
+        // B = [Wx ; Wh] in the gate-interleaved copy Wg[g][H + 64][64 units][4 gates]: one 16-byte load per k row
+        const float *B = Wg + (long long)g * (H + 64) * kG4;
         constexpr int CS = 8;                          // k-steps (2 k rows each) per register chunk
-        const int nchunk = (H + 64) / (2 * CS);
+        const int nchunk = (H + 64) / (2 * CS);        // even: H % 32 == 0
+        const unsigned bb = (unsigned)(kh * kG4 + 4 * j) * 4u;
         float bA[CS][4], bB[CS][4];
+        // unconditional loads only (the last prefetch re-reads the last chunk): the waits stay counted
         auto loadB = [&](float (*dst)[4], int chunk) {
-            const float *src = B + (long long)(chunk * 2 * CS + kh) * kG4 + j;
+            const float *src = B + (long long)chunk * (2 * CS * kG4);       // uniform
 #pragma unroll
-            for (int s2 = 0; s2 < CS; ++s2)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) dst[s2][q] = src[(long long)(2 * s2) * kG4 + 64 * q];
+            for (int s2 = 0; s2 < CS; ++s2) {
+                const float4 w4 = ldg((const float4 *)src, bb + s2 * (2u * kG4 * 4u));
+                dst[s2][0] = w4.x; dst[s2][1] = w4.y; dst[s2][2] = w4.z; dst[s2][3] = w4.w;
+            }
         };
         auto compute = [&](float (*bv)[4], int chunk) {
             const float *As = XH + (chunk * 2 * CS + kh) * kXLd + r0 + li;
@@ -589,10 +594,10 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
         };
         loadB(bA, 0);
         for (int ch = 0; ch < nchunk; ch += 2) {
-            if (ch + 1 < nchunk) loadB(bB, ch + 1);
+            loadB(bB, ch + 1);
             compute(bA, ch);
-            if (ch + 2 < nchunk) loadB(bA, ch + 2);
-            if (ch + 1 < nchunk) compute(bB, ch + 1);
+            loadB(bA, ch + 2 < nchunk ? ch + 2 : nchunk - 1);
+            compute(bB, ch + 1);
         }
     }
     FSTAMP();
@@ -746,6 +751,18 @@ __global__ void transpose_wx_kernel(const float *params, Layout lay, float *WxT)
     WxT[i] = params[(long long)g * lay.stride + lay.oWx + (long long)h * lay.NZ + c];
 }
 
+// Wg[g][k][4*u + q] = [Wx ; Wh][g][k][64*q + u]: the four gates of a unit side by side, so that the fused rollout
+// forward fetches a lane's four B operands (one per gate tile) with ONE 16-byte load.  Dword loads reach only a
+// fraction of the L2 rate, and the weight stream out of L2 is what bounds that kernel.
+__global__ void interleave_gates_kernel(const float *params, Layout lay, float *Wg) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per = (long long)(lay.H + kL) * kG4;
+    if (i >= per * lay.G) return;
+    const long long g = i / per, r = i % per;
+    const int k = (int)(r / kG4), c = (int)(r % kG4), u = c >> 2, q = c & 3;
+    Wg[i] = params[g * lay.stride + lay.oWx + (long long)k * kG4 + 64 * q + u];
+}
+
 __global__ void fill_kernel(float *p, long long n, float v) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -886,6 +903,8 @@ struct tsc_model {
     int *n_act;
     int16_t *rowrange;          // [A][SMAX][2]
     float *params, *grads, *ms, *WxT;
+    float *Wg;                  // gate-interleaved copy of [Wx ; Wh] for the fused forward (interleave_gates_kernel)
+    int wg_dirty;
     float *state_fw, *state_bw, *state_tmp;     // [G][E][128]
     // rollout (on-policy buffer)
     float *r_obs; int *r_act; double *r_rew; float *r_val; uint8_t *r_done;   // done [T+1][E]
@@ -983,6 +1002,8 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     const long long E = n_env, T = m->T, N = E * T, G = L.G, A = L.A;
     MALLOC(m->params, float, m->nparam); MALLOC(m->grads, float, m->nparam); MALLOC(m->ms, float, m->nparam);
     MALLOC(m->WxT, float, G * L.H * kG4);
+    MALLOC(m->Wg, float, G * (L.H + kL) * kG4);
+    m->wg_dirty = 1;
     MALLOC(m->state_fw, float, G * E * 2 * kL); MALLOC(m->state_bw, float, G * E * 2 * kL);
     MALLOC(m->state_tmp, float, G * E * 2 * kL);
     MALLOC(m->r_obs, float, N * A * L.SMAX); MALLOC(m->r_act, int, N * A); MALLOC(m->r_rew, double, N * A);
@@ -1039,6 +1060,7 @@ int tsc_model_layout(tsc_model *m, int64_t out[12]) {
 int tsc_model_set_params(tsc_model *m, const float *h) {
     if (!m || !h) return tsc::fail("tsc_model_set_params: bad arguments");
     m->cached_next = -1;                              // activations cached under the old parameters are stale
+    m->wg_dirty = 1;
     TSC_HIP(hipStreamSynchronize(m->stream));
     TSC_HIP(hipMemcpy(m->params, h, sizeof(float) * m->nparam, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((m->nparam + 255) / 256)), dim3(256), 0, m->stream, m->ms, m->nparam, 1.0f);
@@ -1086,11 +1108,16 @@ static int model_forward(tsc_model *m, const float *obs, const uint8_t *done, fl
     }
     if (m->fused_fwd) {
         const int n_tiles = (E + 63) / 64, per_xcd = (L.G + 7) / 8;
+        if (m->wg_dirty) {                                  // parameters changed since the interleaved copy was made
+            const long long tot = (long long)L.G * (L.H + kL) * kG4;
+            hipLaunchKernelGGL(interleave_gates_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, m->stream, m->params, L, m->Wg);
+            m->wg_dirty = 0;
+        }
         tsc::ProfScope ps(tsc::KID_FUSED_FWD, m->stream);
         hipLaunchKernelGGL(policy_fwd_fused_kernel, dim3(8 * per_xcd * n_tiles), dim3(256), m->lds_fused, m->stream, m->params,
                            L, m->n_act, obs, done, m->state_fw, (int)advance, E, n_tiles, pi, v, action,
                            (unsigned long long)seed, (unsigned long long)step, m->dbg, (int)tslot, (long long)m->T * E,
-                           m->X1, m->Z, m->Hh, m->Cc, m->Hp);
+                           m->X1, m->Z, m->Hh, m->Cc, m->Hp, m->Wg);
         ps.stop();
         TSC_HIP(hipGetLastError());
         return 0;
@@ -1264,6 +1291,7 @@ int tsc_model_apply_grads(tsc_model *m, double lr, double grad_scale, double *st
                        per_agent, m->nparam, m->norm2, (float)grad_scale, (float)m->max_norm, (float)lr, (float)m->alpha,
                        (float)m->eps);
     ps11.stop();
+    m->wg_dirty = 1;
     TSC_HIP(hipGetLastError());
     // states_bw <- states_fw (policies.py:153); buffer.reset(dones[-1]) (utils.py:227)
     TSC_HIP(hipMemcpyAsync(m->state_bw, m->state_fw, sizeof(float) * (size_t)L.G * m->E * 2 * kL, hipMemcpyDeviceToDevice, st));

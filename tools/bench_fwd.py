@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Timing / phase breakdown of the fused rollout forward (tsc_model_forward)."""
+"""Timing / phase breakdown of the fused rollout forward as the trainer runs it
+(tsc_model_forward_sample with the activation cache on)."""
 import ctypes as C
 import os
 import sys
@@ -22,17 +23,17 @@ done = torch.zeros(E, dtype=torch.uint8, device='cuda')
 big = torch.zeros(16 << 20, device='cuda')
 for label, fn in (('back to back', lambda: None), ('64 MB memset between', lambda: big.zero_())):
     for _ in range(5):
-        m.forward(obs, done, 'pv'); fn()
+        m.forward_sample(obs, done, cache=True); fn()
     _lib.profile(enable=True, reset=True)
     for _ in range(50):
-        m.forward(obs, done, 'pv'); fn()
+        m.forward_sample(obs, done, cache=True); fn()
     p = _lib.profile(); _lib.profile(enable=False)
     print('fused forward %s: %.1f us' % (label, 1e3 * p['policy_fwd_fused'][0] / p['policy_fwd_fused'][1]))
     nblk = 8 * ((m.G + 7) // 8) * ((E + 63) // 64)
     buf = (C.c_int64 * (64 + 2 * nblk))()
     _lib.check(m._L.tsc_model_debug_clock(m._h, 1, None, 0))
     for _ in range(3):
-        m.forward(obs, done, 'pv'); fn()
+        m.forward_sample(obs, done, cache=True); fn()
     _lib.check(m._L.tsc_model_debug_clock(m._h, 1, buf, 64 + 2 * nblk))
     n = buf[63]
     names = ['obs->LDS', 'fc (X1)', 'state', 'gates MFMA', 'barrier', 'cell', 'head']
