@@ -178,100 +178,99 @@ __global__ void __launch_bounds__(256, PF ? 1 : 2) lstm_fwd_kernel(const float *
 //   Cc  [G][N][64]  c_t;  c_{t-1} = Cc[t-1] or state_bw, masked by done[t]
 //   dH  [G][N][64]  gradient arriving at h_t from the head
 // per step: dz -> LDS (k-major) -> dh_{t-1} = dz * Wh^T on the MFMA (K = 256).
+// Wh^T is the STATIONARY operand: a lane's 128 B values (its unit's row of Wh, one half of the gate columns --
+// the k index of an MFMA step is free to choose, here k = 128*kh + s) stay in registers for all T steps, so
+// LDS holds only the dz tile (70 KB) and two workgroups share a CU: the step is a latency chain
+// (loads -> gate math -> barrier -> 128 MFMAs -> barrier) that one workgroup per CU cannot hide.
+// The step inputs are fetched four accumulator rows at a time (no next-step prefetch: the registers hold Wh^T).
 // ------------------------------------------------------------------------------------------------
-constexpr int kWtLd = 64 + 4;
 constexpr int kDzLd = 64 + 4;
 
-__global__ void __launch_bounds__(256) lstm_bwd_kernel(const float *__restrict__ params, Layout lay, float *Z,
-                                                      const float *Cc, const float *state_bw, const float *dH,
-                                                      const uint8_t *done, int T, int E) {
+__global__ void __launch_bounds__(256, 2) lstm_bwd_kernel(const float *__restrict__ params, Layout lay, float *Z,
+                                                         const float *Cc, const float *state_bw, const float *dH,
+                                                         const uint8_t *done, int T, int E) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float *WhT = (float *)smem_raw;                 // [256 k = gate col][kWtLd n = unit]
-    float *dzs = WhT + kG4 * kWtLd;                 // [256 k][kDzLd m = env]
+    float *dzs = (float *)smem_raw;                 // [256 k = gate col][kDzLd m = env]
     const int g = blockIdx.x, e0 = blockIdx.y * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = 32 * (wave & 1), j0 = 32 * (wave >> 1), li = lane & 31, kh = lane >> 5;
-    const float *Wh = params + (long long)g * lay.stride + lay.oWh;
-    for (int i = tid; i < 64 * kG4; i += 256) WhT[(i % kG4) * kWtLd + (i / kG4)] = Wh[i];
-    const long long N = (long long)T * E;
     const int j = j0 + li;
-    float dh_rec[16], dc_rec[16];
-    int erow[16];
+    const long long N = (long long)T * E;
+    float bw[128];                                  // Wh[j][128*kh .. 128*kh+127] = B[k = 128*kh + s][n = j]
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(params + (long long)g * lay.stride + lay.oWh + (long long)j * kG4 + 128 * kh);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        erow[r] = r0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        dh_rec[r] = 0.f; dc_rec[r] = 0.f;
-    }
-    // inputs of the CURRENT step live in registers; those of step t-1 are prefetched while the MFMAs of
-    // step t run (one workgroup per CU: nothing else would hide the HBM latency)
-    float gi[16], gf[16], go[16], gu[16], c_cur[16], c_prv[16], dh_in[16], keepv[16];
-    float ni[16], nf[16], no_[16], nu[16], n_prv[16], ndh[16], nkeep[16];
-    auto load_step = [&](int t, float *li_, float *lf_, float *lo_, float *lu_, float *lprv, float *ldh, float *lkeep) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int e = e0 + erow[r];
-            if (e < E) {
-                const long long n = (long long)g * N + (long long)t * E + e;
-                li_[r] = Z[n * kG4 + j]; lf_[r] = Z[n * kG4 + 64 + j]; lo_[r] = Z[n * kG4 + 128 + j]; lu_[r] = Z[n * kG4 + 192 + j];
-                ldh[r] = dH[n * kL + j];
-                lprv[r] = t > 0 ? Cc[(n - E) * kL + j] : state_bw[((long long)g * E + e) * 2 * kL + j];
-                lkeep[r] = 1.0f - (float)done[(long long)t * E + e];
-            } else {
-                li_[r] = lf_[r] = lo_[r] = lu_[r] = ldh[r] = lprv[r] = 0.f; lkeep[r] = 0.f;
-            }
+        for (int q = 0; q < 32; ++q) {
+            const float4 w4 = src[q];
+            bw[4 * q] = w4.x; bw[4 * q + 1] = w4.y; bw[4 * q + 2] = w4.z; bw[4 * q + 3] = w4.w;
         }
-    };
-    load_step(T - 1, gi, gf, go, gu, c_prv, dh_in, keepv);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int e = e0 + erow[r];
-        c_cur[r] = e < E ? Cc[((long long)g * N + (long long)(T - 1) * E + e) * kL + j] : 0.f;
     }
-    __syncthreads();
-    for (int t = T - 1; t >= 0; --t) {
+    float dh_rec[16], dc_rec[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int e = e0 + erow[r];
-            float di = 0.f, df = 0.f, dog = 0.f, du = 0.f;
-            if (e < E) {
-                const long long n = (long long)g * N + (long long)t * E + e;
-                const float ig = gi[r], fg = gf[r], og = go[r], ug = gu[r];
-                const float cn = c_cur[r];
-                const float keep = keepv[r];
-                const float cp = c_prv[r] * keep;
-                const float dh = dh_in[r] + dh_rec[r];
-                const float tc = tanhf_(cn);
-                dog = dh * tc * og * (1.0f - og);
-                const float dc = dh * og * (1.0f - tc * tc) + dc_rec[r];
-                di = dc * ug * ig * (1.0f - ig);
-                df = dc * cp * fg * (1.0f - fg);
-                du = dc * ig * (1.0f - ug * ug);
-                dc_rec[r] = dc * fg * keep;
-                Z[n * kG4 + j] = di; Z[n * kG4 + 64 + j] = df; Z[n * kG4 + 128 + j] = dog; Z[n * kG4 + 192 + j] = du;
+    for (int r = 0; r < 16; ++r) { dh_rec[r] = 0.f; dc_rec[r] = 0.f; }
+    // workgroup-uniform bases + 32-bit lane offsets (rows past E are clamped for the loads and never stored)
+    const float *zg = Z + (long long)g * N * kG4, *cg = Cc + (long long)g * N * kL, *hg = dH + (long long)g * N * kL;
+    const float *sg = state_bw + (long long)g * E * 2 * kL;
+    for (int t = T - 1; t >= 0; --t) {
+        const long long nt = (long long)t * E;
+        const float *zt = zg + nt * kG4, *ct = cg + nt * kL, *ht = hg + nt * kL;
+        const float *cp_base = t > 0 ? ct - (long long)E * kL : sg;         // c_{t-1}: Cc[t-1] ([e][64]) or the state ([e][128])
+        const unsigned cp_ld = t > 0 ? kL : 2 * kL;
+        const uint8_t *dt = done + nt;
+        unsigned keepbits = 0;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            float gi[4], gf[4], go[4], gu[4], cc[4], cpv[4], dhi[4], kp[4];
+            int er[4];
+            int zq = 0;
+            asm volatile("" : "+v"(zq));                // lane offsets are formed here every step, not hoisted out of the t loop and spilled
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * qd + q;
+                er[q] = r0 + (r & 3) + 8 * (r >> 2) + 4 * kh + zq;
+                const int e = e0 + er[q] < E ? e0 + er[q] : E - 1;
+                const unsigned oz = (unsigned)(e * kG4 + j) * 4u, oc = (unsigned)(e * kL + j) * 4u;
+                gi[q] = ldg(zt, oz); gf[q] = ldg(zt, oz + 256u); go[q] = ldg(zt, oz + 512u); gu[q] = ldg(zt, oz + 768u);
+                cc[q] = ldg(ct, oc); dhi[q] = ldg(ht, oc);
+                cpv[q] = ldg(cp_base, (unsigned)(e * cp_ld + j) * 4u);
+                kp[q] = 1.0f - (float)dt[e];
             }
-            dzs[(j) * kDzLd + erow[r]] = di;
-            dzs[(64 + j) * kDzLd + erow[r]] = df;
-            dzs[(128 + j) * kDzLd + erow[r]] = dog;
-            dzs[(192 + j) * kDzLd + erow[r]] = du;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * qd + q;
+                const float ig = gi[q], fg = gf[q], og = go[q], ug = gu[q];
+                const float keep = kp[q];
+                const float cp = cpv[q] * keep;
+                const float dh = dhi[q] + dh_rec[r];
+                const float tc = tanhf_(cc[q]);
+                const float dog = dh * tc * og * (1.0f - og);
+                const float dc = dh * og * (1.0f - tc * tc) + dc_rec[r];
+                const float di = dc * ug * ig * (1.0f - ig);
+                const float df = dc * cp * fg * (1.0f - fg);
+                const float du = dc * ig * (1.0f - ug * ug);
+                dc_rec[r] = dc * fg * keep;
+                if (keep != 0.f) keepbits |= 1u << r;
+                if (e0 + er[q] < E) {
+                    float *zw = Z + ((long long)g * N + nt) * kG4;
+                    const unsigned oz = (unsigned)((e0 + er[q]) * kG4 + j) * 4u;
+                    stg(zw, oz, di); stg(zw, oz + 256u, df); stg(zw, oz + 512u, dog); stg(zw, oz + 768u, du);
+                }
+                dzs[(j) * kDzLd + er[q]] = di;
+                dzs[(64 + j) * kDzLd + er[q]] = df;
+                dzs[(128 + j) * kDzLd + er[q]] = dog;
+                dzs[(192 + j) * kDzLd + er[q]] = du;
+            }
+            __builtin_amdgcn_sched_barrier(0);          // keep the quarters apart: their loads would all be hoisted (and spilled)
         }
         __syncthreads();
-        if (t > 0) load_step(t - 1, ni, nf, no_, nu, n_prv, ndh, nkeep);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 8
-        for (int kk = 0; kk < kG4; kk += 2) {
-            const float a = dzs[(kk + kh) * kDzLd + r0 + li];
-            const float b = WhT[(kk + kh) * kWtLd + j];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
+        const float *As = dzs + (128 * kh) * kDzLd + r0 + li;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            dh_rec[r] = acc[r] * keepv[r];
-            c_cur[r] = c_prv[r];                                // Cc[t-1] (unmasked) becomes the current cell
-            gi[r] = ni[r]; gf[r] = nf[r]; go[r] = no_[r]; gu[r] = nu[r];
-            c_prv[r] = n_prv[r]; dh_in[r] = ndh[r]; keepv[r] = nkeep[r];
-        }
+        for (int s2 = 0; s2 < 128; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[s2 * kDzLd], bw[s2], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh_rec[r] = (keepbits >> r) & 1u ? acc[r] : 0.f;
         __syncthreads();
     }
 }
@@ -1016,7 +1015,7 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     m->ws_floats = (size_t)48 << 20; m->wsc_floats = (size_t)1 << 20;      // 192 MiB + 4 MiB
     MALLOC(m->ws, float, m->ws_floats); MALLOC(m->wsc, float, m->wsc_floats);
     m->lds_fwd = sizeof(float) * (64 * kWhLd + 64 * kHsLd);
-    m->lds_bwd = sizeof(float) * (kG4 * kWtLd + kG4 * kDzLd);
+    m->lds_bwd = sizeof(float) * (kG4 * kDzLd);
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fwd));
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fwd));
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bwd));
