@@ -893,6 +893,179 @@ __global__ void dwxh_reduce_kernel(const float *__restrict__ ws, int G, int S, l
     grads[g * stride + off + j] = acc;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// First-layer gradients of one tower in ONE pass over the n-step batch, without ever writing dX1:
+//   dX1 = (dZ Wx^T) * relu'(X1)   (32-row chunks, never leaves the registers)
+//   dW1 = obs^T dX1,  db1 = colsum(dX1)        (agents/utils.py:66-74 through tf.gradients)
+// Work split of the 8-wave workgroup (one per CU, S x G workgroups, each a fixed row range of one tower):
+//   * waves 0..NCT-1 each own one 32-column strip of X1.  Their slice of Wx^T (256 x 32) is the STATIONARY MFMA
+//     operand: 128 registers per lane, loaded once.  Per chunk: 128 MFMAs (A = the dZ chunk, k-major in LDS),
+//     mask with X1 > 0, then the masked accumulator tile is fed STRAIGHT back as the B operand of the dW1 product
+//     (accumulator row (r, lane half) = contraction index of step r), A = the obs chunk from LDS: 32 more MFMAs;
+//   * the remaining wave(s) are LOADERS: they fetch the next dZ / obs chunk with 16-byte loads while the others
+//     compute, and scatter it into the other LDS buffer (k-major for dZ, so the MFMA reads are conflict-free).
+// Replaces the dX1 GEMM (second column tile 25 % empty, dZ read twice), the 11 GB dX1 round trip through HBM and
+// the dW1 GEMM.  Deterministic: partial dW1 / db1 per workgroup, added in split order by dx1w1_reduce_kernel,
+// which also applies the structural zeros of the block-diagonal first layer.
+// ------------------------------------------------------------------------------------------------
+constexpr int kD1Ld = 36;        // dZ chunk [256 k][32 rows + 4]
+constexpr int kObLd = 68;        // obs chunk [32 rows][64 features + 4]
+
+template <int NCT>   // H / 32
+__global__ void __launch_bounds__(512, 1)
+dx1w1_kernel(const float *__restrict__ dZ, const float *__restrict__ X1, const float *__restrict__ WxT,
+             const float *__restrict__ obs, long long N, int G, int S, long long rows_per_split, int A, int SMAX,
+             float *__restrict__ ws) {
+    constexpr int H = 32 * NCT, NLT = 512 - 64 * NCT;           // loader threads
+    constexpr int NZQ = 32 * 64, NOQ = 32 * 16;                 // float4s per chunk: dZ (32 x 256), obs (32 x 64, zero padded)
+    constexpr int NQ = (NZQ + NOQ + NLT - 1) / NLT;             // staging slots per loader thread
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *Az = (float *)smem_raw;                              // [2][256][kD1Ld]
+    float *Ob = Az + 2 * kG4 * kD1Ld;                           // [2][32][kObLd]
+    const int g = blockIdx.x % G, sp = blockIdx.x / G, a = g >> 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
+    const long long n0 = (long long)sp * rows_per_split;
+    long long n1 = n0 + rows_per_split;
+    if (n1 > N) n1 = N;
+    const float *dz = dZ + (long long)g * N * kG4, *x1 = X1 + (long long)g * N * H;
+    const long long AS = (long long)A * SMAX;
+    const int sq = SMAX >> 2;                                   // float4s per obs row
+    float *w = ws + ((long long)sp * G + g) * ((long long)65 * H);
+    if (wave >= NCT) {
+        // ---------------- loader waves ----------------
+        const int lt = tid - 64 * NCT;
+        // sub-batches of 8 float4s, software-pipelined (load batch b+1, then scatter batch b): a chunk's 40 slots
+        // as one register array end up in scratch
+        constexpr int SB = 8, NB = (NQ + SB - 1) / SB;
+        auto load1 = [&](int idx, long long row0) {
+            if (idx >= NZQ + NOQ) idx = NZQ + NOQ - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < NZQ) {                                 // dZ: row fastest, so the k-major LDS scatter is conflict-free
+                long long row = row0 + (idx & 31);
+                if (row >= n1) row = n1 - 1;
+                v = *reinterpret_cast<const float4 *>(dz + row * kG4 + 4 * (idx >> 5));
+            } else {
+                const int j = idx - NZQ, c4 = j & 15;
+                long long row = row0 + (j >> 4);
+                if (row >= n1) row = n1 - 1;
+                if (c4 < sq) v = *reinterpret_cast<const float4 *>(obs + row * AS + (long long)a * SMAX + 4 * c4);
+            }
+            return v;
+        };
+        auto store1 = [&](int idx, int buf, const float4 &v) {
+            if (idx < NZQ) {
+                float *d = Az + ((long long)buf * kG4 + 4 * (idx >> 5)) * kD1Ld + (idx & 31);
+                d[0] = v.x; d[kD1Ld] = v.y; d[2 * kD1Ld] = v.z; d[3 * kD1Ld] = v.w;
+            } else if (idx < NZQ + NOQ) {
+                const int j = idx - NZQ;
+                *reinterpret_cast<float4 *>(Ob + ((long long)buf * 32 + (j >> 4)) * kObLd + 4 * (j & 15)) = v;
+            }
+        };
+        // stage chunk [row0, row0 + 32) into LDS buffer buf
+        auto stage = [&](long long row0, int buf) {
+            float4 c0, c1, c2, c3, c4, c5, c6, c7, d0, d1, d2, d3, d4, d5, d6, d7;
+#define TSC_LD8(p, b) do { const int i0 = lt + NLT * SB * (b); p##0 = load1(i0, row0); p##1 = load1(i0 + NLT, row0); p##2 = load1(i0 + 2 * NLT, row0); p##3 = load1(i0 + 3 * NLT, row0); p##4 = load1(i0 + 4 * NLT, row0); p##5 = load1(i0 + 5 * NLT, row0); p##6 = load1(i0 + 6 * NLT, row0); p##7 = load1(i0 + 7 * NLT, row0); } while (0)
+#define TSC_ST8(p, b) do { const int i0 = lt + NLT * SB * (b); store1(i0, buf, p##0); store1(i0 + NLT, buf, p##1); store1(i0 + 2 * NLT, buf, p##2); store1(i0 + 3 * NLT, buf, p##3); store1(i0 + 4 * NLT, buf, p##4); store1(i0 + 5 * NLT, buf, p##5); store1(i0 + 6 * NLT, buf, p##6); store1(i0 + 7 * NLT, buf, p##7); } while (0)
+            TSC_LD8(c, 0);
+#pragma unroll
+            for (int b2 = 0; b2 < NB; b2 += 2) {
+                if (b2 + 1 < NB) TSC_LD8(d, b2 + 1);
+                TSC_ST8(c, b2);
+                if (b2 + 2 < NB) TSC_LD8(c, b2 + 2);
+                if (b2 + 1 < NB) TSC_ST8(d, b2 + 1);
+            }
+#undef TSC_LD8
+#undef TSC_ST8
+        };
+        if (n0 < n1) {
+            stage(n0, 0);
+            __syncthreads();
+            int buf = 0;
+            for (long long row = n0; row < n1; row += 32, buf ^= 1) {
+                stage(row + 32, buf ^ 1);                   // while the MFMA waves work on `buf`
+                __syncthreads();
+            }
+        }
+        return;
+    }
+    // ---------------- MFMA waves: column strip [32 * wave, 32 * wave + 32) ----------------
+    const int col = 32 * wave + li;
+    float bw[128];                                              // Wx^T[k = 128 * kh + s][col]
+    {
+        const float *src = WxT + (long long)g * kG4 * H + (long long)(128 * kh) * H + col;
+#pragma unroll
+        for (int s2 = 0; s2 < 128; ++s2) bw[s2] = src[(long long)s2 * H];
+    }
+    f32x16 accW[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accW[mt][r] = 0.f;
+    float bsum = 0.f;
+    if (n0 < n1) {
+        __syncthreads();
+        int buf = 0;
+        for (long long row = n0; row < n1; row += 32, buf ^= 1) {
+            // relu mask of this chunk: in flight under the 128 MFMAs
+            float xm[16];
+            int zq = 0;
+            asm volatile("" : "+v"(zq));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                long long rr = row + ((r & 3) + 8 * (r >> 2) + 4 * kh + zq);
+                if (rr >= n1) rr = n1 - 1;
+                xm[r] = x1[rr * H + col];
+            }
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float *As = Az + ((long long)buf * kG4 + 128 * kh) * kD1Ld + li;
+#pragma unroll
+            for (int s2 = 0; s2 < 128; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[s2 * kD1Ld], bw[s2], acc, 0, 0, 0);
+            const float *Os = Ob + (long long)buf * 32 * kObLd + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rho = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const float d = (xm[r] > 0.f && row + rho < n1) ? acc[r] : 0.f;        // dX1[row + rho][col]
+                bsum += d;
+                accW[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[rho * kObLd], d, accW[0], 0, 0, 0);
+                accW[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[rho * kObLd + 32], d, accW[1], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kh;       // obs feature
+            w[(long long)f * H + col] = accW[mt][r];
+        }
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (kh == 0) w[(long long)64 * H + col] = bsum;
+}
+
+// grads[g][oW1 .. +SMAX*H) and [ob1 .. +H) = sum over splits, in split order; structural zeros of W1 applied
+__global__ void dx1w1_reduce_kernel(const float *__restrict__ ws, int G, int S, int H, int SMAX, const int16_t *__restrict__ rr,
+                                    float *__restrict__ grads, long long stride, long long oW1, long long ob1) {
+    const long long per = (long long)65 * H, out = (long long)(SMAX + 1) * H;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= out * G) return;
+    const long long g = i / out, j = i % out;
+    const int f = (int)(j / H), n = (int)(j % H);
+    const long long src = f < SMAX ? j : (long long)64 * H + n;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += ws[((long long)s * G + g) * per + src];
+    if (f < SMAX) {
+        const int16_t *q = rr + ((g >> 1) * SMAX + f) * 2;
+        if (n < q[0] || n >= q[1]) acc = 0.f;
+        grads[g * stride + oW1 + j] = acc;
+    } else {
+        grads[g * stride + ob1 + n] = acc;
+    }
+}
+
 struct tsc_model {
     Layout lay;
     int E, T, device;
@@ -916,6 +1089,7 @@ struct tsc_model {
     size_t lds_fwd, lds_bwd, lds_fused;
     int fused_fwd;
     int fused_dw;               // dWx | dWh | dbl in one pass (dwxh_kernel)
+    int fused_dx;               // dX1 in registers, dW1 | db1 in the same pass (dx1w1_kernel)
     int cached_next;            // next rollout slot whose activations the fused forward will cache; T = all cached
     long long *dbg;
     long long nparam;
@@ -1026,6 +1200,13 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     if (const char *ev = getenv("TSC_UNFUSED_FWD")) if (atoi(ev)) m->fused_fwd = 0;
     m->fused_dw = !L.fc && (L.H == 224 || L.H == 160);
     if (const char *ev = getenv("TSC_UNFUSED_DW")) if (atoi(ev)) m->fused_dw = 0;
+    m->fused_dx = !L.fc && (L.H == 224 || L.H == 160) && L.SMAX <= 64 && L.SMAX % 4 == 0;
+    if (const char *ev = getenv("TSC_UNFUSED_DX")) if (atoi(ev)) m->fused_dx = 0;
+    if (m->fused_dx) {
+        const int lds = (int)(sizeof(float) * (2 * kG4 * kD1Ld + 2 * 32 * kObLd));
+        TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
     if (m->fused_fwd)
         TSC_HIP(hipFuncSetAttribute((const void *)policy_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fused));
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((m->nparam + 255) / 256)), dim3(256), 0, 0, m->ms, m->nparam, 1.0f);
@@ -1258,6 +1439,26 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
              kG4, nullptr, 0, nullptr, 0, 0, nullptr, 0, g + L.obl, L.stride)) return tsc::fail("gemm failed");
     if (gemm(m, tsc::KID_DWX_GEMM, true, tsc::EPI_NONE, (int)G, L.H, kG4, (int)N, m->X1, N * L.H, L.H, 1, m->Z, N * kG4, kG4, g + L.oWx, L.stride,
              kG4, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, 0)) return tsc::fail("gemm failed");
+    }
+    if (m->fused_dx && L.ob1 == L.oW1 + (long long)L.SMAX * L.H && (size_t)((long long)S * G * 65 * L.H) <= m->ws_floats) {
+        // dX1 stays in registers: dW1 | db1 come out of the same pass (dx1w1_kernel)
+        long long rps = (N + S - 1) / S;
+        rps = (rps + 31) / 32 * 32;                  // whole 32-row chunks
+        const size_t lds = sizeof(float) * (2 * kG4 * kD1Ld + 2 * 32 * kObLd);
+        {
+            tsc::ProfScope ps(tsc::KID_DX1_GEMM, m->stream);
+            if (L.H == 224) hipLaunchKernelGGL(dx1w1_kernel<7>, dim3((unsigned)(S * G)), dim3(512), lds, st, m->Z, m->X1, m->WxT, m->r_obs, N, (int)G, S, rps, (int)A, L.SMAX, m->ws);
+            else hipLaunchKernelGGL(dx1w1_kernel<5>, dim3((unsigned)(S * G)), dim3(512), lds, st, m->Z, m->X1, m->WxT, m->r_obs, N, (int)G, S, rps, (int)A, L.SMAX, m->ws);
+        }
+        {
+            tsc::ProfScope ps(tsc::KID_DW1_GEMM, m->stream);
+            const long long tot = (long long)(L.SMAX + 1) * L.H * G;
+            hipLaunchKernelGGL(dx1w1_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m->ws, (int)G, S, L.H, L.SMAX,
+                               m->rowrange, g, L.stride, L.oW1, L.ob1);
+        }
+        TSC_HIP(hipGetLastError());
+        m->cached_next = 0;
+        return 0;
     }
     // dX1 = (dZ Wx^T) * relu'(X1), in place over X1
     if (gemm(m, tsc::KID_DX1_GEMM, false, tsc::EPI_MASK_POS, (int)G, (int)N, L.H, kG4, m->Z, N * kG4, kG4, 1, m->WxT, (long long)L.H * kG4, L.H,

@@ -118,3 +118,32 @@ def test_zero_copy_fingerprint_and_reward_sum():
         tot += float(ga.sum().item())
     assert abs(a.reward_sum() - tot) < 1e-6 * max(1.0, abs(tot))
     a.close(); b.close()
+
+
+def test_helper_threads_equal_plain_walk(monkeypatch):
+    """step_kernel<., true> (phase A1: car-following of queued vehicles on all threads, chunk-prefetched tail walk)
+    against step_kernel<., false> (every vehicle evaluated by its lane thread) at a load where most lanes are
+    queued: obs, rewards and the complete vehicle state stay bit-identical."""
+    from deeprl_signal_control_amd.env import VecTrafficEnv
+    scn = build_large_grid('ma2c')
+    E = 96
+    monkeypatch.setenv('TSC_ENV_HELP', '1')
+    a = VecTrafficEnv(scn, E, seed=7)
+    monkeypatch.setenv('TSC_ENV_HELP', '0')
+    b = VecTrafficEnv(scn, E, seed=7)
+    oa, ob = a.reset(), b.reset()
+    assert torch.equal(oa, ob)
+    g = torch.Generator(device='cuda'); g.manual_seed(3)
+    for t in range(400):                                     # random phases: heavy congestion by t = 2000 s
+        act = torch.randint(0, 5, (E, 25), generator=g, device='cuda', dtype=torch.int32)
+        pol = torch.rand(E, 25, 5, generator=g, device='cuda')
+        a.update_fingerprint(pol); b.update_fingerprint(pol)
+        oa, ra, da, ga = a.step(act)
+        ob, rb, db, gb = b.step(act)
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(ga, gb) and torch.equal(da, db), t
+    assert a.mean_live_vehicles() > 400
+    for e in (0, 17, 95):
+        sa, sb = a.get_state(e), b.get_state(e)
+        for k in ('n', 'x', 'v', 'sf', 'w', 'r'):
+            np.testing.assert_array_equal(sa[k], sb[k], err_msg='state %s e=%d' % (k, e))
+    a.close(); b.close()

@@ -255,3 +255,58 @@ def test_forward_sample_equals_forward_then_sample():
     act2 = m.sample(pi2)
     assert torch.equal(pi, pi2) and torch.equal(v, v2) and torch.equal(act, act2)
     m.close()
+
+
+@pytest.mark.parametrize('agent,knob', [('ma2c', 'TSC_UNFUSED_DW'), ('ia2c', 'TSC_UNFUSED_DW'),
+                                        ('ma2c', 'TSC_UNFUSED_DX'), ('ia2c', 'TSC_UNFUSED_DX')])
+def test_fused_update_kernels_equal_grouped_gemms(agent, knob, monkeypatch):
+    """dwxh_kernel (dWx | dWh | dbl in one pass, whole tower output in accumulators) and dx1w1_kernel (dX1 kept in
+    registers, dW1 | db1 from the same pass) against the grouped GEMMs they replace: same gradient up to fp32
+    summation order, structural zeros of W1 exactly zero."""
+    E, T = 40, 9
+    rng = np.random.RandomState(11)
+    grads = []
+    for unfused in ('0', '1'):
+        monkeypatch.setenv(knob, unfused)
+        scn, m, o = _make(agent, E, T, seed=5)
+        m.reset(); o.reset()
+        r2 = np.random.RandomState(123)
+        obs, done = _fill(scn, m, o, E, T, r2, terminal=False, use_cache=True)
+        Rb = m.forward(torch.from_numpy(obs).cuda(), False, 'v').clone()
+        from deeprl_signal_control_amd import _lib
+        _lib.check(m._L.tsc_model_compute_grads(m._h, C.c_void_p(Rb.data_ptr()), 0.01))
+        grads.append(m.grad_tensor().cpu().numpy().copy())
+        m.close()
+    scale = np.abs(grads[1]).max()
+    assert scale > 0
+    np.testing.assert_allclose(grads[0], grads[1], atol=2e-5 * scale, rtol=0)
+    np.testing.assert_array_equal(grads[0] == 0, grads[1] == 0)
+
+
+def test_multibatch_trainer_keeps_replicas_identical():
+    """MultiBatchTrainer: two half-batches on two streams; after an iteration every handle holds the same
+    parameters, and they equal one VecA2C fed the summed gradient (the N-rank update rule)."""
+    from deeprl_signal_control_amd.agents import VecA2C
+    from deeprl_signal_control_amd.env import VecTrafficEnv
+    from deeprl_signal_control_amd.scenario import build_large_grid
+    from deeprl_signal_control_amd.trainer import MultiBatchTrainer
+    scn = build_large_grid('ma2c')
+    E, T = 8, 6
+    cfg = {'batch_size': T, 'reward_norm': 2000.0}
+    envs = [VecTrafficEnv(scn, E, seed=30 + 100 * b) for b in range(2)]
+    models = [VecA2C(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, scn.n_f_ls, E, scn.s_max, 5, cfg, seed=3, name='ma2c')
+              for b in range(2)]
+    models[1].sample_seed = 51                                # same initial parameters, different action draws
+    p0 = models[0].get_flat().copy()
+    np.testing.assert_array_equal(p0, models[1].get_flat())
+    tr = MultiBatchTrainer(envs, models)
+    for _ in range(2):
+        tr.run_iteration()
+    torch.cuda.synchronize()
+    pa, pb = models[0].get_flat(), models[1].get_flat()
+    np.testing.assert_array_equal(pa, pb)
+    assert np.abs(pa - p0).max() > 0
+    for e in envs:
+        e.close()
+    for m in models:
+        m.close()
