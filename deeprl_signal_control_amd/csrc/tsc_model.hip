@@ -476,55 +476,85 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
     const float *P = params + (long long)g * lay.stride;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
 
-    // LSTM state of this wave's 16 (env, unit) pairs: issued first so the HBM latency hides under phases 0-1
     const int r0 = 32 * (wave & 1), j0 = 32 * (wave >> 1), j = j0 + li;
+    // Everything this workgroup needs from memory before its first MFMA is requested up front, in the order of
+    // use and UNCONDITIONALLY (indices clamped; rows past E are computed but never stored), so that each phase
+    // waits with a counted vmcnt for exactly its own operands: obs tile -> first W1 column tile -> head weights
+    // -> LSTM state.  (Loads under `if (e < E)` make every wait a full drain: the obs tile then also waited for
+    // the 32 state loads issued before it.)
+    const int q4 = SMAX >> 2, AS = lay.A * SMAX, nct = H >> 5;
+    const float *W1 = P + lay.oW1, *b1 = P + lay.ob1;
+    float4 ov[4];
+    int om[4], ok4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int idx = tid + 256 * q;
+        om[q] = -1;
+        if (idx < 64 * q4) om[q] = idx / q4; else idx = 64 * q4 - 1;
+        const int m = idx / q4;
+        ok4[q] = (idx % q4) * 4;
+        const int e = e0 + m < E ? e0 + m : E - 1;
+        ov[q] = *reinterpret_cast<const float4 *>(obs + (long long)e * AS + a * SMAX + ok4[q]);
+    }
+    float bw0[32];
+    {
+        const int ct = wave < nct ? wave : nct - 1;
+        const unsigned wb = (unsigned)(ct * 32 + li) * 4u;
+#pragma unroll
+        for (int s2 = 0; s2 < 32; ++s2) {
+            const int kr = 2 * s2 + kh < SMAX ? 2 * s2 + kh : SMAX - 1;       // rows past SMAX meet a zeroed A operand
+            bw0[s2] = ldg(W1, wb + (unsigned)(kr * H) * 4u);
+        }
+    }
+    float *WoS = XH + (H + 64) * kXLd;              // [64][8] head weights + [8] bias
+    if (tid < (kL * kOut + kOut) / 4)
+        *reinterpret_cast<float4 *>(WoS + 4 * tid) = *reinterpret_cast<const float4 *>(P + lay.oWo + 4 * tid);
+    // LSTM state of this wave's 16 (env, unit) pairs: lands under phases 0-1
     float c[16], h0v[16];
     int erow[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        erow[r] = r0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        const int e = e0 + erow[r];
-        float c0 = 0.f, h0 = 0.f;
-        if (e < E) {
-            const float *st = state + ((long long)g * E + e) * 2 * kL;
-            const float keep = 1.0f - (float)done[e];
-            c0 = st[j] * keep; h0 = st[kL + j] * keep;
-        }
-        c[r] = c0; h0v[r] = h0;
-    }
-    // ---- phase 0: obs tile -> LDS, k-major
     {
-        const int q4 = SMAX >> 2, AS = lay.A * SMAX;
-        for (int idx = tid; idx < 64 * q4; idx += 256) {
-            const int m = idx / q4, k4 = (idx % q4) * 4, e = e0 + m;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < E) v = *reinterpret_cast<const float4 *>(obs + (long long)e * AS + a * SMAX + k4);
-            Hs[(k4 + 0) * kXLd + m] = v.x; Hs[(k4 + 1) * kXLd + m] = v.y;
-            Hs[(k4 + 2) * kXLd + m] = v.z; Hs[(k4 + 3) * kXLd + m] = v.w;
+        const float *stb = state + (long long)g * E * 2 * kL;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            erow[r] = r0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int e = e0 + erow[r] < E ? e0 + erow[r] : E - 1;
+            const float keep = 1.0f - (float)done[e];
+            const unsigned ob = (unsigned)(e * 2 * kL + j) * 4u;
+            c[r] = ldg(stb, ob) * keep; h0v[r] = ldg(stb, ob + kL * 4u) * keep;
         }
     }
+    // ---- phase 0: obs tile -> LDS, k-major; rows [SMAX, 64) of the staging area are zero
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (om[q] >= 0) {
+            Hs[(ok4[q] + 0) * kXLd + om[q]] = ov[q].x; Hs[(ok4[q] + 1) * kXLd + om[q]] = ov[q].y;
+            Hs[(ok4[q] + 2) * kXLd + om[q]] = ov[q].z; Hs[(ok4[q] + 3) * kXLd + om[q]] = ov[q].w;
+        }
+    for (int idx = tid; idx < (64 - SMAX) * 64; idx += 256) Hs[(SMAX + (idx >> 6)) * kXLd + (idx & 63)] = 0.f;
     __syncthreads();
     FSTAMP();
-    // ---- phase 1: X1 = relu(obs W1 + b1) -> XH rows [0, H)
+    // ---- phase 1: X1 = relu(obs W1 + b1) -> XH rows [0, H); column tiles wave and wave + 4
     {
-        const float *W1 = P + lay.oW1, *b1 = P + lay.ob1;
-        const int nct = H >> 5;
-        for (int ct = wave; ct < nct; ct += 4) {
+        float bw1[32];
+        {
+            const int ct = wave + 4 < nct ? wave + 4 : nct - 1;
+            const unsigned wb = (unsigned)(ct * 32 + li) * 4u;
+#pragma unroll
+            for (int s2 = 0; s2 < 32; ++s2) {
+                const int kr = 2 * s2 + kh < SMAX ? 2 * s2 + kh : SMAX - 1;
+                bw1[s2] = ldg(W1, wb + (unsigned)(kr * H) * 4u);
+            }
+        }
+        auto tile = [&](const float *bw, int ct) {
             f32x16 acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
             const int col = ct * 32 + li;
-            // all B operands of this column tile first (<= 32 independent loads in flight), then the MFMAs
-            float bw[32];
-#pragma unroll
-            for (int s2 = 0; s2 < 32; ++s2) bw[s2] = 2 * s2 < SMAX ? W1[(long long)(2 * s2 + kh) * H + col] : 0.f;
 #pragma unroll
             for (int s2 = 0; s2 < 32; ++s2) {
-                if (2 * s2 < SMAX) {
-                    const float a0 = Hs[(2 * s2 + kh) * kXLd + li], a1 = Hs[(2 * s2 + kh) * kXLd + 32 + li];
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bw[s2], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bw[s2], acc1, 0, 0, 0);
-                }
+                const float a0 = Hs[(2 * s2 + kh) * kXLd + li], a1 = Hs[(2 * s2 + kh) * kXLd + 32 + li];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bw[s2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bw[s2], acc1, 0, 0, 0);
             }
             const float bias = b1[col];
             int eb1 = e0;
@@ -542,7 +572,9 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
                     if (eb1 + 32 + row < E) X1c[(nb + 32 + row) * H + col] = v1;
                 }
             }
-        }
+        };
+        if (wave < nct) tile(bw0, wave);
+        if (wave + 4 < nct) tile(bw1, wave + 4);
     }
     __syncthreads();
     FSTAMP();
@@ -630,9 +662,10 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
     // ---- phase 4: head.  thread -> (env = tid & 63, outputs 2*(tid>>6), 2*(tid>>6)+1)
     float *LG = XH + 64 * kXLd;                        // [64][8] logits
     {
-        const float *Wo = P + lay.oWo, *bo = P + lay.obo;
+        const float *Wo = WoS, *bo = WoS + kL * kOut;           // staged at kernel entry
         const int e = tid & 63, k0 = 2 * (tid >> 6);
         float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
         for (int jj = 0; jj < kL; ++jj) {
             const float h = XH[jj * kXLd + e];
             s0 += h * Wo[jj * kOut + k0];
@@ -1195,7 +1228,7 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bwd));
     m->dbg = nullptr;
     m->cached_next = 0;
-    m->lds_fused = sizeof(float) * (size_t)(L.H + 64) * kXLd;
+    m->lds_fused = sizeof(float) * ((size_t)(L.H + 64) * kXLd + kL * kOut + kOut + 8);   // activations + head weights
     m->fused_fwd = !L.fc && (L.H % 32 == 0) && (L.SMAX <= 64) && (L.SMAX % 4 == 0) && ((L.H + 64) % 8 == 0) && m->lds_fused <= 160 * 1024;
     if (const char *ev = getenv("TSC_UNFUSED_FWD")) if (atoi(ev)) m->fused_fwd = 0;
     m->fused_dw = !L.fc && (L.H == 224 || L.H == 160);
