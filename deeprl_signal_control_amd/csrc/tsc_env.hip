@@ -57,6 +57,7 @@ struct EnvDev {
     const int *agent_lanes, *agent_nlane, *agent_nlink, *agent_nphase;
     const uint8_t *green_tab, *yellow_tab;
     const int *nbr, *obs_kind, *obs_src;
+    const int *obs_ks;             // [A*SMAX] obs_kind << 16 | obs_src (one load per observation entry)
     int ctrl, yellow, episode, teleport, queue_cap, objective, agent_kind, realnet_scale;
     double coop_gamma, norm_wave, norm_wait, clip_wave, clip_wait, coef_wait;
     float *X, *V, *SF;
@@ -266,33 +267,79 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     uint32_t *M = P.M + (size_t)e * kCap * NLP;
     float *C = P.C + (size_t)e * kCap * NLP;   // phase A1 -> A2: new speed of a queued vehicle that cannot cross
 
-    // ---- K1: signal FSM (envs/env.py:128-152) -> link chars for the yellow and the green interval
-    for (int a = l; a < P.A; a += blockDim.x) {
-        int act = action[(size_t)e * P.A + a];
-        int prev = P.prev_action[(size_t)e * P.A + a];
-        P.prev_action[(size_t)e * P.A + a] = act;
-        const uint8_t *g = P.green_tab + ((size_t)a * P.PMAX + act) * P.KMAX;
-        const uint8_t *y = (prev < 0 || prev == act) ? g : P.yellow_tab + (((size_t)a * P.PMAX + prev) * P.PMAX + act) * P.KMAX;
-        for (int k = 0; k < P.KMAX; ++k) { s.link_y[a * P.KMAX + k] = y[k]; s.link_g[a * P.KMAX + k] = g[k]; }
+    // ---- prologue.  Everything is requested in two levels -- first all loads that depend on nothing, then (under
+    // the table copies) the ones that need a first-level value -- and unconditionally (lane index clamped), so
+    // that the prologue costs a few memory round trips instead of one per table.
+    const int lc = lane ? l : P.NU - 1;                                  // clamped lane for the loads
+    const bool ag = l < P.A;
+    const int ac = ag ? l : P.A - 1;
+    // level 1
+    const int act = action[(size_t)e * P.A + ac];
+    const int prev = P.prev_action[(size_t)e * P.A + ac];
+    int n = P.N[(size_t)e * NLP + lc];
+    float L = P.lane_len[lc], vmax = P.lane_vmax[lc], det = P.lane_det[lc];
+    int my_node = P.lane_node[lc];
+    int up0 = P.lane_up[lc * kMaxUp], up1 = P.lane_up[lc * kMaxUp + 1], up2 = P.lane_up[lc * kMaxUp + 2], up3 = P.lane_up[lc * kMaxUp + 3];
+    int myr[kMaxEntry];
+#pragma unroll
+    for (int q = 0; q < kMaxEntry; ++q) myr[q] = P.lane_routes[lc * kMaxEntry + q];
+    int t = P.tsec[e];
+    const uint32_t seed = P.seed[e];
+    const int rc = l < NR ? l : NR - 1;
+    const int pend0 = P.pending[(size_t)e * NR + rc], ser0 = P.serial[(size_t)e * NR + rc];
+    if (!lane) {
+        n = 0; L = 1.0f; vmax = 1.0f; det = 0.0f; my_node = -1; up0 = up1 = up2 = up3 = -1;
+#pragma unroll
+        for (int q = 0; q < kMaxEntry; ++q) myr[q] = -1;
     }
-    for (int i = l; i < P.NU * NR; i += blockDim.x) s.mv[i] = P.mv[i];
-    for (int i = l; i < (P.NU * NR + 3) / 4; i += blockDim.x) ((uint32_t *)s.zip)[i] = ((const uint32_t *)P.zip)[i];   // padded to 4 B
+    // table copies: four (clamped, unconditional) loads in flight per thread and round instead of one
+    auto copy_words = [&](uint32_t *dst, const uint32_t *src, int count) {
+        for (int base = l; base < count; base += 4 * (int)blockDim.x) {
+            uint32_t w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = base + u * (int)blockDim.x; w[u] = src[i < count ? i : count - 1]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = base + u * (int)blockDim.x; if (i < count) dst[i] = w[u]; }
+        }
+    };
+    copy_words((uint32_t *)s.mv, (const uint32_t *)P.mv, P.NU * NR);
+    copy_words((uint32_t *)s.zip, (const uint32_t *)P.zip, (P.NU * NR + 3) / 4);      // padded to 4 B
+    // level 2 (needs n / act / t), issued before the remaining LDS fills
+    float hx = 0, hv = 0, tx = 0, tv = 0; uint32_t hm = 0;
+    {
+        const int nl = n > 0 ? n - 1 : 0;
+        const float x0 = X[lc], v0 = V[lc], xl = X[nl * NLP + lc], vl = V[nl * NLP + lc];
+        const uint32_t m0 = M[lc];
+        if (n > 0) { hx = x0; hv = v0; hm = m0; tx = xl; tv = vl; }
+    }
+    // K1: signal FSM (envs/env.py:128-152) -> link chars for the yellow and the green interval
+    if (ag) {
+        P.prev_action[(size_t)e * P.A + l] = act;
+        const uint8_t *g = P.green_tab + ((size_t)l * P.PMAX + act) * P.KMAX;
+        const uint8_t *y = (prev < 0 || prev == act) ? g : P.yellow_tab + (((size_t)l * P.PMAX + prev) * P.PMAX + act) * P.KMAX;
+        for (int k = 0; k < P.KMAX; ++k) { s.link_y[l * P.KMAX + k] = y[k]; s.link_g[l * P.KMAX + k] = g[k]; }
+    }
+    // per-route insertion state and this step's emissions live in LDS for the duration of the launch
+    if (l < NR) {
+        s.pend[l] = pend0; s.ser[l] = ser0;
+        for (int q = 0; q < 8; ++q) s.emit[l * 8 + q] = q < P.ctrl ? P.emit_tab[(size_t)l * P.emit_len + t + q] : 0;
+    }
+    for (int r = blockDim.x + l; r < NR; r += blockDim.x) {              // more routes than threads (not on the reference scenarios)
+        s.pend[r] = P.pending[(size_t)e * NR + r]; s.ser[r] = P.serial[(size_t)e * NR + r];
+        for (int q = 0; q < 8; ++q) s.emit[r * 8 + q] = q < P.ctrl ? P.emit_tab[(size_t)r * P.emit_len + t + q] : 0;
+    }
+    for (int a2 = blockDim.x + l; a2 < P.A; a2 += blockDim.x) {          // more agents than threads (ditto)
+        const int act2 = action[(size_t)e * P.A + a2], prev2 = P.prev_action[(size_t)e * P.A + a2];
+        P.prev_action[(size_t)e * P.A + a2] = act2;
+        const uint8_t *g = P.green_tab + ((size_t)a2 * P.PMAX + act2) * P.KMAX;
+        const uint8_t *y = (prev2 < 0 || prev2 == act2) ? g : P.yellow_tab + (((size_t)a2 * P.PMAX + prev2) * P.PMAX + act2) * P.KMAX;
+        for (int k = 0; k < P.KMAX; ++k) { s.link_y[a2 * P.KMAX + k] = y[k]; s.link_g[a2 * P.KMAX + k] = g[k]; }
+    }
     for (int q = l; q < NLA; q += blockDim.x) {
         const bool in = q < P.NU;
         s.len[q] = in ? P.lane_len[q] : 1.0f; s.node[q] = in ? P.lane_node[q] : -1; s.vmax[q] = in ? P.lane_vmax[q] : 1.0f;
     }
     for (int q = l; q < NLP; q += blockDim.x) { s.wave[q] = 0; s.halt[q] = 0; s.hwait[q] = 0; }
-
-    // ---- per-lane constants and the initial lane summary
-    int n = 0, my_node = -1;
-    float L = 1.0f, vmax = 1.0f, det = 0.0f;
-    float hx = 0, hv = 0, tx = 0, tv = 0; uint32_t hm = 0;
-    if (lane) {
-        n = P.N[(size_t)e * NLP + l];
-        L = P.lane_len[l]; vmax = P.lane_vmax[l]; det = P.lane_det[l];
-        my_node = P.lane_node[l];
-        if (n > 0) { hx = X[l]; hv = V[l]; hm = M[l]; tx = X[(n - 1) * NLP + l]; tv = V[(n - 1) * NLP + l]; }
-    }
     // publishes a lane's summary for the next second; with HELP also the wave-local inclusive scan of the number
     // of queued vehicles (slots >= 1) that phase A1 distributes over the workgroup
     auto publish = [&]() {
@@ -311,25 +358,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     };
     publish();
     if (lthr) s.nout[l] = 0;
-    int t = P.tsec[e];
-    const uint32_t seed = P.seed[e];
     unsigned arrived = 0;
-    // everything the per-second loop needs from constant tables / per-route state is pulled into registers
-    // here, so no dependent global load sits between two barriers
-    int up0 = -1, up1 = -1, up2 = -1, up3 = -1;
-    int myr[kMaxEntry];
-#pragma unroll
-    for (int q = 0; q < kMaxEntry; ++q) myr[q] = -1;
-    if (lane) {
-        up0 = P.lane_up[l * kMaxUp]; up1 = P.lane_up[l * kMaxUp + 1]; up2 = P.lane_up[l * kMaxUp + 2]; up3 = P.lane_up[l * kMaxUp + 3];
-#pragma unroll
-        for (int q = 0; q < kMaxEntry; ++q) myr[q] = P.lane_routes[l * kMaxEntry + q];
-    }
-    // per-route insertion state and this step's emissions live in LDS for the duration of the launch
-    for (int r = l; r < NR; r += blockDim.x) {
-        s.pend[r] = P.pending[(size_t)e * NR + r]; s.ser[r] = P.serial[(size_t)e * NR + r];
-        for (int q = 0; q < 8; ++q) s.emit[r * 8 + q] = q < P.ctrl ? P.emit_tab[(size_t)r * P.emit_len + t + q] : 0;
-    }
     __syncthreads();
     TSC_STAMP();
 
@@ -624,21 +653,58 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     __syncthreads();
     TSC_STAMP();
 
-    // ---- K5: observations
-    emit_obs(P, s, e, obs);
-
+    // ---- K5: observations.  The float64 normalisation (envs/env.py:439-442, a division) is done once per lane,
+    // not once per observation entry; the entries then only gather.  The outbox arrays are dead by now.
+    float *o_wave = s.ox, *o_coop = s.ov, *o_wait = s.osf;        // [NLP] each (kMaxCross * NLA >= NLP)
+    int *qacc = (int *)s.om, *wacc = qacc + P.A;                   // per-agent queue / wait sums (integers: exact in any order)
+    for (int q = l; q < NLP; q += blockDim.x) {
+        const double wv = norm_clip((double)s.wave[q], P.norm_wave, P.clip_wave);
+        o_wave[q] = (float)wv;
+        o_coop[q] = (float)(wv * P.coop_gamma);
+        o_wait[q] = (float)norm_clip((double)s.hwait[q], P.norm_wait, P.clip_wait);
+    }
+    for (int a = l; a < 2 * P.A; a += blockDim.x) qacc[a] = 0;
+    __syncthreads();
+    {
+        const int tot = P.A * P.SMAX;
+        const float *fp = (P.fp_bound ? P.fp_bound : P.fp) + (size_t)e * P.A * P.PMAX;
+        float *ob = obs + (size_t)e * tot;
+        constexpr int kOB = 6;                                     // entries per thread and round, loads first
+        for (int base = l; base < tot; base += kOB * (int)blockDim.x) {
+            int ks[kOB];
+#pragma unroll
+            for (int u = 0; u < kOB; ++u) { const int idx = base + u * (int)blockDim.x; ks[u] = P.obs_ks[idx < tot ? idx : tot - 1]; }
+#pragma unroll
+            for (int u = 0; u < kOB; ++u) {
+                const int idx = base + u * (int)blockDim.x;
+                if (idx >= tot) continue;
+                const int kind = ks[u] >> 16, src = ks[u] & 0xFFFF;
+                float o = 0.0f;
+                if (kind == 1) o = o_wave[src];
+                else if (kind == 2) o = o_coop[src];
+                else if (kind == 3) o = o_wait[src];
+                else if (kind == 4) o = fp[src];
+                ob[idx] = o;
+            }
+        }
+    }
     TSC_STAMP();
-    // ---- K6: reward (envs/env.py:356-367) and shaping (:580,:590-631), float64
-    for (int a = l; a < P.A; a += blockDim.x) {
-        long long queue = 0;
-        double wsum = 0.0;
-        for (int k = 0; k < P.agent_nlane[a]; ++k) {
-            const int ln = P.agent_lanes[a * P.LMAX + k];
+    // ---- K6: reward (envs/env.py:356-367) and shaping (:580,:590-631), float64.  Queue and wait of an agent are
+    // sums of small integers: accumulated with LDS atomics over all (agent, lane) pairs in parallel.
+    for (int p2 = l; p2 < P.A * P.LMAX; p2 += blockDim.x) {
+        const int ln = P.agent_lanes[p2];
+        const int a = p2 / P.LMAX;
+        if (ln >= 0 && p2 - a * P.LMAX < P.agent_nlane[a]) {
             int q = s.halt[ln];
             if (P.queue_cap >= 0 && q > P.queue_cap) q = P.queue_cap;
-            queue += q;
-            wsum += (double)s.hwait[ln];
+            atomicAdd(&qacc[a], q);
+            atomicAdd(&wacc[a], s.hwait[ln]);
         }
+    }
+    __syncthreads();
+    for (int a = l; a < P.A; a += blockDim.x) {
+        const long long queue = qacc[a];
+        const double wsum = (double)wacc[a];
         double r;
         if (P.objective == TSC_OBJ_QUEUE) r = (double)(-queue);
         else if (P.objective == TSC_OBJ_WAIT) r = -wsum;
@@ -857,6 +923,14 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     UP(yellow_tab, uint8_t, sc->yellow_tab, (size_t)A * P.PMAX * P.PMAX * P.KMAX);
     UP(nbr, int, sc->nbr, A * P.NBR);
     UP(obs_kind, int, sc->obs_kind, A * P.SMAX); UP(obs_src, int, sc->obs_src, A * P.SMAX);
+    {
+        std::vector<int> ks((size_t)A * P.SMAX);
+        for (size_t i = 0; i < ks.size(); ++i) {
+            if (sc->obs_src[i] < 0 || sc->obs_src[i] > 0xFFFF) { ks[i] = 0; continue; }
+            ks[i] = (sc->obs_kind[i] << 16) | sc->obs_src[i];
+        }
+        UP(obs_ks, int, ks.data(), ks.size());
+    }
 
     const size_t slots = (size_t)n_env * kCap * P.NLP;
     ALLOC(X, float, slots); ALLOC(C, float, slots); ALLOC(V, float, slots); ALLOC(SF, float, slots); ALLOC(M, uint32_t, slots);
@@ -875,6 +949,8 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
         const char *ev = getenv("TSC_ENV_HELP");
         P.help = (ev && ev[0] == '0') ? 0 : 1;
     }
+    if (kMaxCross * P.NLA < P.NLP || kMaxCross * P.NLA < 2 * P.A)
+        return tsc::fail("tsc_env_create: too few live lanes (%d of %d) for the observation scratch", P.NU, P.NL);
     h->smem = smem_bytes(P);
     if (h->smem > 160 * 1024) return tsc::fail("tsc_env_create: LDS need %zu B > 160 KiB", h->smem);
     h->threads = (P.help && P.NLA < 256) ? 256 : P.NLA;
