@@ -144,6 +144,8 @@ def main():
     ap.add_argument('--batches', type=int, default=1, help='independent half-batches per GPU on separate HIP streams')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--profile-stride', type=int, default=8,
+                    help='HIP-event timing of every n-th launch of the per-control-step kernels (1 = all; the pairs serialise dependent kernels)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -193,7 +195,7 @@ def main():
     sync()
     live = []
     if not args.no_profile:
-        _lib.profile(enable=True, reset=True)
+        _lib.profile(enable=max(1, args.profile_stride), reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         tr.run_iteration()
@@ -249,6 +251,7 @@ def main():
                     ach = fl.get(dom, 0.0) / avg_s / 1e12
                 roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
                         'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(dom)}
+            roof['timed'] = 'HIP events on the launch stream, every %s launch of the per-control-step kernels, every launch of the others' % ('%dth' % args.profile_stride if args.profile_stride > 1 else '')
             roof['avg_launch_ms'] = ms / cnt
             roof['share_of_kernel_time'] = ms / total
             roof['kernel_time_ms_total'] = total

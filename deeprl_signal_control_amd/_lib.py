@@ -125,10 +125,12 @@ def scenario_struct(scn):
 
 
 def profile(enable=None, reset=False):
-    """Per-kernel HIP-event timings of the library: returns {name: (total_ms, count)}."""
+    """Per-kernel HIP-event timings of the library: returns {name: (total_ms, count)}.
+    enable: False/0 off, True/1 every launch, n > 1 every n-th launch of the per-control-step kernels
+    (total_ms is then average x launches, see include/tsc.h)."""
     L = lib()
     if enable is not None:
-        check(L.tsc_profile_enable(int(bool(enable))))
+        check(L.tsc_profile_enable(int(enable)))
     if reset:
         check(L.tsc_profile_reset())
         return {}

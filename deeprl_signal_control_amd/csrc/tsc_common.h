@@ -38,8 +38,11 @@ inline hipError_t upload(T **dst, const T *src, size_t count) {
 
 
 // ---- per-kernel timing with HIP events (bench.py's live roofline figure) -------------------------
-// Off by default.  When on, every launch site brackets its kernel with two events on the launch
-// stream; tsc_profile_read() synchronises and folds the elapsed times per kernel id.
+// Off by default.  When on, launch sites bracket their kernel with two events on the launch stream;
+// tsc_profile_read() synchronises and folds the elapsed times per kernel id.  An event pair costs a few
+// microseconds of serialisation between dependent kernels (5 % of the rollout when every launch is bracketed), so
+// the per-control-step kernels are SAMPLED: every `stride`-th launch of a kernel id is timed, all are counted, and
+// the reported total is average x launches.
 enum KernelId : int {
     KID_ENV_STEP = 0, KID_FC_GEMM, KID_ZX_GEMM, KID_LSTM_FWD, KID_HEAD_FWD, KID_SAMPLE, KID_ADD_TRANS,
     KID_RETURNS, KID_HEAD_BWD, KID_LSTM_BWD, KID_DWO_GEMM, KID_DWH_GEMM, KID_DWX_GEMM, KID_DX1_GEMM,
@@ -48,6 +51,8 @@ enum KernelId : int {
 
 struct ProfState {
     bool on = false;
+    int stride = 1;                               // time every stride-th launch of the per-control-step kernels
+    long long seq[KID_COUNT] = {0};               // all launches
     struct Rec { int id; hipEvent_t a, b; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
@@ -61,6 +66,9 @@ struct ProfScope {
     ProfScope(int id_, hipStream_t st_) : id(id_), st(st_) {
         ProfState &p = prof();
         if (!p.on) return;
+        const bool per_step = id == KID_ENV_STEP || id == KID_FUSED_FWD || id == KID_ADD_TRANS || id == KID_FINGERPRINT ||
+                              id == KID_SAMPLE;
+        if (p.seq[id]++ % (per_step ? p.stride : 1) != 0) return;
         auto get = [&]() { hipEvent_t e; if (!p.pool.empty()) { e = p.pool.back(); p.pool.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
         a = get(); b = get();
         (void)hipEventRecord(a, st);

@@ -769,7 +769,7 @@ extern "C" {
 
 const char *tsc_last_error(void) { return tsc::err_buf(); }
 
-int tsc_profile_enable(int32_t on) { tsc::prof().on = on != 0; return 0; }
+int tsc_profile_enable(int32_t on) { tsc::prof().on = on != 0; tsc::prof().stride = on > 1 ? on : 1; return 0; }
 
 static int prof_fold() {
     tsc::ProfState &p = tsc::prof();
@@ -787,14 +787,17 @@ static int prof_fold() {
 int tsc_profile_reset(void) {
     if (prof_fold()) return 1;
     tsc::ProfState &p = tsc::prof();
-    for (int i = 0; i < tsc::KID_COUNT; ++i) { p.total_ms[i] = 0; p.count[i] = 0; }
+    for (int i = 0; i < tsc::KID_COUNT; ++i) { p.total_ms[i] = 0; p.count[i] = 0; p.seq[i] = 0; }
     return 0;
 }
 
 int tsc_profile_read(int32_t kernel_id, double *total_ms, int64_t *count) {
     if (kernel_id < 0 || kernel_id >= tsc::KID_COUNT || !total_ms || !count) return tsc::fail("tsc_profile_read: bad arguments");
     if (prof_fold()) return 1;
-    *total_ms = tsc::prof().total_ms[kernel_id]; *count = tsc::prof().count[kernel_id];
+    const tsc::ProfState &p = tsc::prof();
+    const long long timed = p.count[kernel_id], all = p.seq[kernel_id];
+    *total_ms = timed ? p.total_ms[kernel_id] / (double)timed * (double)all : 0.0;     // average x launches
+    *count = all;
     return 0;
 }
 

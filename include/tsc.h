@@ -76,7 +76,10 @@ const char *tsc_last_error(void);
 int tsc_version(void);
 
 /* Per-kernel timing with HIP events on the launch stream (bench.py's live roofline figure; the
- * reference has no equivalent).  Off by default; read() synchronises the recorded events. */
+ * reference has no equivalent).  Off by default; read() synchronises the recorded events.
+ * enable(on): 0 = off, 1 = time every launch, n > 1 = time every n-th launch of the kernels that run once per
+ * control step (an event pair serialises dependent kernels for a few microseconds); read() then returns
+ * total_ms = average of the timed launches x all launches, count = all launches. */
 int tsc_profile_enable(int32_t on);
 int tsc_profile_reset(void);
 int tsc_profile_read(int32_t kernel_id, double *total_ms, int64_t *count);

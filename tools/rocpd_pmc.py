@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""Fold rocprofv3 --pmc passes (rocpd SQLite databases, one counter set per pass) into the per-kernel
+HBM traffic table bench.py reads (profiles/r01_pmc.json) and, for an SQ pass, a utilisation CSV.
+
+    python tools/rocpd_pmc.py traffic gpurun_out/pmc_fetch/*.db gpurun_out/pmc_write/*.db profiles/r01_pmc.json
+    python tools/rocpd_pmc.py sq gpurun_out/pmc_sq/*.db profiles/r01_pmc_sq.csv
+
+FETCH_SIZE / WRITE_SIZE are rocprofv3's derived counters (KB per dispatch, from the L2's memory-side request
+counters, MI355X_MICROARCH.md "HBM / rocprofv3"); they are collected in separate passes from any trace.
+"""
+import csv
+import json
+import sqlite3
+import sys
+
+NAMES = [('step_kernel', 'env_step'), ('policy_fwd_fused', 'policy_fwd_fused'), ('dwxh_kernel', 'dwx_gemm'),
+         ('dx1w1_kernel', 'dx1_gemm'), ('lstm_bwd', 'lstm_bwd'), ('lstm_fwd', 'lstm_fwd'), ('head_bwd', 'head_bwd'),
+         ('head_fwd', 'head_fwd'), ('add_transition', 'add_transition'), ('dwxh_reduce', 'dwh_gemm'),
+         ('dx1w1_reduce', 'dw1_gemm'), ('returns_kernel', 'returns'), ('rmsprop', 'rmsprop'), ('grad_norm', 'grad_norm'),
+         ('interleave_gates', 'interleave_gates'), ('transpose_wx', 'transpose_wx'),
+         ('gemm_grouped_kernel<true', 'gemm_tn'), ('gemm_grouped_kernel<false', 'gemm_nn'), ('splitk_reduce', 'splitk_reduce')]
+
+
+def short(name):
+    for key, s in NAMES:
+        if key in name:
+            return s
+    return None
+
+
+def per_kernel(db, counter):
+    c = sqlite3.connect(db)
+    out = {}
+    for name, val in c.execute('select kernel_name, value from counters_collection where counter_name = ?', (counter,)):
+        k = short(name)
+        if k is None:
+            continue
+        tot, n = out.get(k, (0.0, 0))
+        out[k] = (tot + float(val), n + 1)
+    return out
+
+
+def traffic(fetch_db, write_db, out_path):
+    f, w = per_kernel(fetch_db, 'FETCH_SIZE'), per_kernel(write_db, 'WRITE_SIZE')
+    kern = {}
+    for k in sorted(set(f) | set(w)):
+        ft, fn = f.get(k, (0.0, 0))
+        wt, wn = w.get(k, (0.0, 0))
+        kern[k] = {'fetch_kb': ft / max(fn, 1), 'write_kb': wt / max(wn, 1), 'launches': max(fn, wn)}
+    doc = {'command': 'rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python bench.py --steps 1 --warmup 1 '
+                      '--no-cpu-baseline --no-profile; folded by tools/rocpd_pmc.py',
+           'units': 'KB per launch (average over launches)', 'kernels': kern}
+    json.dump(doc, open(out_path, 'w'), indent=1)
+    print('%d kernels -> %s' % (len(kern), out_path))
+
+
+def sq(db, out_path):
+    c = sqlite3.connect(db)
+    names = [r[0] for r in c.execute('select distinct counter_name from counters_collection')]
+    agg = {}
+    for name, cn, val in c.execute('select kernel_name, counter_name, value from counters_collection'):
+        k = short(name)
+        if k is None:
+            continue
+        d = agg.setdefault(k, {})
+        d[cn] = d.get(cn, 0.0) + float(val)
+        d['_n_' + cn] = d.get('_n_' + cn, 0) + 1
+    with open(out_path, 'w', newline='') as fh:
+        w = csv.writer(fh)
+        w.writerow(['kernel', 'dispatches'] + names + ['wait_any_frac', 'active_inst_frac', 'mfma_busy_per_simd_frac'])
+        for k, d in sorted(agg.items()):
+            wc = d.get('SQ_WAVE_CYCLES', 0.0)
+            row = [k, d.get('_n_' + names[0], 0)] + ['%.0f' % d.get(n, 0.0) for n in names]
+            row.append('%.3f' % (d.get('SQ_WAIT_ANY', 0.0) / wc) if wc else '')
+            row.append('%.3f' % (d.get('SQ_ACTIVE_INST_ANY', 0.0) / wc) if wc else '')
+            ga = d.get('GRBM_GUI_ACTIVE', 0.0)
+            row.append('%.3f' % (d.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (128.0 * ga)) if ga else '')
+            w.writerow(row)
+    print('%d kernels -> %s' % (len(agg), out_path))
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'traffic':
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4])
+    else:
+        sq(sys.argv[2], sys.argv[3])
