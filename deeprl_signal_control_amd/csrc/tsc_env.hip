@@ -845,12 +845,19 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     P.clip_wave = sc->clip_wave; P.clip_wait = sc->clip_wait; P.coef_wait = sc->coef_wait;
 
     const int NL = P.NL, NR = P.NR, A = P.A;
-    {   // lanes that some route can put a vehicle on
+    // Lanes that can ever hold a vehicle: the chains route entry lane -> mv_next[lane][route] -> ...  (the movement
+    // table also has rows for the sibling lanes of every edge a route passes, which no vehicle of that route is
+    // ever put on).  After load sorting they are a prefix; only they get a thread and LDS rows.
+    std::vector<char> reach((size_t)NL, 0);
+    {
         int nu = 0;
-        for (int r = 0; r < NR; ++r) if (sc->route_entry[r] + 1 > nu) nu = sc->route_entry[r] + 1;
-        for (int i = 0; i < NL * NR; ++i) if (sc->mv_next[i] >= 0) {
-            if (sc->mv_next[i] + 1 > nu) nu = sc->mv_next[i] + 1;
-            if (i / NR + 1 > nu) nu = i / NR + 1;
+        for (int r = 0; r < NR; ++r) {
+            int l = sc->route_entry[r];
+            for (int hops = 0; l >= 0 && l < NL && hops <= NL; ++hops) {
+                reach[l] = 1;
+                if (l + 1 > nu) nu = l + 1;
+                l = sc->mv_next[(size_t)l * NR + r];
+            }
         }
         P.NU = nu < 1 ? 1 : nu;
         P.NLA = (P.NU + 63) / 64 * 64;
@@ -858,17 +865,22 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     UP(lane_len, float, sc->lane_len, NL); UP(lane_vmax, float, sc->lane_vmax, NL);
     UP(lane_det, float, sc->lane_det_start, NL);
     UP(lane_node, int, sc->lane_node, NL);
-    UP(lane_up, int, sc->lane_up, NL * kMaxUp);
+    {
+        std::vector<int> up(sc->lane_up, sc->lane_up + (size_t)NL * kMaxUp);
+        for (int &u : up) if (u >= 0 && (u >= NL || !reach[u])) u = -1;        // a feeder that is never occupied never sends
+        UP(lane_up, int, up.data(), up.size());
+    }
     if (NL > 0xFFD) return tsc::fail("tsc_env_create: n_lane %d > 4093 unsupported", NL);
     std::vector<int> mv((size_t)NL * NR);
     for (int i = 0; i < NL * NR; ++i) {
-        const int nx = sc->mv_next[i], lk = sc->mv_link[i], yl = sc->mv_yield[i], pr = sc->mv_prio[i];
+        const int nx = sc->mv_next[i], lk = sc->mv_link[i], pr = sc->mv_prio[i];
+        const int yl = (sc->mv_yield[i] >= 0 && reach[sc->mv_yield[i]]) ? sc->mv_yield[i] : -1;   // an empty lane has no right of way to give
         if (lk > 62) return tsc::fail("tsc_env_create: signal link index %d > 62 unsupported", lk);
         const unsigned a = nx == -1 ? 0xFFFu : nx < -1 ? 0xFFEu : (unsigned)nx;
         const unsigned b = lk < 0 ? 63u : (unsigned)lk;
         const unsigned c = yl < 0 ? 0xFFFu : (unsigned)yl;
         mv[i] = (int)(a | (b << 12) | (c << 18) | ((pr ? 1u : 0u) << 30));
-        if (mv_tl(mv[i]) != (nx < -1 ? -2 : nx) || mv_k(mv[i]) != (lk < 0 ? -1 : lk) || mv_yield(mv[i]) != (yl < 0 ? -1 : yl))
+        if (mv_tl(mv[i]) != (nx < -1 ? -2 : nx) || mv_k(mv[i]) != (lk < 0 ? -1 : lk) || mv_yield(mv[i]) != yl)
             return tsc::fail("tsc_env_create: movement table overflow");
     }
     UP(mv, int, mv.data(), NL * NR);
