@@ -933,16 +933,17 @@ __global__ void dwxh_reduce_kernel(const float *__restrict__ ws, int G, int S, l
 //   dW1 = obs^T dX1,  db1 = colsum(dX1)        (agents/utils.py:66-74 through tf.gradients)
 // Work split of the 8-wave workgroup (one per CU, S x G workgroups, each a fixed row range of one tower):
 //   * waves 0..NCT-1 each own one 32-column strip of X1.  Their slice of Wx^T (256 x 32) is the STATIONARY MFMA
-//     operand: 128 registers per lane, loaded once.  Per chunk: 128 MFMAs (A = the dZ chunk, k-major in LDS),
+//     operand: 128 registers per lane, loaded once.  Per chunk: 128 MFMAs (A = the dZ chunk, row-major in LDS,
+//     one 16-byte read per four steps),
 //     mask with X1 > 0, then the masked accumulator tile is fed STRAIGHT back as the B operand of the dW1 product
 //     (accumulator row (r, lane half) = contraction index of step r), A = the obs chunk from LDS: 32 more MFMAs;
 //   * the remaining wave(s) are LOADERS: they fetch the next dZ / obs chunk with 16-byte loads while the others
-//     compute, and scatter it into the other LDS buffer (k-major for dZ, so the MFMA reads are conflict-free).
+//     compute, and copy it into the other LDS buffer.
 // Replaces the dX1 GEMM (second column tile 25 % empty, dZ read twice), the 11 GB dX1 round trip through HBM and
 // the dW1 GEMM.  Deterministic: partial dW1 / db1 per workgroup, added in split order by dx1w1_reduce_kernel,
 // which also applies the structural zeros of the block-diagonal first layer.
 // ------------------------------------------------------------------------------------------------
-constexpr int kD1Ld = 36;        // dZ chunk [256 k][32 rows + 4]
+constexpr int kD1Ld = 260;       // dZ chunk [32 rows][256 k + 4]: row-major like HBM, read as 16-byte A-operand quads
 constexpr int kObLd = 68;        // obs chunk [32 rows][64 features + 4]
 
 template <int NCT>   // H / 32
@@ -954,8 +955,8 @@ dx1w1_kernel(const float *__restrict__ dZ, const float *__restrict__ X1, const f
     constexpr int NZQ = 32 * 64, NOQ = 32 * 16;                 // float4s per chunk: dZ (32 x 256), obs (32 x 64, zero padded)
     constexpr int NQ = (NZQ + NOQ + NLT - 1) / NLT;             // staging slots per loader thread
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float *Az = (float *)smem_raw;                              // [2][256][kD1Ld]
-    float *Ob = Az + 2 * kG4 * kD1Ld;                           // [2][32][kObLd]
+    float *Az = (float *)smem_raw;                              // [2][32][kD1Ld]
+    float *Ob = Az + 2 * 32 * kD1Ld;                            // [2][32][kObLd]
     const int g = blockIdx.x % G, sp = blockIdx.x / G, a = g >> 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
     const long long n0 = (long long)sp * rows_per_split;
@@ -974,10 +975,10 @@ dx1w1_kernel(const float *__restrict__ dZ, const float *__restrict__ X1, const f
         auto load1 = [&](int idx, long long row0) {
             if (idx >= NZQ + NOQ) idx = NZQ + NOQ - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < NZQ) {                                 // dZ: row fastest, so the k-major LDS scatter is conflict-free
-                long long row = row0 + (idx & 31);
+            if (idx < NZQ) {                                 // dZ: 64 float4 per row, coalesced
+                long long row = row0 + (idx >> 6);
                 if (row >= n1) row = n1 - 1;
-                v = *reinterpret_cast<const float4 *>(dz + row * kG4 + 4 * (idx >> 5));
+                v = *reinterpret_cast<const float4 *>(dz + row * kG4 + 4 * (idx & 63));
             } else {
                 const int j = idx - NZQ, c4 = j & 15;
                 long long row = row0 + (j >> 4);
@@ -988,8 +989,7 @@ dx1w1_kernel(const float *__restrict__ dZ, const float *__restrict__ X1, const f
         };
         auto store1 = [&](int idx, int buf, const float4 &v) {
             if (idx < NZQ) {
-                float *d = Az + ((long long)buf * kG4 + 4 * (idx >> 5)) * kD1Ld + (idx & 31);
-                d[0] = v.x; d[kD1Ld] = v.y; d[2 * kD1Ld] = v.z; d[3 * kD1Ld] = v.w;
+                *reinterpret_cast<float4 *>(Az + ((long long)buf * 32 + (idx >> 6)) * kD1Ld + 4 * (idx & 63)) = v;
             } else if (idx < NZQ + NOQ) {
                 const int j = idx - NZQ;
                 *reinterpret_cast<float4 *>(Ob + ((long long)buf * 32 + (j >> 4)) * kObLd + 4 * (j & 15)) = v;
@@ -1053,9 +1053,16 @@ dx1w1_kernel(const float *__restrict__ dZ, const float *__restrict__ X1, const f
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const float *As = Az + ((long long)buf * kG4 + 128 * kh) * kD1Ld + li;
+            // A operand: row li of the chunk, k = 128 * kh + s2 -- four MFMA steps per 16-byte LDS read
+            const float4 *As = reinterpret_cast<const float4 *>(Az + ((long long)buf * 32 + li) * kD1Ld + 128 * kh);
 #pragma unroll
-            for (int s2 = 0; s2 < 128; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[s2 * kD1Ld], bw[s2], acc, 0, 0, 0);
+            for (int j4 = 0; j4 < 32; ++j4) {
+                const float4 a4 = As[j4];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bw[4 * j4], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bw[4 * j4 + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bw[4 * j4 + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bw[4 * j4 + 3], acc, 0, 0, 0);
+            }
             const float *Os = Ob + (long long)buf * 32 * kObLd + li;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -1236,7 +1243,7 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     m->fused_dx = !L.fc && (L.H == 224 || L.H == 160) && L.SMAX <= 64 && L.SMAX % 4 == 0;
     if (const char *ev = getenv("TSC_UNFUSED_DX")) if (atoi(ev)) m->fused_dx = 0;
     if (m->fused_dx) {
-        const int lds = (int)(sizeof(float) * (2 * kG4 * kD1Ld + 2 * 32 * kObLd));
+        const int lds = (int)(sizeof(float) * (2 * 32 * kD1Ld + 2 * 32 * kObLd));
         TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
@@ -1477,7 +1484,7 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
         // dX1 stays in registers: dW1 | db1 come out of the same pass (dx1w1_kernel)
         long long rps = (N + S - 1) / S;
         rps = (rps + 31) / 32 * 32;                  // whole 32-row chunks
-        const size_t lds = sizeof(float) * (2 * kG4 * kD1Ld + 2 * 32 * kObLd);
+        const size_t lds = sizeof(float) * (2 * 32 * kD1Ld + 2 * 32 * kObLd);
         {
             tsc::ProfScope ps(tsc::KID_DX1_GEMM, m->stream);
             if (L.H == 224) hipLaunchKernelGGL(dx1w1_kernel<7>, dim3((unsigned)(S * G)), dim3(512), lds, st, m->Z, m->X1, m->WxT, m->r_obs, N, (int)G, S, rps, (int)A, L.SMAX, m->ws);
