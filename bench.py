@@ -60,7 +60,7 @@ def algorithmic_flops(model, rows):
             'dwo_gemm': out * rows}
 
 
-def cpu_baseline(n_env=16, n_step=120, threads=8):
+def cpu_baseline(n_env=48, n_step=120, threads=8):
     """Same iteration on the host: oracle/ (test infrastructure) = C microsim + NumPy restatement of
     envs/env.py + torch-CPU restatement of agents/policies.py.  Bounded sample: n_env env instances,
     one iteration (n_step control steps + update)."""
