@@ -700,6 +700,202 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
 #undef FSTAMP
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight-stationary rollout forward.  The kernel above streams a tower's 330 KB of weights out of L2 once per
+// 64-instance tile and runs 1.56 rounds of latency-chain workgroups.  Here ONE 8-wave workgroup per (tower, fifth of
+// the instances) loads the weights ONCE into registers -- wave w owns gate columns [32w, 32w + 32) of [Wx ; Wh]
+// (KS2 = (H + 64) / 2 MFMA steps = 144 registers per lane) and, for w < H / 32, column tile w of W1 -- and then
+// walks its 32-instance tiles:
+//   obs -> LDS (k-major) -> X1 tile per wave (MFMA, W1 in LDS) -> LDS (instance-major, so the gate GEMM reads its A
+//   operand as 16-byte quads) -> gate tile per wave (KS2 MFMAs, [Wx;Wh] stationary) -> LDS [256][33] -> cell update with thread = (instance, 4 units): float4 state / cache traffic ->
+//   h -> LDS -> head -> softmax -> action.
+// G x S workgroups (S = 256 / G) ~ one per CU, every instance tile of a tower is a loop iteration instead of a
+// workgroup, the next tile's obs / state are prefetched under the gate MFMAs.
+// ------------------------------------------------------------------------------------------------
+constexpr int kWsLdx = 36;       // activations [k][32 instances + 4]
+constexpr int kWsLdg = 33;       // gate pre-activations [256 columns][32 instances + 1]
+
+template <int KS2>
+__global__ void __launch_bounds__(512, 1)
+policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__restrict__ n_act,
+                     const float *__restrict__ obs, const uint8_t *__restrict__ done, float *state, int advance,
+                     int E, int S, float *__restrict__ pi_out, float *__restrict__ v_out, int *action_out,
+                     unsigned long long seed, unsigned long long step,
+                     int tslot, long long Ntot, float *X1c, float *Zc, float *Hhc, float *Ccc, float *Hpc) {
+    constexpr int H = 2 * KS2 - 64, NCT = H / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int LDK = H + 64 + 4;                     // [X1 | h_prev] row of one instance (+4: 16-byte reads stay conflict-free)
+    float *XH = (float *)smem_raw;                      // [32 instances][LDK]: A operand of the gate GEMM, read as float4 quads
+    float *Hs = XH + 32 * LDK;                          // [64 k][kWsLdx]: obs tile, k-major (A operand of the first layer)
+    float *Hn = Hs + 64 * kWsLdx;                       // [64 units][kWsLdg]: new h, k-major for the head
+    float *Gz = Hn + kL * kWsLdg;                       // [256][kWsLdg]
+    float *WoS = Gz + kG4 * kWsLdg;                     // [64][8] + [8] (+ pad to 528)
+    float *LG = WoS + 528;                              // [32][8]
+    float *W1s = LG + 32 * kOut;                        // [SMAX][H]: W1 is small enough to sit in LDS for the whole launch
+    const int g = blockIdx.x % lay.G, sp = blockIdx.x / lay.G;
+    const int n_tiles = (E + 31) / 32;
+    const int t0 = (int)((long long)n_tiles * sp / S), t1 = (int)((long long)n_tiles * (sp + 1) / S);
+    const int a = g >> 1, tower = g & 1, SMAX = lay.SMAX;
+    const float *P = params + (long long)g * lay.stride;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
+    const int col = 32 * wave + li;
+    // ---- stationary operands
+    float bwg[KS2];
+    {
+        // contraction index of MFMA step s2 in lane half kh: k = 8 * (s2 / 4) + 4 * kh + s2 % 4, so that a lane's A
+        // operands of four consecutive steps are one 16-byte LDS read
+        const float *src = P + lay.oWx + col;
+#pragma unroll
+        for (int s2 = 0; s2 < KS2; ++s2) bwg[s2] = src[(long long)(8 * (s2 >> 2) + 4 * kh + (s2 & 3)) * kG4];
+    }
+    for (int i = tid; i < SMAX * H / 4; i += 512)
+        reinterpret_cast<float4 *>(W1s)[i] = reinterpret_cast<const float4 *>(P + lay.oW1)[i];
+    const float blc = P[lay.obl + col];
+    const float b1c = wave < NCT ? P[lay.ob1 + col] : 0.f;
+    if (tid < (kL * kOut + kOut) / 4)
+        *reinterpret_cast<float4 *>(WoS + 4 * tid) = *reinterpret_cast<const float4 *>(P + lay.oWo + 4 * tid);
+    // ---- per-tile roles: obs loader (one float4), cell thread = (instance ce, units cu..cu+3)
+    const int q4 = SMAX >> 2, AS = lay.A * SMAX;
+    const bool ob_on = tid < 32 * q4;
+    const int om = ob_on ? tid / q4 : 0, ok4 = ob_on ? (tid % q4) * 4 : 0;
+    const int ce = tid >> 4, cu = (tid & 15) * 4;
+    const float *stb = state + (long long)g * E * 2 * kL;
+    auto fetch_obs = [&](int e0) {
+        const int e = e0 + om < E ? e0 + om : E - 1;
+        return *reinterpret_cast<const float4 *>(obs + (long long)e * AS + a * SMAX + ok4);
+    };
+    auto fetch_state = [&](int e0, int off) {
+        const int e = e0 + ce < E ? e0 + ce : E - 1;
+        return *reinterpret_cast<const float4 *>(stb + (long long)e * 2 * kL + off + cu);
+    };
+    auto fetch_keep = [&](int e0) { return 1.0f - (float)done[e0 + ce < E ? e0 + ce : E - 1]; };
+    float4 ov = make_float4(0.f, 0.f, 0.f, 0.f), c4 = ov, h4 = ov;
+    float keep = 0.f;
+    if (t0 < t1) { ov = fetch_obs(32 * t0); c4 = fetch_state(32 * t0, 0); h4 = fetch_state(32 * t0, kL); keep = fetch_keep(32 * t0); }
+    for (int tt = t0; tt < t1; ++tt) {
+        const int e0 = 32 * tt;
+        const long long nb0 = (long long)g * Ntot + (long long)(tslot < 0 ? 0 : tslot) * E + e0;   // first cache row of the tile
+        // ---- phase 0: obs tile -> LDS, k-major; rows [SMAX, 64) of the staging area are zero
+        if (ob_on) {
+            Hs[(ok4 + 0) * kWsLdx + om] = ov.x; Hs[(ok4 + 1) * kWsLdx + om] = ov.y;
+            Hs[(ok4 + 2) * kWsLdx + om] = ov.z; Hs[(ok4 + 3) * kWsLdx + om] = ov.w;
+        }
+        for (int idx = tid; idx < (64 - SMAX) * 32; idx += 512) Hs[(SMAX + (idx >> 5)) * kWsLdx + (idx & 31)] = 0.f;
+        __syncthreads();
+        // ---- phase 1: X1 = relu(obs W1 + b1): wave w < NCT owns column tile w
+        if (wave < NCT) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const int ks1 = (SMAX + 1) >> 1;                       // obs rows past SMAX are zero; W1 rows clamped
+            for (int s2 = 0; s2 < ks1; ++s2) {
+                const int kr = 2 * s2 + kh < SMAX ? 2 * s2 + kh : SMAX - 1;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Hs[(2 * s2 + kh) * kWsLdx + li], W1s[kr * H + col], acc, 0, 0, 0);
+            }
+            float *x1b = X1c + nb0 * H;
+            int z1 = 0;
+            asm volatile("" : "+v"(z1));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kh + z1;
+                float v0 = acc[r] + b1c;
+                v0 = v0 > 0.f ? v0 : 0.f;
+                XH[row * LDK + col] = v0;
+                if (tslot >= 0 && e0 + row < E) stg(x1b, (unsigned)(row * H + col) * 4u, v0);
+            }
+        }
+        // ---- phase 1.5: done-masked h_prev -> columns [H, H+64) of the instance's row (no barrier before: phase 1
+        // writes columns [0, H))
+        const float4 hm = make_float4(h4.x * keep, h4.y * keep, h4.z * keep, h4.w * keep);
+        const float4 cm = make_float4(c4.x * keep, c4.y * keep, c4.z * keep, c4.w * keep);
+        *reinterpret_cast<float4 *>(XH + ce * LDK + H + cu) = hm;
+        if (tslot >= 0 && e0 + ce < E) *reinterpret_cast<float4 *>(Hpc + (nb0 + ce) * kL + cu) = hm;
+        __syncthreads();
+        // next tile's inputs: in flight under the gate MFMAs
+        float4 nov = ov, nc4 = c4, nh4 = h4;
+        float nkeep = keep;
+        if (tt + 1 < t1) { nov = fetch_obs(e0 + 32); nc4 = fetch_state(e0 + 32, 0); nh4 = fetch_state(e0 + 32, kL); nkeep = fetch_keep(e0 + 32); }
+        // ---- phase 2: gate tile of this wave = bl + [X1 | h] [Wx ; Wh][:, 32w .. 32w+32)
+        {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = blc;
+            const float4 *As = reinterpret_cast<const float4 *>(XH + li * LDK + 4 * kh);
+#pragma unroll
+            for (int j4 = 0; j4 < KS2 / 4; ++j4) {
+                const float4 a4 = As[2 * j4];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bwg[4 * j4], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bwg[4 * j4 + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bwg[4 * j4 + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bwg[4 * j4 + 3], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Gz[col * kWsLdg + (r & 3) + 8 * (r >> 2) + 4 * kh] = acc[r];
+        }
+        __syncthreads();
+        // ---- phase 3: cell update of (instance ce, units cu..cu+3); h -> LDS rows [0, 64)
+        {
+            float gi[4], gf[4], go[4], gu[4], cn[4], hn[4];
+            const float cin[4] = {cm.x, cm.y, cm.z, cm.w};
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int u = cu + jj;
+                gi[jj] = sigmoidf_(Gz[u * kWsLdg + ce]); gf[jj] = sigmoidf_(Gz[(64 + u) * kWsLdg + ce]);
+                go[jj] = sigmoidf_(Gz[(128 + u) * kWsLdg + ce]); gu[jj] = tanhf_(Gz[(192 + u) * kWsLdg + ce]);
+                cn[jj] = gf[jj] * cin[jj] + gi[jj] * gu[jj];
+                hn[jj] = go[jj] * tanhf_(cn[jj]);
+                Hn[u * kWsLdg + ce] = hn[jj];
+            }
+            if (e0 + ce < E) {
+                const float4 c4n = make_float4(cn[0], cn[1], cn[2], cn[3]), h4n = make_float4(hn[0], hn[1], hn[2], hn[3]);
+                if (advance) {
+                    float *st = state + ((long long)g * E + e0 + ce) * 2 * kL + cu;
+                    *reinterpret_cast<float4 *>(st) = c4n; *reinterpret_cast<float4 *>(st + kL) = h4n;
+                }
+                if (tslot >= 0) {                                  // what lstm_fwd_kernel<true> would store
+                    float *zr = Zc + (nb0 + ce) * kG4 + cu;
+                    *reinterpret_cast<float4 *>(zr) = make_float4(gi[0], gi[1], gi[2], gi[3]);
+                    *reinterpret_cast<float4 *>(zr + 64) = make_float4(gf[0], gf[1], gf[2], gf[3]);
+                    *reinterpret_cast<float4 *>(zr + 128) = make_float4(go[0], go[1], go[2], go[3]);
+                    *reinterpret_cast<float4 *>(zr + 192) = make_float4(gu[0], gu[1], gu[2], gu[3]);
+                    *reinterpret_cast<float4 *>(Ccc + (nb0 + ce) * kL + cu) = c4n;
+                    *reinterpret_cast<float4 *>(Hhc + (nb0 + ce) * kL + cu) = h4n;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 4: head.  thread -> (instance tid & 31, output tid >> 5), 256 threads
+        if (tid < 256) {
+            const int e = tid & 31, k0 = tid >> 5;
+            float s0 = 0.f;
+#pragma unroll 8
+            for (int jj = 0; jj < kL; ++jj) s0 += Hn[jj * kWsLdg + e] * WoS[jj * kOut + k0];
+            LG[e * kOut + k0] = s0 + WoS[kL * kOut + k0];
+        }
+        __syncthreads();
+        if (tid < 32 && e0 + tid < E) {
+            const long long idx = (long long)(e0 + tid) * lay.A + a;
+            const float *lg = LG + tid * kOut;
+            if (tower == 0) {
+                const int na = n_act[a];
+                float mx = -INFINITY;
+                for (int k = 0; k < na; ++k) mx = fmaxf(mx, lg[k]);
+                float pk[kOut], sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < kOut; ++k) { pk[k] = k < na ? expf(lg[k] - mx) : 0.f; sum += pk[k]; }
+                float pn[kOut];
+#pragma unroll
+                for (int k = 0; k < kOut; ++k) pn[k] = pk[k] / sum;
+                for (int k = 0; k < lay.AMAX; ++k) pi_out[idx * lay.AMAX + k] = k < kOut ? pn[k] : 0.f;
+                if (action_out) action_out[idx] = sample_action(pn, na, seed, step, idx);   // utils.py:155-157
+            } else {
+                v_out[idx] = lg[0];
+            }
+        }
+        ov = nov; c4 = nc4; h4 = nh4; keep = nkeep;
+    }
+}
+
 // n-step returns and advantages (agents/utils.py:202-228): float64 recursion from the back with
 // POST-step dones, Adv = R - v, cast to float32.   rew f64 [T][E][A], val f32, done_all u8 [T+1][E]
 __global__ void returns_kernel(const double *rew, const float *val, const uint8_t *done_all, const float *Rboot,
@@ -1126,7 +1322,7 @@ struct tsc_model {
     double *norm2, *stats;
     float *ws, *wsc;            // split-K workspace
     size_t ws_floats, wsc_floats;
-    size_t lds_fwd, lds_bwd, lds_fused;
+    size_t lds_fwd, lds_bwd, lds_fused, lds_ws;
     int fused_fwd;
     int fused_dw;               // dWx | dWh | dbl in one pass (dwxh_kernel)
     int fused_dx;               // dX1 in registers, dW1 | db1 in the same pass (dx1w1_kernel)
@@ -1247,6 +1443,14 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
         TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
+    m->lds_ws = sizeof(float) * ((size_t)32 * (L.H + 64 + 4) + 64 * kWsLdx + (size_t)kL * kWsLdg + (size_t)kG4 * kWsLdg + 528 + 32 * kOut + (size_t)L.SMAX * L.H);
+    if (m->fused_fwd && (L.H == 224 || L.H == 160) && m->lds_ws <= 160 * 1024) {
+        // weight-stationary variant (TSC_FWD_WS=0 falls back to the tile-per-workgroup kernel)
+        const char *ev = getenv("TSC_FWD_WS");
+        if (!(ev && ev[0] == '0')) m->fused_fwd = 2;
+        TSC_HIP(hipFuncSetAttribute((const void *)policy_fwd_ws_kernel<144>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_ws));
+        TSC_HIP(hipFuncSetAttribute((const void *)policy_fwd_ws_kernel<112>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_ws));
+    }
     if (m->fused_fwd)
         TSC_HIP(hipFuncSetAttribute((const void *)policy_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fused));
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((m->nparam + 255) / 256)), dim3(256), 0, 0, m->ms, m->nparam, 1.0f);
@@ -1328,12 +1532,25 @@ static int model_forward(tsc_model *m, const float *obs, const uint8_t *done, fl
     }
     if (m->fused_fwd) {
         const int n_tiles = (E + 63) / 64, per_xcd = (L.G + 7) / 8;
-        if (m->wg_dirty) {                                  // parameters changed since the interleaved copy was made
+        if (m->wg_dirty && m->fused_fwd == 1) {             // parameters changed since the interleaved copy was made
             const long long tot = (long long)L.G * (L.H + kL) * kG4;
             hipLaunchKernelGGL(interleave_gates_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, m->stream, m->params, L, m->Wg);
             m->wg_dirty = 0;
         }
         tsc::ProfScope ps(tsc::KID_FUSED_FWD, m->stream);
+        if (m->fused_fwd == 2) {
+            int S = 256 / L.G;
+            if (S < 1) S = 1;
+            if (S > (E + 31) / 32) S = (E + 31) / 32;
+#define TSC_WS(KS2) hipLaunchKernelGGL(policy_fwd_ws_kernel<KS2>, dim3((unsigned)(L.G * S)), dim3(512), m->lds_ws, m->stream, m->params, \
+                                       L, m->n_act, obs, done, m->state_fw, (int)advance, E, S, pi, v, action, (unsigned long long)seed,     \
+                                       (unsigned long long)step, (int)tslot, (long long)m->T * E, m->X1, m->Z, m->Hh, m->Cc, m->Hp)
+            if (L.H == 224) TSC_WS(144); else TSC_WS(112);
+#undef TSC_WS
+            ps.stop();
+            TSC_HIP(hipGetLastError());
+            return 0;
+        }
         hipLaunchKernelGGL(policy_fwd_fused_kernel, dim3(8 * per_xcd * n_tiles), dim3(256), m->lds_fused, m->stream, m->params,
                            L, m->n_act, obs, done, m->state_fw, (int)advance, E, n_tiles, pi, v, action,
                            (unsigned long long)seed, (unsigned long long)step, m->dbg, (int)tslot, (long long)m->T * E,

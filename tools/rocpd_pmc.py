@@ -13,7 +13,7 @@ import json
 import sqlite3
 import sys
 
-NAMES = [('step_kernel', 'env_step'), ('policy_fwd_fused', 'policy_fwd_fused'), ('dwxh_kernel', 'dwx_gemm'),
+NAMES = [('step_kernel', 'env_step'), ('policy_fwd_fused', 'policy_fwd_fused'), ('policy_fwd_ws', 'policy_fwd_fused'), ('dwxh_kernel', 'dwx_gemm'),
          ('dx1w1_kernel', 'dx1_gemm'), ('lstm_bwd', 'lstm_bwd'), ('lstm_fwd', 'lstm_fwd'), ('head_bwd', 'head_bwd'),
          ('head_fwd', 'head_fwd'), ('add_transition', 'add_transition'), ('dwxh_reduce', 'dwh_gemm'),
          ('dx1w1_reduce', 'dw1_gemm'), ('returns_kernel', 'returns'), ('rmsprop', 'rmsprop'), ('grad_norm', 'grad_norm'),
