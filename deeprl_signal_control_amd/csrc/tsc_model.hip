@@ -714,6 +714,7 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
 // ------------------------------------------------------------------------------------------------
 constexpr int kWsLdx = 36;       // activations [k][32 instances + 4]
 constexpr int kWsLdg = 33;       // gate pre-activations [256 columns][32 instances + 1]
+constexpr int kWsBuf = 8;        // tiles whose logits are buffered before the softmax / sampling pass
 
 template <int KS2>
 __global__ void __launch_bounds__(512, 1)
@@ -721,8 +722,13 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
                      const float *__restrict__ obs, const uint8_t *__restrict__ done, float *state, int advance,
                      int E, int S, float *__restrict__ pi_out, float *__restrict__ v_out, int *action_out,
                      unsigned long long seed, unsigned long long step,
-                     int tslot, long long Ntot, float *X1c, float *Zc, float *Hhc, float *Ccc, float *Hpc) {
+                     int tslot, long long Ntot, float *X1c, float *Zc, float *Hhc, float *Ccc, float *Hpc,
+                     long long *dbg) {
     constexpr int H = 2 * KS2 - 64, NCT = H / 32;
+    const bool stamp = dbg && blockIdx.x == 0 && threadIdx.x == 0;
+    int nstamp = 0;
+#define WSTAMP() do { if (stamp && nstamp < 60) dbg[nstamp++] = clock64(); } while (0)
+    WSTAMP();
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int LDK = H + 64 + 4;                     // [X1 | h_prev] row of one instance (+4: 16-byte reads stay conflict-free)
     float *XH = (float *)smem_raw;                      // [32 instances][LDK]: A operand of the gate GEMM, read as float4 quads
@@ -730,8 +736,11 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
     float *Hn = Hs + 64 * kWsLdx;                       // [64 units][kWsLdg]: new h, k-major for the head
     float *Gz = Hn + kL * kWsLdg;                       // [256][kWsLdg]
     float *WoS = Gz + kG4 * kWsLdg;                     // [64][8] + [8] (+ pad to 528)
-    float *LG = WoS + 528;                              // [32][8]
-    float *W1s = LG + 32 * kOut;                        // [SMAX][H]: W1 is small enough to sit in LDS for the whole launch
+    float *LG = WoS + 528;                              // [kWsBuf tiles][32][8] logits, then [32][8] partial sums
+    float *LGp = LG + kWsBuf * 32 * kOut;
+    float *W1s = LGp + 32 * kOut;                        // [SMAX][H]: W1 is small enough to sit in LDS for the whole launch
+    // (numbering the S workgroups of a tower onto one XCD so that four of the five weight reads hit its L2 halves the
+    //  prologue but leaves two XCDs with 35 workgroups for 32 CUs: 126 -> 207 us)
     const int g = blockIdx.x % lay.G, sp = blockIdx.x / lay.G;
     const int n_tiles = (E + 31) / 32;
     const int t0 = (int)((long long)n_tiles * sp / S), t1 = (int)((long long)n_tiles * (sp + 1) / S);
@@ -772,6 +781,29 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
     float4 ov = make_float4(0.f, 0.f, 0.f, 0.f), c4 = ov, h4 = ov;
     float keep = 0.f;
     if (t0 < t1) { ov = fetch_obs(32 * t0); c4 = fetch_state(32 * t0, 0); h4 = fetch_state(32 * t0, kL); keep = fetch_keep(32 * t0); }
+    // softmax + action of the buffered tiles (~600 instructions per instance, half of them float64): one instance
+    // per thread for up to kWsBuf tiles at once instead of 32 threads after every tile
+    auto emit = [&](int e0p, int nbuf) {
+        if (tid >= 32 * nbuf || e0p + tid >= E) return;
+        const long long idx = (long long)(e0p + tid) * lay.A + a;
+        const float *lg = LG + tid * kOut;
+        if (tower == 0) {
+            const int na = n_act[a];
+            float mx = -INFINITY;
+            for (int k = 0; k < na; ++k) mx = fmaxf(mx, lg[k]);
+            float pk[kOut], sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < kOut; ++k) { pk[k] = k < na ? expf(lg[k] - mx) : 0.f; sum += pk[k]; }
+            float pn[kOut];
+#pragma unroll
+            for (int k = 0; k < kOut; ++k) pn[k] = pk[k] / sum;
+            for (int k = 0; k < lay.AMAX; ++k) pi_out[idx * lay.AMAX + k] = k < kOut ? pn[k] : 0.f;
+            if (action_out) action_out[idx] = sample_action(pn, na, seed, step, idx);   // utils.py:155-157
+        } else {
+            v_out[idx] = lg[0];
+        }
+    };
+    WSTAMP();
     for (int tt = t0; tt < t1; ++tt) {
         const int e0 = 32 * tt;
         const long long nb0 = (long long)g * Ntot + (long long)(tslot < 0 ? 0 : tslot) * E + e0;   // first cache row of the tile
@@ -782,6 +814,7 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
         }
         for (int idx = tid; idx < (64 - SMAX) * 32; idx += 512) Hs[(SMAX + (idx >> 5)) * kWsLdx + (idx & 31)] = 0.f;
         __syncthreads();
+        WSTAMP();
         // ---- phase 1: X1 = relu(obs W1 + b1): wave w < NCT owns column tile w
         if (wave < NCT) {
             f32x16 acc;
@@ -811,6 +844,7 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
         *reinterpret_cast<float4 *>(XH + ce * LDK + H + cu) = hm;
         if (tslot >= 0 && e0 + ce < E) *reinterpret_cast<float4 *>(Hpc + (nb0 + ce) * kL + cu) = hm;
         __syncthreads();
+        WSTAMP();
         // next tile's inputs: in flight under the gate MFMAs
         float4 nov = ov, nc4 = c4, nh4 = h4;
         float nkeep = keep;
@@ -832,7 +866,9 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
 #pragma unroll
             for (int r = 0; r < 16; ++r) Gz[col * kWsLdg + (r & 3) + 8 * (r >> 2) + 4 * kh] = acc[r];
         }
+        WSTAMP();
         __syncthreads();
+        WSTAMP();
         // ---- phase 3: cell update of (instance ce, units cu..cu+3); h -> LDS rows [0, 64)
         {
             float gi[4], gf[4], go[4], gu[4], cn[4], hn[4];
@@ -864,36 +900,28 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
             }
         }
         __syncthreads();
-        // ---- phase 4: head.  thread -> (instance tid & 31, output tid >> 5), 256 threads
-        if (tid < 256) {
-            const int e = tid & 31, k0 = tid >> 5;
+        WSTAMP();
+        // ---- phase 4: head.  thread -> (instance tid & 31, output (tid >> 5) & 7, half of the units tid >> 8)
+        {
+            const int e = tid & 31, k0 = (tid >> 5) & 7, hf = tid >> 8;
             float s0 = 0.f;
 #pragma unroll 8
-            for (int jj = 0; jj < kL; ++jj) s0 += Hn[jj * kWsLdg + e] * WoS[jj * kOut + k0];
-            LG[e * kOut + k0] = s0 + WoS[kL * kOut + k0];
-        }
-        __syncthreads();
-        if (tid < 32 && e0 + tid < E) {
-            const long long idx = (long long)(e0 + tid) * lay.A + a;
-            const float *lg = LG + tid * kOut;
-            if (tower == 0) {
-                const int na = n_act[a];
-                float mx = -INFINITY;
-                for (int k = 0; k < na; ++k) mx = fmaxf(mx, lg[k]);
-                float pk[kOut], sum = 0.f;
-#pragma unroll
-                for (int k = 0; k < kOut; ++k) { pk[k] = k < na ? expf(lg[k] - mx) : 0.f; sum += pk[k]; }
-                float pn[kOut];
-#pragma unroll
-                for (int k = 0; k < kOut; ++k) pn[k] = pk[k] / sum;
-                for (int k = 0; k < lay.AMAX; ++k) pi_out[idx * lay.AMAX + k] = k < kOut ? pn[k] : 0.f;
-                if (action_out) action_out[idx] = sample_action(pn, na, seed, step, idx);   // utils.py:155-157
-            } else {
-                v_out[idx] = lg[0];
+            for (int jj = 32 * hf; jj < 32 * hf + 32; ++jj) s0 += Hn[jj * kWsLdg + e] * WoS[jj * kOut + k0];
+            if (hf) LGp[e * kOut + k0] = s0;
+            __syncthreads();
+            const int slot = (tt - t0) % kWsBuf;
+            if (!hf) LG[(slot * 32 + e) * kOut + k0] = (s0 + LGp[e * kOut + k0]) + WoS[kL * kOut + k0];
+            if (slot == kWsBuf - 1 || tt == t1 - 1) {            // buffer full or last tile: emit (uniform branch)
+                __syncthreads();
+                emit(32 * (tt - slot), slot + 1);
             }
         }
+        __syncthreads();
         ov = nov; c4 = nc4; h4 = nh4; keep = nkeep;
+        WSTAMP();
     }
+    if (stamp) dbg[63] = nstamp;
+#undef WSTAMP
 }
 
 // n-step returns and advantages (agents/utils.py:202-228): float64 recursion from the back with
@@ -1443,7 +1471,7 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
         TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
-    m->lds_ws = sizeof(float) * ((size_t)32 * (L.H + 64 + 4) + 64 * kWsLdx + (size_t)kL * kWsLdg + (size_t)kG4 * kWsLdg + 528 + 32 * kOut + (size_t)L.SMAX * L.H);
+    m->lds_ws = sizeof(float) * ((size_t)32 * (L.H + 64 + 4) + 64 * kWsLdx + (size_t)kL * kWsLdg + (size_t)kG4 * kWsLdg + 528 + (kWsBuf + 1) * 32 * kOut + (size_t)L.SMAX * L.H);
     if (m->fused_fwd && (L.H == 224 || L.H == 160) && m->lds_ws <= 160 * 1024) {
         // weight-stationary variant (TSC_FWD_WS=0 falls back to the tile-per-workgroup kernel)
         const char *ev = getenv("TSC_FWD_WS");
@@ -1544,7 +1572,7 @@ static int model_forward(tsc_model *m, const float *obs, const uint8_t *done, fl
             if (S > (E + 31) / 32) S = (E + 31) / 32;
 #define TSC_WS(KS2) hipLaunchKernelGGL(policy_fwd_ws_kernel<KS2>, dim3((unsigned)(L.G * S)), dim3(512), m->lds_ws, m->stream, m->params, \
                                        L, m->n_act, obs, done, m->state_fw, (int)advance, E, S, pi, v, action, (unsigned long long)seed,     \
-                                       (unsigned long long)step, (int)tslot, (long long)m->T * E, m->X1, m->Z, m->Hh, m->Cc, m->Hp)
+                                       (unsigned long long)step, (int)tslot, (long long)m->T * E, m->X1, m->Z, m->Hh, m->Cc, m->Hp, m->dbg)
             if (L.H == 224) TSC_WS(144); else TSC_WS(112);
 #undef TSC_WS
             ps.stop();
