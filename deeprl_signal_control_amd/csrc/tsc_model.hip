@@ -748,17 +748,17 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
     const float *P = params + (long long)g * lay.stride;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
     const int col = 32 * wave + li;
-    // ---- stationary operands
-    float bwg[KS2];
-    {
-        // contraction index of MFMA step s2 in lane half kh: k = 8 * (s2 / 4) + 4 * kh + s2 % 4, so that a lane's A
-        // operands of four consecutive steps are one 16-byte LDS read
-        const float *src = P + lay.oWx + col;
+    {   // W1 -> LDS: eight 16-byte loads in flight per thread and round (one round for SMAX <= 64)
+        const int tot = SMAX * H / 4;
+        const float4 *src = reinterpret_cast<const float4 *>(P + lay.oW1);
+        for (int base = tid; base < tot; base += 8 * 512) {
+            float4 wq[8];
 #pragma unroll
-        for (int s2 = 0; s2 < KS2; ++s2) bwg[s2] = src[(long long)(8 * (s2 >> 2) + 4 * kh + (s2 & 3)) * kG4];
+            for (int q = 0; q < 8; ++q) { const int i = base + 512 * q; wq[q] = src[i < tot ? i : tot - 1]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int i = base + 512 * q; if (i < tot) reinterpret_cast<float4 *>(W1s)[i] = wq[q]; }
+        }
     }
-    for (int i = tid; i < SMAX * H / 4; i += 512)
-        reinterpret_cast<float4 *>(W1s)[i] = reinterpret_cast<const float4 *>(P + lay.oW1)[i];
     const float blc = P[lay.obl + col];
     const float b1c = wave < NCT ? P[lay.ob1 + col] : 0.f;
     if (tid < (kL * kOut + kOut) / 4)
@@ -780,7 +780,18 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
     auto fetch_keep = [&](int e0) { return 1.0f - (float)done[e0 + ce < E ? e0 + ce : E - 1]; };
     float4 ov = make_float4(0.f, 0.f, 0.f, 0.f), c4 = ov, h4 = ov;
     float keep = 0.f;
-    if (t0 < t1) { ov = fetch_obs(32 * t0); c4 = fetch_state(32 * t0, 0); h4 = fetch_state(32 * t0, kL); keep = fetch_keep(32 * t0); }
+    if (t0 >= t1) return;                                      // fewer tiles than workgroups per tower
+    ov = fetch_obs(32 * t0); c4 = fetch_state(32 * t0, 0); h4 = fetch_state(32 * t0, kL); keep = fetch_keep(32 * t0);
+    // ---- stationary operand, requested LAST: the first tile's obs / first-layer phases wait (counted, in order) only
+    // for what was requested before it, so the 144 weight loads land under them instead of in front of the loop
+    float bwg[KS2];
+    {
+        // contraction index of MFMA step s2 in lane half kh: k = 8 * (s2 / 4) + 4 * kh + s2 % 4, so that a lane's A
+        // operands of four consecutive steps are one 16-byte LDS read
+        const float *src = P + lay.oWx + col;
+#pragma unroll
+        for (int s2 = 0; s2 < KS2; ++s2) bwg[s2] = src[(long long)(8 * (s2 >> 2) + 4 * kh + (s2 & 3)) * kG4];
+    }
     // softmax + action of the buffered tiles (~600 instructions per instance, half of them float64): one instance
     // per thread for up to kWsBuf tiles at once instead of 32 threads after every tile
     auto emit = [&](int e0p, int nbuf) {
@@ -821,10 +832,17 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const int ks1 = (SMAX + 1) >> 1;                       // obs rows past SMAX are zero; W1 rows clamped
-            for (int s2 = 0; s2 < ks1; ++s2) {
-                const int kr = 2 * s2 + kh < SMAX ? 2 * s2 + kh : SMAX - 1;
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Hs[(2 * s2 + kh) * kWsLdx + li], W1s[kr * H + col], acc, 0, 0, 0);
+            auto w1row = [&](int s2) { return 2 * s2 + kh < SMAX ? 2 * s2 + kh : SMAX - 1; };
+            int s2 = 0;
+            for (; s2 + 4 <= ks1; s2 += 4) {                       // four steps: all LDS operands first, then the MFMAs
+                float av[4], bv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { av[q] = Hs[(2 * (s2 + q) + kh) * kWsLdx + li]; bv[q] = W1s[w1row(s2 + q) * H + col]; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
             }
+            for (; s2 < ks1; ++s2)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Hs[(2 * s2 + kh) * kWsLdx + li], W1s[w1row(s2) * H + col], acc, 0, 0, 0);
             float *x1b = X1c + nb0 * H;
             int z1 = 0;
             asm volatile("" : "+v"(z1));
