@@ -54,9 +54,16 @@ def algorithmic_flops(model, rows):
     H, L, G = model.H, model.Lh, model.G
     out = sum(2 * L * (na + 1) for na in model.n_a_ls)
     fused = fc + G * 2 * H * 4 * L + G * 2 * L * 4 * L + out           # one rollout forward of every tower
-    return {'policy_fwd_fused': fused * rows, 'fc_gemm': fc * rows, 'zx_gemm': G * 2 * H * 4 * L * rows, 'lstm_fwd': G * 2 * L * 4 * L * rows,
-            'lstm_bwd': G * 2 * L * 4 * L * rows, 'dwx_gemm': G * 2 * H * 4 * L * rows,
-            'dx1_gemm': G * 2 * H * 4 * L * rows, 'dwh_gemm': G * 2 * L * 4 * L * rows, 'dw1_gemm': fc * rows,
+    # profile ids keep the names of the grouped GEMMs they started as: with the fused update kernels (default)
+    # 'dwx_gemm' times dwxh_kernel (dWx + dWh + dbl in one pass) and 'dx1_gemm' times dx1w1_kernel (dX1 + dW1 + db1);
+    # 'dwh_gemm' / 'dw1_gemm' are then only their split reductions
+    dwx = G * 2 * H * 4 * L * rows
+    dwh = G * 2 * L * 4 * L * rows
+    fused_update = model.policy == 'lstm' and H in (160, 224)
+    return {'policy_fwd_fused': fused * rows, 'fc_gemm': fc * rows, 'zx_gemm': G * 2 * H * 4 * L * rows,
+            'lstm_fwd': G * 2 * L * 4 * L * rows, 'lstm_bwd': G * 2 * L * 4 * L * rows,
+            'dwx_gemm': dwx + dwh if fused_update else dwx, 'dwh_gemm': 0.0 if fused_update else dwh,
+            'dx1_gemm': dwx + fc * rows if fused_update else dwx, 'dw1_gemm': 0.0 if fused_update else fc * rows,
             'dwo_gemm': out * rows}
 
 
