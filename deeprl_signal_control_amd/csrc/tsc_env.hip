@@ -9,12 +9,14 @@
 //   K5 observation gather .... envs/env.py:163-205,439-442 (float64 arithmetic, cast to f32)
 //   K6 reward + shaping ...... envs/env.py:356-367,580,590-631 (float64, numpy sum order)
 //
-// Mapping: one workgroup per env instance, one thread per lane (lanes padded to a multiple of
-// 64 = NLP).  Vehicles live in HBM as slot-major SoA  X/V/SF/M[E][CAP][NLP]: slot i of all lanes
-// of one env is contiguous, so the per-lane front-to-back walk issues fully coalesced loads.
-// Everything lanes need from *other* lanes (tail/head summaries, signal states, the per-step
-// hand-off outbox, the route tables) is staged in LDS; one control step (2 yellow + 3 green
-// simulated seconds, detectors, obs, reward) is a single launch with 2 barriers per second.
+// Mapping: one workgroup per env instance: one thread per lane that a route can ever put a vehicle on (a
+// prefix after load sorting, padded to a multiple of 64 = NLA) plus helper threads up to 256.  Vehicles live
+// in HBM as slot-major SoA  X/V/SF/M[E][CAP][NLP]: slot i of all lanes of one env is contiguous, so the
+// per-lane front-to-back walk issues fully coalesced loads.  Everything lanes need from *other* lanes
+// (tail/head summaries, signal states, the per-step hand-off outbox, the route tables) is staged in LDS; one
+// control step (2 yellow + 3 green simulated seconds, detectors, obs, reward) is a single launch.  Per
+// simulated second: phase A1 (all threads: car-following of every queued vehicle, load-balanced), phase A2
+// (lane threads: the sequential walk), phase B (gather + demand) -- three barriers (see step_kernel).
 //
 // Arithmetic is fp32 with one rounding per operation (-ffp-contract=off, IEEE div/sqrt) so the
 // vehicle state is bit-identical to the CPU oracle; obs/reward are computed in float64 exactly

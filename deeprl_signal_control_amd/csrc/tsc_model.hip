@@ -15,9 +15,14 @@
 // RMSProp accumulator use the same layout, so the gradient buffer is one contiguous RCCL
 // all-reduce.  The three input FCs (wave / fingerprint / wait) are one block-diagonal
 // [SMAX x H] matrix with structural zeros (kept zero by a row-range mask on its gradient).
-// Dense contractions run on the fp32 MFMA grouped GEMM (tsc_gemm.h); the recurrent part is a
-// persistent per-(group, 64-env tile) kernel with Wh resident in LDS and c/h (forward) or
-// dc/dh (backward) resident in registers across the n_step time steps.
+// Kernels (all fp32, v_mfma_f32_32x32x2_f32 for every contraction):
+//   rollout ......... policy_fwd_ws_kernel: one launch per control step, [Wx ; Wh] stationary in registers, also
+//                     fills the activation cache the update reads (policy_fwd_fused_kernel: tile-per-workgroup
+//                     variant; grouped GEMMs + lstm_fwd + head_fwd: training-shape re-forward / FC policy)
+//   update .......... head_bwd -> lstm_bwd (Wh^T stationary in registers, dc/dh in registers over the n_step
+//                     time steps) -> dwxh (dWx | dWh | dbl, whole tower output in accumulators) -> dx1w1 (dX1 in
+//                     registers, chained into dW1 | db1) -> grad_norm -> rmsprop; dWo and the FC-policy path on
+//                     the grouped split-K GEMM (tsc_gemm.h)
 #include "tsc_common.h"
 #include "tsc_gemm.h"
 #include "../../include/tsc.h"
