@@ -98,3 +98,38 @@ def test_microsim_invariants():
     tot = m.totals()
     assert tot['departed'] == tot['arrived'] + tot['live']
     assert tot['live'] > 100
+
+
+@pytest.mark.parametrize('name', ['large_grid', 'real_net'])
+def test_live_lanes_are_a_prefix_after_load_sorting(name):
+    """csrc/tsc_env.hip gives threads / LDS rows only to the lanes a route can put a vehicle on (entry lane ->
+    mv_next chain).  That set must be exactly the lanes with static load > 0 and a prefix [0, NU) of the sorted
+    numbering; unreachable lanes may be referenced as yield lanes / feeders (the loader drops those references)
+    but never as the target of a reachable lane's movement."""
+    from deeprl_signal_control_amd.scenario import build_scenario, lane_load
+    scn = build_scenario(name, 'ma2c')
+    NR = scn.mv_next.shape[1]
+    reach = set()
+    for r in range(NR):
+        l, hops = int(scn.route_entry_lane[r]), 0
+        while l >= 0:
+            reach.add(l)
+            l = int(scn.mv_next[l][r])
+            hops += 1
+            assert hops <= len(scn.lane_len), 'route %d loops' % r
+    nu = max(reach) + 1
+    assert reach == set(range(nu))
+    load = lane_load(scn)
+    assert set(np.nonzero(load > 0)[0].tolist()) == reach
+    assert nu == {'large_grid': 81, 'real_net': 160}[name]
+    for l in reach:
+        for r in range(NR):
+            t = int(scn.mv_next[l][r])
+            if t >= 0 and any(int(scn.route_entry_lane[q]) >= 0 for q in (r,)):
+                # a movement of a route that actually passes l leads to a reachable lane
+                chain, c = set(), int(scn.route_entry_lane[r])
+                while c >= 0:
+                    chain.add(c)
+                    c = int(scn.mv_next[c][r])
+                if l in chain:
+                    assert t in reach
