@@ -90,7 +90,10 @@ class VecTrafficEnv:
             seeds = self.seeds.copy()
             self.seeds += self.seed_stride                      # `self.seed += 1`, env.py:560
         else:
-            seeds = np.full(self.E, self.test_seeds[test_ind], np.int64)
+            # test_ind: one index for every instance (the reference's perform(test_ind)), or one index per
+            # instance so that all test seeds are evaluated in one batched episode
+            ti = np.broadcast_to(np.asarray(test_ind, np.int64), (self.E,))
+            seeds = np.asarray(self.test_seeds, np.int64)[ti]
             self.seeds += self.seed_stride                      # the reference bumps it in test mode too
         s32 = (seeds & 0xFFFFFFFF).astype(np.uint32)
         _lib.check(self._L.tsc_env_reset(self._h, s32.ctypes.data_as(C.POINTER(C.c_uint32)),

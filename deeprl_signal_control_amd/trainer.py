@@ -94,6 +94,69 @@ class VecTrainer:
             if self.global_counter.should_stop():
                 break
 
+    # ---- evaluation (utils.py:195-234, 257-275) ---------------------------------------------
+    def perform(self, test_ind=0, policy_type='default'):
+        """Trainer.perform for every env instance at once: one test episode in the env's current mode
+        (the caller sets train_mode = False for un-shaped rewards), actions sampled from the policy
+        ('default' / 'stochastic') or its argmax ('deterministic').  test_ind: one index, or one per instance.
+        Returns (mean, std) of the global reward over the episode's control steps, float64 arrays [E]
+        (np.mean / np.std of the reference's `rewards` list, per instance)."""
+        env, model = self.env, self.model
+        ob = env.reset(test_ind=test_ind)
+        done = True                                               # pre-decision: resets the LSTM state
+        model.reset()
+        rewards = []
+        while True:
+            pi = model.forward(ob, done, 'p')
+            if self.agent == 'ma2c':
+                env.update_fingerprint(pi)
+            if policy_type != 'deterministic':
+                action = model.sample(pi)
+            else:
+                action = pi.argmax(dim=-1).to(torch.int32)       # padded actions have probability 0
+            ob, _, done, g = env.step(action)
+            rewards.append(g.clone())
+            if env.cur_sec >= env.scn.episode_length_sec:
+                break
+        r = torch.stack(rewards)                                  # [T, E] float64
+        self.ob = None                                            # the training episode has to restart
+        return r.mean(0).cpu().numpy(), r.std(0, unbiased=False).cpu().numpy()
+
+    def evaluate(self, policy_type='default', output_path=None, step=0):
+        """The test block of Trainer.run (utils.py:257-275): every test seed once, un-shaped rewards.  With
+        E >= test_num all seeds run in ONE batched episode (instance e evaluates seed e % test_num).
+        Returns the reference's log rows; output_path appends them to `train_reward.csv`'s schema."""
+        env = self.env
+        was = env.train_mode
+        env.train_mode = False
+        try:
+            rows = []
+            if env.E >= env.test_num:
+                inds = np.arange(env.E) % env.test_num
+                mean, std = self.perform(inds, policy_type)
+                for t in range(env.test_num):
+                    rows.append({'agent': self.agent, 'step': step, 'test_id': t,
+                                 'avg_reward': float(mean[inds == t].mean()), 'std_reward': float(std[inds == t].mean())})
+            else:
+                for t in range(env.test_num):
+                    mean, std = self.perform(t, policy_type)
+                    env.terminate()
+                    rows.append({'agent': self.agent, 'step': step, 'test_id': t,
+                                 'avg_reward': float(mean.mean()), 'std_reward': float(std.mean())})
+        finally:
+            env.train_mode = was
+        if output_path is not None:
+            import csv
+            import os
+            path = os.path.join(output_path, 'train_reward.csv')
+            new_file = not os.path.exists(path)
+            with open(path, 'a', newline='') as fh:
+                w = csv.DictWriter(fh, fieldnames=['agent', 'avg_reward', 'std_reward', 'step', 'test_id'])
+                if new_file:
+                    w.writeheader()
+                w.writerows(rows)
+        return rows
+
     def mean_step_reward(self):
         steps = max(1, self.global_counter.cur_step)
         return self.env.reward_sum() / (steps * self.env.E)

@@ -310,3 +310,34 @@ def test_multibatch_trainer_keeps_replicas_identical():
         e.close()
     for m in models:
         m.close()
+
+
+def test_evaluation_path_perform_and_evaluate(tmp_path):
+    """VecTrainer.perform / evaluate (utils.py:195-234, 257-275): deterministic evaluation is reproducible, each
+    instance sees its own test seed, rewards are the un-shaped global reward, train mode is restored."""
+    from deeprl_signal_control_amd.agents import VecA2C
+    from deeprl_signal_control_amd.env import VecTrafficEnv
+    from deeprl_signal_control_amd.scenario import build_large_grid
+    from deeprl_signal_control_amd.trainer import VecTrainer
+    scn = build_large_grid('ma2c')
+    E = 4
+    env = VecTrafficEnv(scn, E, seed=12, test_seeds=(10000, 20000))
+    model = VecA2C(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, scn.n_f_ls, E, scn.s_max, 5, {'batch_size': 120}, seed=1, name='ma2c')
+    tr = VecTrainer(env, model)
+    env.train_mode = False
+    m1, s1 = tr.perform([0, 1, 0, 1], 'deterministic')
+    m2, s2 = tr.perform([0, 1, 0, 1], 'deterministic')
+    np.testing.assert_array_equal(m1, m2)
+    np.testing.assert_array_equal(s1, s2)
+    assert m1[0] == m1[2] and m1[1] == m1[3] and m1[0] != m1[1]      # same seed -> same episode; seeds differ
+    assert np.all(m1 < 0) and np.all(s1 > 0)
+    env.train_mode = True
+    rows = tr.evaluate('deterministic', output_path=str(tmp_path), step=7)
+    assert env.train_mode is True
+    assert [r['test_id'] for r in rows] == [0, 1]
+    assert rows[0]['avg_reward'] == pytest.approx(m1[0]) and rows[1]['avg_reward'] == pytest.approx(m1[1])
+    assert (tmp_path / 'train_reward.csv').read_text().splitlines()[0] == 'agent,avg_reward,std_reward,step,test_id'
+    ms, _ = tr.perform(0, 'stochastic')
+    assert ms.shape == (E,) and len(set(ms.tolist())) > 1            # sampled actions differ per instance
+    tr.run_iteration()                                               # training resumes from a fresh episode
+    env.close(); model.close()
