@@ -256,3 +256,37 @@ def greedy_actions_large_grid(obs):
     flows = torch.stack([w[..., 0] + w[..., 3], w[..., 2] + w[..., 5], w[..., 1] + w[..., 4],
                          w[..., 1] + w[..., 2], w[..., 4] + w[..., 5]], -1)
     return flows.argmax(-1).to(torch.int32)
+
+
+def greedy_table(scn):
+    """[A, PMAX, LMAX] 0/1: lane j (ild order) of agent a has a 'G' link in phase p -- every lane once, as
+    RealNetController.greedy counts it (envs/real_net_env.py:96-111; lower-case 'g' links do not count)."""
+    A, P = scn.n_agent, scn.green_tab.shape[1]
+    gm = np.zeros((A, P, scn.agent_lanes.shape[1]), np.float64)
+    for a in range(A):
+        lanes = [int(x) for x in scn.agent_lanes[a, :scn.agent_nlane[a]]]
+        for p in range(int(scn.agent_nphase[a])):
+            for k in range(int(scn.agent_nlink[a])):
+                if scn.green_tab[a, p, k] == ord('G'):
+                    gm[a, p, lanes.index(int(scn.link_lane[a, k]))] = 1.0
+    return gm
+
+
+def greedy_actions(scn, wave, table=None):
+    """Max-green-wave phase per agent (the reference's greedy controllers).  wave [..., A, >= LMAX]:
+    the agents' own wave entries first (as in every obs layout).  numpy or torch (device) input; ties go to the
+    lowest phase like np.argmax."""
+    gm = greedy_table(scn) if table is None else table
+    L = gm.shape[2]
+    nph = np.asarray(scn.agent_nphase)
+    if torch.is_tensor(wave):
+        g = torch.as_tensor(gm, dtype=wave.dtype, device=wave.device)
+        flows = torch.einsum('...al,apl->...ap', wave[..., :L], g)
+        valid = torch.as_tensor(np.arange(gm.shape[1])[None, :] < nph[:, None], device=wave.device)
+        flows = torch.where(valid, flows, torch.full_like(flows, -1.0))
+        best = flows.max(-1, keepdim=True).values
+        rank = torch.arange(gm.shape[1], 0, -1, device=wave.device)       # first maximum wins
+        return ((flows == best) * rank).argmax(-1).to(torch.int32)
+    flows = np.einsum('...al,apl->...ap', np.asarray(wave, np.float64)[..., :L], gm)
+    flows = np.where(np.arange(gm.shape[1])[None, :] < nph[:, None], flows, -1.0)
+    return flows.argmax(-1).astype(np.int32)

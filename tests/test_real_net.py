@@ -123,3 +123,16 @@ def test_gpu_batched_vs_oracle_monaco():
         for k in ('n', 'x', 'v', 'sf', 'w', 'r'):
             np.testing.assert_array_equal(st[k], sn[k], err_msg='state %s e=%d' % (k, e))
     env.close()
+
+
+def test_greedy_controller_matches_reference(golden_dir):
+    """trainer.greedy_actions (phase -> lanes with a 'G' link -> wave sums -> first argmax) against
+    RealNetController.greedy of the reference (tools/make_golden.py:greedy_fixtures), numpy and torch paths.
+    (large_grid has its own hard-coded controller, trainer.greedy_actions_large_grid, pinned by
+    tests/golden/large_grid_greedy.npz.)"""
+    import torch
+    from deeprl_signal_control_amd.trainer import greedy_actions
+    g = np.load(os.path.join(golden_dir, 'real_net_greedy_controller.npz'))
+    scn = build_real_net('greedy')
+    np.testing.assert_array_equal(greedy_actions(scn, g['wave']), g['action'])
+    np.testing.assert_array_equal(greedy_actions(scn, torch.from_numpy(g['wave'])).numpy(), g['action'])

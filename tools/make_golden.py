@@ -117,6 +117,29 @@ def real_net_fixtures():
         json.dump(static, f, indent=1)
 
 
+def greedy_fixtures():
+    """RealNetController.greedy (envs/real_net_env.py:90-111) of the reference on random wave vectors: pins
+    trainer.greedy_actions (phase -> green lanes -> wave sums -> argmax) for Monaco."""
+    from deeprl_signal_control_amd.scenario import build_real_net
+    from envs.real_net_env import RealNetController
+    env = fake_traci.ref_env('real_net', 'ma2c', scn=build_real_net('ma2c'))
+    ctrl = RealNetController(env.node_names, env.nodes)
+    rng = np.random.RandomState(77)
+    N, A = 64, len(env.node_names)
+    lmax = max(len(env.nodes[n].ilds_in) for n in env.node_names)
+    wave = np.zeros((N, A, lmax))
+    act = np.zeros((N, A), np.int32)
+    for i in range(N):
+        obs = []
+        for a, n in enumerate(env.node_names):
+            k = len(env.nodes[n].ilds_in)
+            w = np.round(rng.rand(k) * 4, 1) if i % 2 else rng.randint(0, 3, k).astype(np.float64)   # ties included
+            wave[i, a, :k] = w
+            obs.append(w)
+        act[i] = ctrl.forward(obs)
+    np.savez_compressed(os.path.join(OUT, 'real_net_greedy_controller.npz'), wave=wave, action=act)
+
+
 def env_fixtures():
     # 1. MA2C, full episode (720 control steps), then a second short episode (seed += 1)
     env = fake_traci.ref_env('large_grid', 'ma2c')
@@ -201,6 +224,7 @@ if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     env_fixtures()
     real_net_fixtures()
+    greedy_fixtures()
     learner_fixtures()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
