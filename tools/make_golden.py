@@ -220,11 +220,33 @@ def learner_fixtures():
     np.savez_compressed(os.path.join(OUT, 'learner_known_answers.npz'), **flat)
 
 
+def iql_fixtures():
+    """Known answers from the reference's ReplayBuffer (agents/utils.py:231-263) under a seeded `random`:
+    which transitions survive the ring overwrite and which are drawn into the minibatches."""
+    import random
+    fake_traci.install(__import__('deeprl_signal_control_amd.scenario', fromlist=['x']).build_large_grid())
+    from agents.utils import ReplayBuffer
+    buf = ReplayBuffer(1000, 20)
+    random.seed(5)
+    sizes, draws = [], []
+    for i in range(1500):
+        buf.add_transition(np.array([float(i)]), i % 5, -0.001 * i, np.array([float(i + 1)]), (i % 720) == 719)
+        if i in (10, 19, 20, 999, 1000, 1499):
+            sizes.append([i, buf.size, buf.cum_size])
+        if i >= 19 and i % 97 == 0:
+            obs, acts, nobs, rs, dones = buf.sample_transition()
+            draws.append(np.concatenate([[i], obs[:, 0], acts, nobs[:, 0], rs, dones.astype(np.float64)]))
+    content = np.array([t[0][0] for t in buf.buffer])
+    np.savez_compressed(os.path.join(OUT, 'iql_known_answers.npz'), sizes=np.array(sizes), draws=np.array(draws),
+                        content=content)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     env_fixtures()
     real_net_fixtures()
     greedy_fixtures()
+    iql_fixtures()
     learner_fixtures()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
