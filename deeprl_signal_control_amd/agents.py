@@ -141,6 +141,30 @@ class ParamLayout:
         return towers
 
 
+def coerce_config(model_config, defaults):
+    """A `configparser` section (what main.py hands over: config['MODEL_CONFIG'], agents/models.py:53-69 reads it with
+    getfloat / getint / get) or a plain dict -> dict typed like `defaults`.  Keys are case-insensitive like the
+    reference's getters (LR_MIN / ENTROPY_COEF_MIN); unknown keys are kept as given."""
+    cfg = dict(defaults)
+    for k, v in dict(model_config or {}).items():
+        k = str(k).lower()
+        if k in defaults and isinstance(v, str):
+            d = defaults[k]
+            v = v.strip()
+            v = int(float(v)) if isinstance(d, int) and not isinstance(d, bool) else float(v) if isinstance(d, float) else v
+        cfg[k] = v
+    return cfg
+
+
+def replica_sample_seed(seed, rank=0, replica=0):
+    """Action-sampling stream of one replica (torch.distributed rank x half-batch index).  Replicas must share the
+    weight-init seed, so the sampling seed is derived from (seed, rank, replica): identical parameters, independent
+    exploration (the uniform of instance idx at step s is U(sample_seed, s, idx), include/tsc.h tsc_model_sample)."""
+    x = (int(seed) * 0x9E3779B97F4A7C15 + (int(rank) + 1) * 0xBF58476D1CE4E5B9 + (int(replica) + 1) * 0x94D049BB133111EB) & ((1 << 64) - 1)
+    x ^= x >> 31
+    return x & ((1 << 63) - 1) if (rank or replica) else int(seed)
+
+
 def allreduce_grads_(flat_grad, group=None):
     """The one collective of the path: sum the flat gradient buffer over ranks (RCCL
     on GPUs, gloo in the CPU test) and return the 1/world factor apply_grads folds in BEFORE the
@@ -149,9 +173,7 @@ def allreduce_grads_(flat_grad, group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return 1.0
     world = dist.get_world_size(group)
-    if world == 1:
-        return 1.0
-    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)     # also with one rank: same code path everywhere
     return 1.0 / world
 
 
@@ -170,6 +192,8 @@ def _setup_lib(L):
     L.tsc_model_layout.argtypes = [vp, C.POINTER(C.c_int64)]
     for f in ('tsc_model_set_params', 'tsc_model_get_params', 'tsc_model_get_opt_state', 'tsc_model_set_opt_state'):
         getattr(L, f).argtypes = [vp, vp]
+    L.tsc_model_reset_opt_state.argtypes = [vp]
+    L.tsc_model_debug_read.argtypes = [vp, C.c_int32, C.c_int32, C.c_int64, C.c_int64, vp]
     L.tsc_model_reset.argtypes = [vp]
     L.tsc_model_forward.argtypes = [vp, vp, vp, vp, vp, C.c_int32]
     L.tsc_model_sample.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64]
@@ -189,11 +213,10 @@ class VecA2C:
     """IA2C / MA2C for A agents x E env instances on one GPU."""
 
     def __init__(self, n_s_ls, n_a_ls, n_w_ls, n_f_ls, n_env, s_max, a_max, model_config=None,
-                 total_step=0, device=0, seed=None, name='ma2c', process_group=None, policy='lstm'):
+                 total_step=0, device=0, seed=None, name='ma2c', process_group=None, policy='lstm', replica=0):
         if not torch.cuda.is_available():
             raise RuntimeError('VecA2C needs a GPU (MI355X); there is no CPU fallback')
-        cfg = dict(A2C_DEFAULTS)
-        cfg.update(model_config or {})
+        cfg = coerce_config(model_config, A2C_DEFAULTS)
         self.cfg, self.name = cfg, name
         self.policy = policy                    # 'lstm' (what the reference instantiates) or 'fc' (FcACPolicy)
         if policy == 'fc' and name == 'ma2c':
@@ -246,8 +269,12 @@ class VecA2C:
         self._grad_ptr, self.n_param = gp.value, int(cnt.value)
         self.cur_t = 0
         self.sample_step = 0
-        self.sample_seed = 0 if seed is None else int(seed)
+        dist = torch.distributed
+        self.rank = dist.get_rank(process_group) if dist.is_available() and dist.is_initialized() else 0
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.sample_seed = replica_sample_seed(0 if seed is None else seed, self.rank, replica)
         self.init_params(seed)
+        self.sync_replicas()
 
     # ---- parameters -----------------------------------------------------------------------
     def _init_scheduler(self):
@@ -290,6 +317,25 @@ class VecA2C:
                 p['out_b'] = np.zeros(n_out, np.float32)
                 towers.append(p)
         self.set_tower_params(towers)
+        _lib.check(self._L.tsc_model_reset_opt_state(self._h))      # TF1 RMSProp slot init: ms = 1
+
+    def sync_replicas(self, src=0):
+        """Data-parallel replicas must start identical (only gradients are exchanged afterwards): broadcast the flat
+        parameters and the RMSProp accumulator from rank `src`.  No-op without an initialised process group."""
+        if self.world <= 1:
+            return
+        for what, setter in (('params', self._L.tsc_model_set_params), ('ms', self._L.tsc_model_set_opt_state)):
+            t = torch.from_numpy(self.get_flat(what)).to(self.device)
+            torch.distributed.broadcast(t, src=src, group=self.pg)
+            flat = np.ascontiguousarray(t.cpu().numpy())
+            _lib.check(setter(self._h, flat.ctypes.data_as(C.c_void_p)))
+
+    def copy_from(self, other):
+        """Make this handle a replica of `other` (same layout): parameters + optimizer state."""
+        assert self.layout.as_tuple() == other.layout.as_tuple()
+        for what, setter in (('params', self._L.tsc_model_set_params), ('ms', self._L.tsc_model_set_opt_state)):
+            flat = np.ascontiguousarray(other.get_flat(what))
+            _lib.check(setter(self._h, flat.ctypes.data_as(C.c_void_p)))
 
     def pack(self, towers):
         return self.layout.pack(towers)
@@ -394,14 +440,19 @@ class VecA2C:
         self.compute_grads(R)
         scale = 1.0
         if torch.distributed.is_available() and torch.distributed.is_initialized():
-            scale = allreduce_grads_(self.grad_tensor(), self.pg)   # RCCL over xGMI, one flat buffer
+            # the gradient kernels run on self.stream: issue the collective there too, so that it starts after
+            # compute_grads and apply_grads starts after it, whatever torch's current stream is
+            with torch.cuda.stream(self.stream):
+                scale = allreduce_grads_(self.grad_tensor(), self.pg)   # RCCL over xGMI, one flat buffer
         return self.apply_grads(scale, want_stats)
 
     # ---- checkpoints (agents/models.py:83-108: `checkpoint-<step>`, highest step wins) -------
     def save(self, model_dir, global_step):
         os.makedirs(model_dir, exist_ok=True)
         np.savez(os.path.join(model_dir, 'checkpoint-%d.npz' % int(global_step)), params=self.get_flat('params'),
-                 ms=self.get_flat('ms'), layout=np.array([self.G, self.stride, self.H, self.s_max]))
+                 ms=self.get_flat('ms'), layout=np.array(self.layout.as_tuple() + (self.s_max,), np.int64),
+                 dims=np.array([self.n_wave_ls, self.n_w_ls, self.n_f_ls, self.n_a_ls], np.int64),
+                 counters=np.array([self.sample_step, self.sample_seed, self.lr_scheduler.n, self.beta_scheduler.n], np.int64))
 
     def load(self, model_dir, checkpoint=None):
         save_file, save_step = None, 0
@@ -421,8 +472,17 @@ class VecA2C:
         z = np.load(os.path.join(model_dir, save_file))
         p = np.ascontiguousarray(z['params'], np.float32)
         ms = np.ascontiguousarray(z['ms'], np.float32)
+        want = self.layout.as_tuple() + (self.s_max,)
+        dims = np.array([self.n_wave_ls, self.n_w_ls, self.n_f_ls, self.n_a_ls], np.int64)
+        if tuple(int(x) for x in z['layout']) != want or p.size != self.n_param or ms.size != self.n_param or \
+                ('dims' in z.files and not np.array_equal(z['dims'], dims)):
+            raise ValueError('checkpoint %s does not fit this model (layout %r vs %r, %d vs %d parameters)'
+                             % (save_file, tuple(int(x) for x in z['layout']), want, p.size, self.n_param))
         _lib.check(self._L.tsc_model_set_params(self._h, p.ctypes.data_as(C.c_void_p)))
         _lib.check(self._L.tsc_model_set_opt_state(self._h, ms.ctypes.data_as(C.c_void_p)))
+        if 'counters' in z.files:            # action-RNG stream and lr / beta schedules resume where they stopped
+            self.sample_step, self.sample_seed = int(z['counters'][0]), int(z['counters'][1])
+            self.lr_scheduler.n, self.beta_scheduler.n = int(z['counters'][2]), int(z['counters'][3])
         return True
 
     def close(self):

@@ -1538,7 +1538,12 @@ int tsc_model_set_params(tsc_model *m, const float *h) {
     m->wg_dirty = 1;
     TSC_HIP(hipStreamSynchronize(m->stream));
     TSC_HIP(hipMemcpy(m->params, h, sizeof(float) * m->nparam, hipMemcpyHostToDevice));
+    return 0;
+}
+int tsc_model_reset_opt_state(tsc_model *m) {
+    if (!m) return tsc::fail("null handle");
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((m->nparam + 255) / 256)), dim3(256), 0, m->stream, m->ms, m->nparam, 1.0f);
+    TSC_HIP(hipGetLastError());
     TSC_HIP(hipStreamSynchronize(m->stream));
     return 0;
 }
@@ -1837,6 +1842,27 @@ int tsc_model_get_returns(tsc_model *m, float *Rs, float *Advs) {
     TSC_HIP(hipStreamSynchronize(m->stream));
     TSC_HIP(hipMemcpy(Rs, m->Rs, sizeof(float) * n, hipMemcpyDeviceToHost));
     TSC_HIP(hipMemcpy(Advs, m->Advs, sizeof(float) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tsc_model_debug_read(tsc_model *m, int32_t what, int32_t g, int64_t row0, int64_t nrows, float *out_host) {
+    if (!m || !out_host || g < 0 || g >= m->lay.G || row0 < 0 || nrows < 0) return tsc::fail("tsc_model_debug_read: bad arguments");
+    const long long N = (long long)m->T * m->E;
+    if (row0 + nrows > N) return tsc::fail("tsc_model_debug_read: rows [%lld, %lld) outside [0, %lld)", (long long)row0, (long long)(row0 + nrows), N);
+    const float *base = nullptr;
+    long long w = 0;
+    switch (what) {
+        case 0: base = m->X1; w = m->lay.H; break;
+        case 1: base = m->Z; w = kG4; break;
+        case 2: base = m->Hh; w = kL; break;
+        case 3: base = m->Cc; w = kL; break;
+        case 4: base = m->Hp; w = kL; break;
+        case 5: base = m->dHh; w = kL; break;
+        default: return tsc::fail("tsc_model_debug_read: unknown buffer %d", what);
+    }
+    if (m->lay.fc && (what == 1 || what == 3 || what == 4)) return tsc::fail("tsc_model_debug_read: buffer %d is LSTM-only", what);
+    TSC_HIP(hipStreamSynchronize(m->stream));
+    TSC_HIP(hipMemcpy(out_host, base + ((long long)g * N + row0) * w, sizeof(float) * (size_t)(nrows * w), hipMemcpyDeviceToHost));
     return 0;
 }
 

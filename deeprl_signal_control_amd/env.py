@@ -83,6 +83,10 @@ class VecTrafficEnv:
         self.stream = stream
         _lib.check(self._L.tsc_env_set_stream(self._h, C.c_void_p(stream.cuda_stream)))
 
+    def set_record(self, on):
+        """is_record (envs/env.py:517-528): per-second network statistics are accumulated on the device."""
+        self.is_record = bool(on)
+
     # -- reference API, batched ------------------------------------------------------------
     def reset(self, test_ind=0):
         """envs/env.py:544-561 -> obs float32 [E, A, SMAX]."""
@@ -149,18 +153,85 @@ class VecTrafficEnv:
         return v.value
 
 
+ENV_CONFIG_KEYS = dict(control_interval_sec=int, yellow_interval_sec=int, episode_length_sec=int, coop_gamma=float,
+                       norm_wave=float, norm_wait=float, clip_wave=float, clip_wait=float, coef_wait=float,
+                       objective=str)
+SCENARIO_KEYS = {'large_grid': dict(peak_flow1=int, peak_flow2=int, init_density=float),
+                 'real_net': dict(flow_rate=int), 'small_grid': dict(num_extra_car_per_hour=int)}
+
+
+def scenario_from_config(config):
+    """[ENV_CONFIG] section (configparser SectionProxy or dict of strings, config/config_*.ini) -> (Scenario, seed,
+    test_seeds): the keys TrafficSimulator.__init__ and the scenario subclasses read (envs/env.py:83-110,
+    envs/large_grid_env.py:64-68, envs/real_net_env.py:115-117, envs/small_grid_env.py:59-61).  `data_path` is
+    accepted and ignored: nothing is generated on disk (the demand tables live on the device)."""
+    get = config.get
+    name, agent = get('scenario'), get('agent')
+    kw = {}
+    for k, typ in list(ENV_CONFIG_KEYS.items()) + list(SCENARIO_KEYS.get(name, {}).items()):
+        v = get(k)
+        if v is not None:
+            kw[k] = typ(float(v)) if typ is int else typ(v)
+    seed = int(get('seed'))
+    test_seeds = tuple(int(x) for x in str(get('test_seeds')).split(','))
+    return build_scenario(name, agent, **kw), seed, test_seeds
+
+
+class NodeView:
+    """Read-only stand-in for envs/env.py:63-80 `Node`: what main.init_env hands to the greedy controllers
+    (envs/real_net_env.py:78-111 reads lanes_in / ilds_in) and what the evaluation scripts print."""
+
+    def __init__(self, scn, a):
+        self.name = scn.node_names[a]
+        self.control = False
+        self.lanes_in = [scn.lane_names[l] for l in scn.link_lane[a, :scn.agent_nlink[a]]]
+        self.ilds_in = [scn.lane_names[l] for l in scn.agent_lanes[a, :scn.agent_nlane[a]]]
+        self.neighbor = [scn.node_names[j] for j in scn.neighbors[a]]
+        self.n_a = int(scn.n_a_ls[a])
+        self.num_state = int(scn.agent_nlane[a])
+        self.num_fingerprint = int(scn.n_f_ls[a])
+        self.phase_id = scn.extra.get('phase_ids', {}).get(self.name, scn.name)
+        self.phases = list(scn.phases[a])
+
+
 class TrafficEnv:
     """The reference's single-env duck-type (envs/env.py:544-635) on top of VecTrafficEnv(E=1):
     ``reset() -> list[A] of 1-D float arrays``, ``step(list[A] of int) -> (obs, reward ndarray,
     done bool, global_reward float)``.  Observations come back as float32 (the value the
-    reference feeds to its nets, agents/policies.py:82,130); rewards stay float64."""
+    reference feeds to its nets, agents/policies.py:82,130); rewards stay float64.
 
-    def __init__(self, scn: Scenario, device=0, seed=12, test_seeds=(10000, 20000)):
-        self.vec = VecTrafficEnv(scn, 1, device=device, seed=seed, test_seeds=test_seeds, seed_stride=1)
+    Constructed like the reference's env classes -- ``TrafficEnv(config['ENV_CONFIG'], port=0, output_path='',
+    is_record=False, record_stat=False)`` (envs/large_grid_env.py:64-68) -- or from a compiled Scenario."""
+
+    def __init__(self, config, port=0, output_path='', is_record=False, record_stat=False, device=0, seed=None,
+                 test_seeds=None):
+        if isinstance(config, Scenario):
+            scn, cseed, ctest = config, 12, (10000, 20000)
+        else:
+            scn, cseed, ctest = scenario_from_config(config)
+        seed = cseed if seed is None else seed
+        test_seeds = ctest if test_seeds is None else test_seeds
+        self.vec = VecTrafficEnv(scn, 1, device=device, seed=seed + port, test_seeds=test_seeds, seed_stride=1)
         self.scn = scn
-        for k in ('agent', 'n_s_ls', 'n_a_ls', 'n_w_ls', 'n_f_ls', 'n_s', 'n_a', 'node_names', 'T', 'test_num'):
+        for k in ('agent', 'n_s_ls', 'n_a_ls', 'n_w_ls', 'n_f_ls', 'n_s', 'n_a', 'node_names', 'T'):
             setattr(self, k, getattr(self.vec, k))
         self.name = scn.name
+        self.port = port
+        self.nodes = {n: NodeView(scn, a) for a, n in enumerate(scn.node_names)}
+        self.init_data(is_record, record_stat, output_path)
+
+    test_num = property(lambda self: self.vec.test_num)
+    test_seeds = property(lambda self: self.vec.test_seeds)
+
+    def init_test_seeds(self, test_seeds):
+        """envs/env.py:530-532."""
+        self.vec.test_seeds = [int(s) for s in test_seeds]
+        self.vec.test_num = len(self.vec.test_seeds)
+
+    def init_data(self, is_record, record_stats, output_path):
+        """envs/env.py:517-528."""
+        self.is_record, self.record_stats, self.output_path = is_record, record_stats, output_path
+        self.vec.set_record(bool(is_record))
 
     train_mode = property(lambda self: self.vec.train_mode,
                           lambda self, v: setattr(self.vec, 'train_mode', v))
@@ -197,7 +268,12 @@ class TrafficEnv:
 
 
 def make_env(scenario='large_grid', agent='ma2c', n_env=None, **kw):
-    """init_env (main.py:51-79) equivalent; n_env=None gives the reference's single-env type."""
+    """init_env (main.py:51-79) equivalent; n_env=None gives the reference's single-env type.  `scenario` may also be
+    the [ENV_CONFIG] section itself (then `agent` and the other keys come from it)."""
+    if not isinstance(scenario, str):
+        scn, seed, test_seeds = scenario_from_config(scenario)
+        kw.setdefault('seed', seed); kw.setdefault('test_seeds', test_seeds)
+        return TrafficEnv(scn, **kw) if n_env is None else VecTrafficEnv(scn, n_env, **kw)
     scn_kw = {k: kw.pop(k) for k in list(kw)
               if k in Scenario.__dataclass_fields__ or k in ('peak_flow1', 'peak_flow2', 'sort_lanes')}
     scn = build_scenario(scenario, agent, **scn_kw)

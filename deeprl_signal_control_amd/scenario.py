@@ -261,7 +261,12 @@ _RIGHT, _THROUGH, _LEFT = 0, 1, 2
 
 
 def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: int = 925,
-                     sort_lanes: bool = True, **env_kw) -> Scenario:
+                     sort_lanes: bool = True, init_density: float = 0.0, **env_kw) -> Scenario:
+    if init_density > 0:
+        # large_grid/data/build_file.py:223-266 seeds every internal edge with vehicles bound for a sink drawn per
+        # episode from np.random: up to 120 x 20 (source lane, sink) routes.  No reference config sets it
+        # (config/*.ini: init_density = 0), and the route tables here are per-OD (n_route <= 255).
+        raise NotImplementedError('init_density > 0 (initial traffic, build_file.py:223-266) is not supported')
     L0, L0_END, N = 200.0, 75.0, 5
     pos: Dict[str, Tuple[float, float]] = {}
     for r in range(N):

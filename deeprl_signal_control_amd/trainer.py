@@ -173,6 +173,12 @@ class MultiBatchTrainer:
     def __init__(self, envs, models):
         assert len(envs) == len(models) and len(envs) >= 1
         self.envs, self.models = envs, models
+        from .agents import replica_sample_seed
+        for b, m in enumerate(models[1:], 1):
+            # replicas of ONE learner: identical parameters / optimizer state, independent action streams
+            m.copy_from(models[0])
+            if m.sample_seed == models[0].sample_seed:
+                m.sample_seed = replica_sample_seed(models[0].sample_seed, models[0].rank, b)
         self.parts = [VecTrainer(e, m) for e, m in zip(envs, models)]
         dev = envs[0].device
         self.streams = [torch.cuda.Stream(device=dev) for _ in envs]

@@ -159,7 +159,8 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
 int tsc_model_destroy(tsc_model *m);
 int tsc_model_set_stream(tsc_model *m, void *hip_stream);
 int tsc_model_layout(tsc_model *m, int64_t out[12]);
-int tsc_model_set_params(tsc_model *m, const float *params_host);     /* also resets RMSProp ms to 1 */
+int tsc_model_set_params(tsc_model *m, const float *params_host);     /* optimizer state untouched */
+int tsc_model_reset_opt_state(tsc_model *m);                         /* RMSProp ms <- 1 (TF1 slot init) */
 int tsc_model_get_params(tsc_model *m, float *params_host);
 int tsc_model_get_opt_state(tsc_model *m, float *ms_host);
 int tsc_model_set_opt_state(tsc_model *m, const float *ms_host);
@@ -213,6 +214,12 @@ int tsc_model_debug_clock(tsc_model *m, int32_t enable, int64_t *stamps_host, in
 /* Debug / parity access: the float32 returns and advantages [n_step, E, A] the last
  * tsc_model_compute_grads() fed to the loss (agents/utils.py:223-224). Synchronises. */
 int tsc_model_get_returns(tsc_model *m, float *Rs_host, float *Advs_host);
+
+/* Debug / parity access to the training activations of agent-tower g, rows [row0, row0 + nrows) of the
+ * [n_step * E] sample axis (row = t * E + e): what = 0 X1 [H], 1 gates i|f|o|u (dz after compute_grads) [256],
+ * 2 h [64], 3 c [64], 4 masked h_prev [64], 5 dH [64].  After n_step tsc_model_forward_sample calls with
+ * t_slot = 0..n_step-1 these are the rows the fused forward cached for the update.  Synchronises. */
+int tsc_model_debug_read(tsc_model *m, int32_t what, int32_t g, int64_t row0, int64_t nrows, float *out_host);
 
 /* Test hook: the grouped fp32 MFMA GEMM used by every layer.  form: 0 = NN, 1 = TN; epi as
  * csrc/tsc_gemm.h.  All pointers device; strides in elements.  A non-null split-K workspace lets

@@ -63,6 +63,27 @@ def tower(p, ob, dones, s, nw, nt, nf):
     return out, s_new
 
 
+def tower_activations(p, ob, done, s, nw, nt, nf):
+    """One LSTM step of one tower with every intermediate the HIP rollout forward caches for the update:
+    ob [B,n_s], done [B], s [B,2L] -> dict(X1 [B,H], gates [B,4L] post-activation i|f|o|u, c, h, hprev [B,L]).
+    Same arithmetic as tower() / lstm() above (agents/policies.py:99-118,191-211; agents/utils.py:88-116)."""
+    hs = [fc(ob[..., :nw], p['fcw_w'], p['fcw_b'])]
+    if nf:
+        hs.append(fc(ob[..., nw + nt:nw + nt + nf], p['fcf_w'], p['fcf_b']))
+    if nt:
+        hs.append(fc(ob[..., nw:nw + nt], p['fct_w'], p['fct_b']))
+    x1 = torch.cat(hs, -1)
+    L = s.shape[1] // 2
+    keep = (1.0 - done).unsqueeze(1)
+    c, h = s[:, :L] * keep, s[:, L:] * keep
+    z = x1 @ p['lstm_wx'] + h @ p['lstm_wh'] + p['lstm_b']
+    i, f, o, u = (torch.sigmoid(z[:, :L]), torch.sigmoid(z[:, L:2 * L]), torch.sigmoid(z[:, 2 * L:3 * L]),
+                  torch.tanh(z[:, 3 * L:]))
+    cn = f * c + i * u
+    hn = o * torch.tanh(cn)
+    return dict(X1=x1, gates=torch.cat([i, f, o, u], 1), c=cn, h=hn, hprev=h)
+
+
 def to_torch(tower_params, requires_grad=False):
     out = []
     for p in tower_params:
