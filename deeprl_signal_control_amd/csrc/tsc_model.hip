@@ -1581,6 +1581,7 @@ static int model_forward(tsc_model *m, const float *obs, const uint8_t *done, fl
     const int E = m->E;
     // activation cache: valid only if slots 0..T-1 are filled in order by advancing forwards
     if (advance) {
+        if (tslot == 0) m->cached_next = 0;         // slot 0 opens a rollout: whatever invalidated the cache before is history
         if (m->fused_fwd && tslot >= 0 && tslot == m->cached_next && tslot < m->T) m->cached_next = tslot + 1;
         else { m->cached_next = -1; tslot = -1; }
     } else {

@@ -221,6 +221,60 @@ int tsc_model_get_returns(tsc_model *m, float *Rs_host, float *Advs_host);
  * t_slot = 0..n_step-1 these are the rows the fused forward cached for the update.  Synchronises. */
 int tsc_model_debug_read(tsc_model *m, int32_t what, int32_t g, int64_t row0, int64_t nrows, float *out_host);
 
+/* ---- IQL: replaces IQL (agents/models.py:264-376) + LRQPolicy / DeepQPolicy (agents/policies.py:285-389) +
+ *      ReplayBuffer (agents/utils.py:231-263) + the TF1 runtime (Adam) ------------------------------------------- */
+
+typedef struct tsc_iql_cfg {
+    int32_t n_agent, s_max, a_max;
+    const int32_t *n_wave;    /* [A] wave inputs = n_s - n_w  (DeepQPolicy's n_s, agents/models.py:301) */
+    const int32_t *n_wait;    /* [A] wait inputs (n_w)                                                  */
+    const int32_t *n_act;     /* [A] actions (n_a)                                                      */
+    int32_t kind;             /* 0 = LRQPolicy (model_type 'lr'), 1 = DeepQPolicy ('dqn')               */
+    int32_t n_fc0, n_h;       /* num_fc, num_h (dqn; the wait FC is n_fc0 / 4 wide, policies.py:359)     */
+    int32_t batch_size;       /* minibatch rows per env instance (= n_step, agents/models.py:275)        */
+    int32_t buffer_size;      /* replay ring per env instance and agent                                  */
+    double gamma, reward_norm, reward_clip, max_grad_norm;
+} tsc_iql_cfg;
+
+typedef struct tsc_iql tsc_iql;
+
+/* Parameter layout, `stride` floats per agent:  dqn: W1[s_max][H1] | b1[H1] | W2[H1][H2] | b2[H2] | Wq[H2][8] | bq[8]
+ * (H1 = n_fc0 + n_fc0/4, W1 block-diagonal q_fcw | q_fct over the obs in env order);  lr: Wq[s_max][8] | bq[8].
+ * out[] = {A, stride, H1, H2, off_W1, off_b1, off_W2, off_b2, off_Wq, off_bq, out_pad(8), kind}. */
+int tsc_iql_create(const tsc_iql_cfg *cfg, int32_t n_env, int32_t device, tsc_iql **out);
+int tsc_iql_destroy(tsc_iql *h);
+int tsc_iql_set_stream(tsc_iql *h, void *hip_stream);
+int tsc_iql_layout(tsc_iql *h, int64_t out[12]);
+int tsc_iql_set_params(tsc_iql *h, const float *params_host);
+int tsc_iql_get_params(tsc_iql *h, float *params_host);
+int tsc_iql_get_opt_state(tsc_iql *h, float *m_host, float *v_host, int64_t *adam_t);   /* Adam moments + step count */
+int tsc_iql_set_opt_state(tsc_iql *h, const float *m_host, const float *v_host, int64_t adam_t);
+
+/* IQL.forward (agents/models.py:332-348).  obs: dev f32 [E,A,SMAX]; q: dev f32 [E,A,AMAX] (padded actions 0);
+ * action: dev i32 [E,A].  mode 0 = argmax ('act'), 1 = 'explore' (u0 < eps ? floor(u1 * n_a) : argmax),
+ * 2 = stochastic (qs / sum(qs) -> np.random.choice).  Uniforms: u_s = U(seed, step, 2 * (e * A + a) + s), the
+ * counter-based generator of tsc_model_sample. */
+int tsc_iql_forward(tsc_iql *h, const float *obs_dev, float *q_dev, int32_t *action_dev, int32_t mode, double eps,
+                    uint64_t seed, uint64_t step);
+
+/* IQL.add_transition (agents/models.py:354-361): reward / reward_norm, clip, append (obs, a, r, next_obs, done) to
+ * every instance's ring (slot = transitions so far % buffer_size).  reward: dev f64 [E,A]; done: dev u8 [E]. */
+int tsc_iql_add_transition(tsc_iql *h, const float *obs_dev, const int32_t *action_dev, const double *reward_dev,
+                           const float *next_obs_dev, const uint8_t *done_dev);
+int tsc_iql_replay_size(tsc_iql *h, int64_t *size, int64_t *cum_size);       /* ReplayBuffer.size / cum_size */
+
+/* One minibatch step of IQL.backward (agents/models.py:319-330 -> policies.py:305-328), first half: draw batch_size
+ * distinct transitions per (instance, agent) -- Floyd's algorithm on U(seed, update_index, (e * A + a) * B + i) --
+ * and leave the gradient of mean((Q(s)[a] - stop_grad(done ? r : r + gamma max Q(s')))^2) over the E * batch_size rows
+ * of every agent in the contiguous buffer tsc_iql_grad_buffer() returns (parameter layout). */
+int tsc_iql_compute_grads(tsc_iql *h, uint64_t seed, uint64_t update_index);
+int tsc_iql_grad_buffer(tsc_iql *h, float **grad_dev, int64_t *count);
+/* ... second half: per-agent clip_by_global_norm(max_grad_norm) on grad * grad_scale, TF1 AdamOptimizer step
+ * (beta1 .9, beta2 .999, epsilon 1e-8).  stats_host (nullable): per agent {loss, grad_norm} float64 [A,2]. */
+int tsc_iql_apply_grads(tsc_iql *h, double lr, double grad_scale, double *stats_host);
+/* Debug / parity access: the replay indices [E, A, batch_size] of the last tsc_iql_compute_grads. Synchronises. */
+int tsc_iql_debug_batch(tsc_iql *h, int32_t *idx_host);
+
 /* Test hook: the grouped fp32 MFMA GEMM used by every layer.  form: 0 = NN, 1 = TN; epi as
  * csrc/tsc_gemm.h.  All pointers device; strides in elements.  A non-null split-K workspace lets
  * the TN form cut its reduction into deterministic chunks (as the weight-gradient GEMMs do). */

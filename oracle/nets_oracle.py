@@ -166,6 +166,27 @@ class OracleA2C:
         dpre = t64(dones[:-1])
         grads, stats = [], []
         P = to_torch([{k: v.numpy() for k, v in p.items()} for p in self.p], requires_grad=True)
+        # ReLU kinks: hidden units with a pre-activation within 1e-5 of zero for some sample.  There a float32
+        # evaluation may land on the other side of the kink than float64 and the unit's weight-gradient column then
+        # differs by that sample's whole contribution -- a property of relu, not an error of either side.  Parity
+        # tests compare those columns with a loose bound (self.kink_cols[tower][layer] = bool per hidden unit).
+        self.kink_cols = []
+        with torch.no_grad():
+            for g_, p in enumerate(self.p):
+                a = g_ // 2
+                ob = self._ob(obs, a)
+                nw, nt, nf = self.nw[a], self.nt[a], self.nf[a]
+                kc = {'fcw': ((ob[..., :nw] @ p['fcw_w'] + p['fcw_b']).abs() < 1e-5).reshape(-1, p['fcw_b'].shape[0]).any(0).numpy()}
+                hs = [fc(ob[..., :nw], p['fcw_w'], p['fcw_b'])]
+                if nf:
+                    kc['fcf'] = ((ob[..., nw + nt:nw + nt + nf] @ p['fcf_w'] + p['fcf_b']).abs() < 1e-5).reshape(-1, p['fcf_b'].shape[0]).any(0).numpy()
+                    hs.append(fc(ob[..., nw + nt:nw + nt + nf], p['fcf_w'], p['fcf_b']))
+                if nt:
+                    kc['fct'] = ((ob[..., nw:nw + nt] @ p['fct_w'] + p['fct_b']).abs() < 1e-5).reshape(-1, p['fct_b'].shape[0]).any(0).numpy()
+                    hs.append(fc(ob[..., nw:nw + nt], p['fct_w'], p['fct_b']))
+                if 'fc_w' in p:
+                    kc['fc'] = ((torch.cat(hs, -1) @ p['fc_w'] + p['fc_b']).abs() < 1e-5).reshape(-1, p['fc_b'].shape[0]).any(0).numpy()
+                self.kink_cols.append(kc)
         for a in range(self.A):
             ob = self._ob(obs, a)
             lo, _ = tower(P[2 * a], ob, dpre, self.s_bw[2 * a], self.nw[a], self.nt[a], self.nf[a])

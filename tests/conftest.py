@@ -30,6 +30,18 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(scope='session', autouse=True)
+def _few_cpu_threads():
+    """The float64 oracle is thousands of tiny torch-CPU ops: on a many-core GPU host the default thread pool makes
+    each of them slower (bench.py's cpu_baseline note), so cap it."""
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    except Exception:
+        pass
+    yield
+
+
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN

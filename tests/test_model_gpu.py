@@ -3,8 +3,10 @@ against the CPU oracle (oracle/nets_oracle.py, float64 restatement of agents/pol
 agents/utils.py) and against known answers recorded from the reference's OnPolicyBuffer.
 
 Tolerances (floating point, fp32 kernels vs float64 oracle): forward outputs |d| <= 2e-5;
-gradients |d| <= 2e-3 * max|g| per tensor (fp32 accumulation over T*E samples through a T-step
-BPTT); returns/advantages bit-exact (float64 recursion on both sides)."""
+gradients |d| <= 2e-5 * max|g| per tensor (1e-4 at n_step = 120; fp32 accumulation over T*E samples through a
+T-step BPTT -- measured ~5e-7), except the weight-gradient columns of hidden units that sit on a ReLU kink in the
+oracle (|pre-activation| < 1e-5 for some sample: float32 may evaluate the other side); returns/advantages
+bit-exact (float64 recursion on both sides)."""
 import ctypes as C
 import os
 
@@ -96,6 +98,25 @@ def _make(agent, E, n_step, seed=0, policy='lstm', scenario='large_grid', **cfg)
                   gamma=m.cfg['gamma'], reward_norm=m.cfg['reward_norm'], reward_clip=m.cfg['reward_clip'],
                   value_coef=m.cfg['value_coef'], max_grad_norm=m.cfg['max_grad_norm'])
     return scn, m, o
+
+
+def _grad_err(o, t, k, got, og):
+    """max |got - og| / max|og| over the entries whose hidden unit is not on a ReLU kink in the oracle
+    (OracleA2C.kink_cols: a float32 evaluation may sit on the other side of the kink there; those columns are only
+    required to be finite and within 10 % of the tensor's scale)."""
+    scale = max(np.abs(og).max(), 1e-7)
+    err = np.abs(got - og)
+    layer = k.split('_')[0]
+    kink = getattr(o, 'kink_cols', None)
+    if kink is not None and layer in kink[t]:
+        cols = kink[t][layer]
+        if cols.any():
+            bad = err[..., cols] if err.ndim == 2 else err[cols]
+            assert np.isfinite(bad).all() and bad.max() <= 0.1 * scale
+            err = err[..., ~cols] if err.ndim == 2 else err[~cols]
+            if err.size == 0:
+                return 0.0
+    return float(err.max() / scale)
 
 
 def _rand_obs(scn, E, rng):
@@ -197,9 +218,9 @@ def test_backward_matches_oracle(agent, E, T, terminal, policy, use_cache):
         g = m.unpack(m.grad_tensor().cpu().numpy())
         for t in range(m.G):
             for k, og in ograds[t].items():
-                og = og.numpy()
-                scale = max(np.abs(og).max(), 1e-7)
-                np.testing.assert_allclose(g[t][k], og, atol=2e-3 * scale, rtol=0, err_msg='it=%d tower=%d %s' % (it, t, k))
+                err = _grad_err(o, t, k, g[t][k], og.numpy())
+                # second round: the parameters already differ by the first update's fp32 rounding (<= 3e-5)
+                assert err <= (2e-5 if it == 0 else 2e-4), 'it=%d tower=%d %s: |dg| / max|g| = %.2e' % (it, t, k, err)
         # structural zeros of the block-diagonal FC must have exactly zero gradient
         flat = m.grad_tensor().cpu().numpy().reshape(m.G, m.stride)
         packed = m.pack(g).reshape(m.G, m.stride)
@@ -408,9 +429,9 @@ def test_forward_sample_multi_tile_vs_oracle(scenario, agent, E, ws, monkeypatch
     m.close()
 
 
-def _update_vs_oracle(scn, m, o, E, T, rng, iters, use_cache, terminal_first=False, gtol=2e-3):
+def _update_vs_oracle(scn, m, o, E, T, rng, iters, use_cache, terminal_first=False, gtol=2e-5):
     from deeprl_signal_control_amd import _lib
-    worst = 0.0
+    worst = {}
     for it in range(iters):
         obs, done = _fill(scn, m, o, E, T, rng, terminal=terminal_first and it == 0, use_cache=use_cache)
         Rb = m.forward(torch.from_numpy(obs).cuda(), False, 'v').clone()
@@ -423,11 +444,9 @@ def _update_vs_oracle(scn, m, o, E, T, rng, iters, use_cache, terminal_first=Fal
         g = m.unpack(m.grad_tensor().cpu().numpy())
         for t in range(m.G):
             for k, og in ograds[t].items():
-                og = og.numpy()
-                scale = max(np.abs(og).max(), 1e-7)
-                err = np.abs(g[t][k] - og).max() / scale
-                worst = max(worst, err)
-                assert err <= gtol, 'it=%d tower=%d %s: |dg| / max|g| = %.2e' % (it, t, k, err)
+                err = _grad_err(o, t, k, g[t][k], og.numpy())
+                worst[k] = max(worst.get(k, 0.0), err)
+                assert err <= (gtol if it == 0 else 10 * gtol), 'it=%d tower=%d %s: |dg| / max|g| = %.2e' % (it, t, k, err)
         stats = np.zeros((scn.n_agent, 4))
         _lib.check(m._L.tsc_model_apply_grads(m._h, 5e-4, 1.0, stats.ctypes.data_as(C.c_void_p)))
         m.cur_t = 0
@@ -444,13 +463,13 @@ def _update_vs_oracle(scn, m, o, E, T, rng, iters, use_cache, terminal_first=Fal
 def test_update_bench_shape_T120():
     """One update at the benchmark's n_step = 120 with E = 160 (five 32-instance forward tiles, three 64-instance
     BPTT tiles, 3840 rows per split of dwxh / dx1w1 = 120 chunks of 32 rows, split boundaries inside a time step) through the
-    cached-activation path, against the float64 oracle.  The measured error is ~1e-4 of the tensor's largest
-    gradient entry; a 32-row chunk lost at a split boundary would be 2e-3."""
+    cached-activation path, against the float64 oracle.  Tolerance 1e-4 of the tensor's largest gradient entry
+    (hidden units on a ReLU kink excepted, see _grad_err); a 32-row chunk lost at a split boundary would be 2e-3."""
     E, T = 160, 120
     scn, m, o = _make('ma2c', E, T, seed=5)
     m.reset(); o.reset()
-    worst = _update_vs_oracle(scn, m, o, E, T, np.random.RandomState(3), 1, True, gtol=6e-4)
-    print('T=120 E=160 worst |dg| / max|g| = %.2e' % worst)
+    worst = _update_vs_oracle(scn, m, o, E, T, np.random.RandomState(3), 1, True, gtol=1e-4)
+    print('T=120 E=160 worst |dg| / max|g|:', {k: '%.1e' % v for k, v in worst.items()})
     m.close()
 
 
@@ -463,7 +482,7 @@ def test_monaco_learner_vs_oracle(agent, E, T, use_cache):
     assert m.H == (192 if agent == 'ma2c' else 128) and max(scn.n_a_ls) == 6 and min(scn.n_a_ls) == 2
     m.reset(); o.reset()
     worst = _update_vs_oracle(scn, m, o, E, T, np.random.RandomState(E), 2, use_cache, terminal_first=True)
-    print('monaco %s worst |dg| / max|g| = %.2e' % (agent, worst))
+    print('monaco %s worst |dg| / max|g|:' % agent, {k: '%.1e' % v for k, v in worst.items()})
     m.close()
 
 
