@@ -52,8 +52,28 @@ class VecTrainer:
         self.model.reset()
         self.episode_step = 0
 
+    def _explore_q(self):
+        """utils.py:142-193 for the value-based agents (IQL): epsilon-greedy forward, replay transitions, R = 0."""
+        env, model = self.env, self.model
+        ob = self.ob
+        finished = False
+        for _ in range(self.n_step):
+            action, _ = model.forward(ob, mode='explore')                    # utils.py:159
+            next_ob, reward, done_post, _ = env.step(action)
+            self.global_counter.next()
+            self.episode_step += 1
+            model.add_transition(ob, action, reward, next_ob, done_post)    # utils.py:166-167
+            finished = env.cur_sec >= env.scn.episode_length_sec
+            ob = next_ob
+            if finished:
+                break
+        self.ob, self.done = ob, done_post
+        return finished, None
+
     def explore(self):
         """utils.py:142-193.  Returns (episode_finished, R) with R the bootstrap values."""
+        if not self.agent.endswith('a2c'):
+            return self._explore_q()
         env, model = self.env, self.model
         ob, done = self.ob, self.done
         finished = False
@@ -82,7 +102,10 @@ class VecTrainer:
         if self.ob is None:
             self.start_episode()
         finished, R = self.explore()
-        stats = self.model.backward(R, want_stats=want_stats)
+        if self.agent.endswith('a2c'):
+            stats = self.model.backward(R, want_stats=want_stats)
+        else:
+            stats = self.model.backward(want_stats=want_stats)         # utils.py:291
         if finished:
             self.env.terminate()                                   # utils.py:293-294
             self.start_episode()
@@ -107,13 +130,16 @@ class VecTrainer:
         model.reset()
         rewards = []
         while True:
-            pi = model.forward(ob, done, 'p')
-            if self.agent == 'ma2c':
-                env.update_fingerprint(pi)
-            if policy_type != 'deterministic':
-                action = model.sample(pi)
+            if not self.agent.endswith('a2c'):                   # value-based (utils.py:221-226)
+                action, _ = model.forward(ob, stochastic=policy_type == 'stochastic')
             else:
-                action = pi.argmax(dim=-1).to(torch.int32)       # padded actions have probability 0
+                pi = model.forward(ob, done, 'p')
+                if self.agent == 'ma2c':
+                    env.update_fingerprint(pi)
+                if policy_type != 'deterministic':
+                    action = model.sample(pi)
+                else:
+                    action = pi.argmax(dim=-1).to(torch.int32)   # padded actions have probability 0
             ob, _, done, g = env.step(action)
             rewards.append(g.clone())
             if env.cur_sec >= env.scn.episode_length_sec:

@@ -1,5 +1,5 @@
 """CPU restatement of the reference's independent Q-learning agents -- TEST INFRASTRUCTURE ONLY
-(oracle/__init__.py).  Groundwork for the SURVEY 8(f) rank-1 row; no HIP path exists yet.
+(oracle/__init__.py): the checker of csrc/tsc_iql.hip (tests/test_iql_gpu.py).
 
 Follows:
   ReplayBuffer .............. agents/utils.py:231-263 (ring of `buffer_size` tuples, random.sample minibatch;
@@ -110,3 +110,77 @@ def act_epsilon_greedy(qs, eps, u_explore, u_action):
     if u_explore < eps:
         return int(u_action * len(qs))
     return int(np.argmax(qs))
+
+
+def floyd_sample(size, batch, uniform):
+    """`batch` distinct indices in [0, size) -- the documented replacement of random.sample (include/tsc.h
+    tsc_iql_compute_grads): for i in [0, B): j = size - B + i; t = floor(uniform(i) * (j + 1)); pick t, or j if t was
+    picked before."""
+    out = []
+    for i in range(batch):
+        j = size - batch + i
+        t = min(int(uniform(i) * (j + 1)), j)
+        out.append(j if t in out else t)
+    return out
+
+
+class OracleIQL:
+    """IQL over E env instances (agents/models.py:264-376): one OracleQ per agent, one ring per (instance, agent),
+    minibatch = the rows every instance's ring contributes, loss = mean over them (E = 1: the reference)."""
+
+    def __init__(self, agent_params, n_wave_ls, n_w_ls, n_a_ls, n_env, batch_size=20, buffer_size=1000, gamma=0.99,
+                 reward_norm=3000.0, reward_clip=2.0, max_grad_norm=40.0, replay_seed=0):
+        self.qs = [OracleQ(p, nw, nt, gamma, max_grad_norm) for p, nw, nt in zip(agent_params, n_wave_ls, n_w_ls)]
+        self.nw, self.nt, self.na = list(n_wave_ls), list(n_w_ls), list(n_a_ls)
+        self.A, self.E, self.B, self.cap = len(n_a_ls), n_env, batch_size, int(buffer_size)
+        self.rnorm, self.rclip, self.replay_seed = reward_norm, reward_clip, replay_seed
+        self.rings = [[ReplayBuffer(self.cap, batch_size) for _ in range(self.A)] for _ in range(n_env)]
+        self.update_step = 0
+        self.last_idx = None
+
+    def forward(self, obs):
+        """obs [E,A,SMAX] -> list[A] of q [E, n_a] (float64)."""
+        out = []
+        for a, q in enumerate(self.qs):
+            n = self.nw[a] + self.nt[a]
+            with torch.no_grad():
+                out.append(q_net(q.p, torch.as_tensor(np.asarray(obs)[:, a, :n], dtype=DT), q.n_s, q.n_w).numpy())
+        return out
+
+    def add_transition(self, obs, actions, rewards, next_obs, done):
+        r = np.asarray(rewards, np.float64)
+        if self.rnorm:
+            r = r / self.rnorm
+        if self.rclip:
+            r = np.clip(r, -self.rclip, self.rclip)
+        for e in range(self.E):
+            for a in range(self.A):
+                n = self.nw[a] + self.nt[a]
+                self.rings[e][a].add_transition(np.array(obs[e, a, :n], np.float64), int(actions[e, a]), float(np.float32(r[e, a])),
+                                                np.array(next_obs[e, a, :n], np.float64), bool(done[e]))
+
+    def minibatch_step(self, lr):
+        """-> (per-agent loss, per-agent grad norm, grads list[A] of dict) ; also applies the Adam step."""
+        from oracle.nets_oracle import sample_uniform
+        size = self.rings[0][0].size
+        idx = np.zeros((self.E, self.A, self.B), np.int32)
+        losses, norms, grads = [], [], []
+        for a, q in enumerate(self.qs):
+            obs, acts, nobs, rs, dones = [], [], [], [], []
+            for e in range(self.E):
+                p = e * self.A + a
+                ids = floyd_sample(size, self.B, lambda i: sample_uniform(self.replay_seed, self.update_step, p * self.B + i))
+                idx[e, a] = ids
+                for s in ids:
+                    ob, ac, r, nob, d = self.rings[e][a].buffer[s]
+                    obs.append(ob); acts.append(ac); rs.append(r); nobs.append(nob); dones.append(d)
+            loss, g = q.loss_and_grads(obs, acts, nobs, dones, rs)
+            grads.append({k: v.numpy().copy() for k, v in g.items()})
+            l2, norm = q.backward(obs, acts, nobs, dones, rs, lr)
+            losses.append(loss); norms.append(norm)
+        self.update_step += 1
+        self.last_idx = idx
+        return np.array(losses), np.array(norms), grads
+
+    def agent_params(self):
+        return [{k: v.numpy().astype(np.float32) for k, v in q.p.items()} for q in self.qs]
