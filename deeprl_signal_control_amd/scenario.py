@@ -492,7 +492,8 @@ def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: in
 # ---------------------------------------------------------------------------
 # real_net (Monaco)
 # ---------------------------------------------------------------------------
-def build_real_net(agent: str = 'ma2c', flow_rate: int = 325, sort_lanes: bool = True, **env_kw) -> Scenario:
+def build_real_net(agent: str = 'ma2c', flow_rate: int = 325, sort_lanes: bool = True, contract: bool = True,
+                   **env_kw) -> Scenario:
     """Monaco scenario (envs/real_net_env.py) from the compiled table file
     ``data/real_net.json`` (tools/compile_real_net.py: most.net.xml lanes / connections / signal links,
     NODES + PHASES of envs/real_net_env.py:20-68, flows of real_net/data/build_file.py:27-104).
@@ -632,7 +633,106 @@ def build_real_net(agent: str = 'ma2c', flow_rate: int = 325, sort_lanes: bool =
         neighbors=neighbors, n_s_ls=n_s, n_w_ls=n_w, n_f_ls=n_f, n_a_ls=n_a_ls,
         obs_kind=obs_kind, obs_src=obs_src, flows=flows, obs_len=lens,
         extra={'flow_rate': flow_rate, 'routes': routes}, **kw)
+    if contract:
+        scn = contract_chains(scn)
     return sort_lanes_by_load(scn) if sort_lanes else scn
+
+
+def contract_chains(scn: Scenario) -> Scenario:
+    """Merge 1-to-1 lane chains across unsignalised junctions (DESIGN.md microsim spec, "lane chains").
+
+    SUMO splits Monaco's roads at every geometry node: half of the lanes a route uses are 2-30 m pieces in series.  With
+    zero-length junctions, one lane hop per second and the room rule at lane entry such a chain is a far worse
+    bottleneck than the road it models.  Lane A is merged into its successor B when B is A's only successor on every
+    route, A is B's only feeder and the junction between them is unsignalised: the merged lane keeps B's name, signal,
+    movements and speed limit, is len(A) + len(B) long, and B's detector (whole lane, envs/env.py:376-377) becomes
+    x >= len(A) -- observations and rewards still count exactly the vehicles on the original lane B."""
+    NL, NR = scn.n_lane, scn.n_route
+    nxt = [set(int(x) for x in scn.mv_next[l] if x >= 0) for l in range(NL)]
+    ends = [bool((scn.mv_next[l] == -1).any()) for l in range(NL)]
+    ups = [[int(u) for u in scn.lane_up[l] if u >= 0] for l in range(NL)]
+    cand = {}                                   # A -> B mergeable pairs
+    for a in range(NL):
+        if scn.lane_node[a] >= 0 or ends[a] or len(nxt[a]) != 1:
+            continue
+        b = next(iter(nxt[a]))
+        if ups[b] == [a] and b != a:
+            cand[a] = b
+    # a merged lane must still fit its vehicles into LANE_CAP slots: grow chains from their downstream end while the
+    # total stays within what LANE_CAP - MAX_CROSS standing vehicles occupy; where a chain is cut the walk starts anew
+    max_len = (LANE_CAP - MAX_CROSS) * (VEH_LEN + MIN_GAP)
+    into = {}                                   # A -> B
+    work = [l for l in range(NL) if l not in cand]
+    while work:
+        cur = work.pop()
+        total = float(scn.lane_len[cur])
+        while len(ups[cur]) == 1 and cand.get(ups[cur][0]) == cur:
+            a = ups[cur][0]
+            if total + float(scn.lane_len[a]) > max_len:
+                work.append(a)
+                break
+            into[a] = cur
+            total += float(scn.lane_len[a])
+            cur = a
+    if not into:
+        return scn
+    head_of = {}                                # every lane -> (last lane of its chain, offset of its start in the merged lane)
+    def resolve(l):
+        chain = [l]
+        while chain[-1] in into:
+            chain.append(into[chain[-1]])
+        return chain
+    keep = [l for l in range(NL) if l not in into]
+    new_id = {l: i for i, l in enumerate(keep)}
+    first_of = {l: l for l in keep}             # kept lane -> first lane of its chain
+    offset = {l: 0.0 for l in keep}
+    for a in sorted(into):
+        if any(into.get(u) == a for u in range(NL)):
+            continue                            # not the first lane of its chain
+        chain = resolve(a)
+        last = chain[-1]
+        first_of[last] = a
+        offset[last] = float(sum(np.float32(scn.lane_len[c]) for c in chain[:-1]))
+    def remap_lane(v):
+        v = np.asarray(v)
+        out = v.copy()
+        for idx in np.ndindex(v.shape):
+            if v[idx] >= 0:
+                out[idx] = new_id[resolve(int(v[idx]))[-1]]
+        return out
+    lane_len = np.array([np.float32(offset[l]) + scn.lane_len[l] for l in keep], np.float32)
+    det = np.array([np.float32(offset[l]) + scn.lane_det_start[l] for l in keep], np.float32)
+    lane_up = np.full((len(keep), MAX_UP), -1, np.int32)
+    for i, l in enumerate(keep):
+        fs = sorted({new_id[resolve(u)[-1]] for u in ups[first_of[l]]})
+        lane_up[i, :len(fs)] = fs
+    mv_next = remap_lane(scn.mv_next[keep])
+    # a route that entered the chain at an inner lane keeps its movement rows from the last lane; rows of the dropped
+    # lanes only said "go to the next piece"
+    scn.extra['contracted'] = {scn.lane_names[a]: scn.lane_names[resolve(a)[-1]] for a in into}
+    scn.lane_names = [scn.lane_names[l] for l in keep]
+    scn.lane_len, scn.lane_det_start = lane_len, det
+    scn.lane_vmax, scn.lane_node = scn.lane_vmax[keep], scn.lane_node[keep]
+    scn.lane_up, scn.mv_next = lane_up, mv_next.astype(np.int32)
+    scn.mv_link, scn.mv_prio = scn.mv_link[keep], scn.mv_prio[keep]
+    scn.mv_yield = remap_lane(scn.mv_yield[keep]).astype(np.int32)
+    zp = np.zeros_like(scn.mv_zip[keep])
+    for i in range(len(keep)):                  # zipper slots follow the new feeder lists
+        for r in range(NR):
+            t2 = scn.mv_next[i, r]
+            if t2 >= 0:
+                fs = [u for u in scn.lane_up[t2] if u >= 0]
+                if len(fs) > 1:
+                    zp[i, r] = fs.index(i) | (len(fs) << 8)
+    scn.mv_zip = zp
+    scn.route_entry_lane = remap_lane(scn.route_entry_lane).astype(np.int32)
+    scn.agent_lanes = remap_lane(scn.agent_lanes).astype(np.int32)
+    scn.link_lane = remap_lane(scn.link_lane).astype(np.int32)
+    src = scn.obs_src.copy()
+    m = (scn.obs_kind >= 1) & (scn.obs_kind <= 3)
+    src[m] = remap_lane(scn.obs_src[m])
+    scn.obs_src = src.astype(np.int32)
+    return scn
 
 
 def lane_load(scn: Scenario) -> np.ndarray:

@@ -61,7 +61,9 @@ class _Detector:
         self.whole = whole_lane
 
     def _start(self, lane):
-        return 0.0 if self.whole else float(self.c.scn.lane_len[lane] - 50.0)
+        # whole lane: the compiled lane may be a contracted chain whose last piece is the SUMO lane (scenario.py
+        # contract_chains) -- lane_det_start marks where that piece begins (0 for an uncontracted lane)
+        return float(self.c.scn.lane_det_start[lane]) if self.whole else float(self.c.scn.lane_len[lane] - 50.0)
 
     def getLastStepVehicleNumber(self, ild):           # env.py:377,379
         l = self.c.lidx[ild]
@@ -77,7 +79,8 @@ class _Detector:
         return ['%d:%d' % (l, i) for i in range(d['n']) if d['x'][i] >= np.float32(self._start(l))]
 
     def getLength(self, ild):
-        return float(self.c.scn.lane_len[self.c.lidx[ild]])
+        l = self.c.lidx[ild]
+        return float(self.c.scn.lane_len[l] - (self.c.scn.lane_det_start[l] if self.whole else 0.0))
 
 
 class _Vehicle:

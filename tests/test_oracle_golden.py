@@ -121,7 +121,7 @@ def test_live_lanes_are_a_prefix_after_load_sorting(name):
     assert reach == set(range(nu))
     load = lane_load(scn)
     assert set(np.nonzero(load > 0)[0].tolist()) == reach
-    assert nu == {'large_grid': 81, 'real_net': 160}[name]
+    assert nu == {'large_grid': 81, 'real_net': 113}[name]      # real_net: 160 SUMO lanes, 1-to-1 chains contracted
     for l in reach:
         for r in range(NR):
             t = int(scn.mv_next[l][r])

@@ -136,3 +136,31 @@ def test_greedy_controller_matches_reference(golden_dir):
     scn = build_real_net('greedy')
     np.testing.assert_array_equal(greedy_actions(scn, g['wave']), g['action'])
     np.testing.assert_array_equal(greedy_actions(scn, torch.from_numpy(g['wave'])).numpy(), g['action'])
+
+
+def test_lane_chain_contraction_preserves_routes_and_detectors():
+    """scenario.contract_chains: merged lanes keep the SUMO lane's name / signal / detector (x >= det_start is the original
+    lane), every route keeps its length and its signalised links, nothing longer than LANE_CAP - MAX_CROSS vehicles."""
+    from deeprl_signal_control_amd.scenario import LANE_CAP, MAX_CROSS
+    raw, scn = build_real_net('ma2c', contract=False, sort_lanes=False), build_real_net('ma2c', sort_lanes=False)
+    assert scn.n_s_ls == raw.n_s_ls and scn.n_lane < raw.n_lane and len(scn.extra['contracted']) == raw.n_lane - scn.n_lane
+    rid = {n: i for i, n in enumerate(raw.lane_names)}
+
+    def walk(s, r):
+        l, tot, links, names = int(s.route_entry_lane[r]), 0.0, [], []
+        while l >= 0:
+            tot += float(s.lane_len[l]); names.append(s.lane_names[l])
+            if s.lane_node[l] >= 0 and s.mv_link[l, r] >= 0:
+                links.append((int(s.lane_node[l]), int(s.mv_link[l, r])))
+            l = int(s.mv_next[l, r])
+        return tot, links, names
+    for r in range(scn.n_route):
+        t0, k0, n0 = walk(raw, r)
+        t1, k1, n1 = walk(scn, r)
+        assert abs(t0 - t1) < 1e-2 and k0 == k1 and [n for n in n0 if n not in scn.extra['contracted']] == n1
+    for l, name in enumerate(scn.lane_names):
+        assert abs((scn.lane_len[l] - scn.lane_det_start[l]) - raw.lane_len[rid[name]]) < 1e-3      # detector = the SUMO lane
+        assert scn.lane_len[l] <= (LANE_CAP - MAX_CROSS) * 7.5 or scn.lane_det_start[l] == 0
+    for a in range(scn.n_agent):                                      # observed / signalised lanes are never merged away
+        assert [scn.lane_names[l] for l in scn.agent_lanes[a, :scn.agent_nlane[a]]] == \
+               [raw.lane_names[l] for l in raw.agent_lanes[a, :raw.agent_nlane[a]]]

@@ -243,10 +243,10 @@ def iql_fixtures():
 
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
-    env_fixtures()
-    real_net_fixtures()
-    greedy_fixtures()
-    iql_fixtures()
-    learner_fixtures()
+    only = set(sys.argv[1:])                 # e.g. `python tools/make_golden.py real_net greedy`
+    for name, fn in (('env', env_fixtures), ('real_net', real_net_fixtures), ('greedy', greedy_fixtures),
+                     ('iql', iql_fixtures), ('learner', learner_fixtures)):
+        if not only or name in only:
+            fn()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
