@@ -30,6 +30,7 @@ class TscScenario(C.Structure):
         ('realnet_scale', C.c_int32),
         ('coop_gamma', C.c_double), ('norm_wave', C.c_double), ('norm_wait', C.c_double),
         ('clip_wave', C.c_double), ('clip_wait', C.c_double), ('coef_wait', C.c_double),
+        ('lane_origin', _fp),
     ]
 
 
@@ -39,7 +40,7 @@ _LIB = None
 SYMBOLS = ['tsc_last_error', 'tsc_version', 'tsc_profile_enable', 'tsc_profile_reset', 'tsc_profile_read',
            'tsc_profile_name', 'tsc_env_create', 'tsc_env_destroy', 'tsc_env_set_stream',
            'tsc_env_reset', 'tsc_env_set_fingerprint', 'tsc_env_bind_fingerprint', 'tsc_env_reward_sum', 'tsc_env_step', 'tsc_env_get_state',
-           'tsc_env_live_vehicles', 'tsc_env_debug_clock',
+           'tsc_env_live_vehicles', 'tsc_env_debug_clock', 'tsc_env_live_sum', 'tsc_env_record', 'tsc_env_read_record', 'tsc_env_read_trips',
            'tsc_model_create', 'tsc_model_destroy', 'tsc_model_set_stream', 'tsc_model_layout',
            'tsc_model_set_params', 'tsc_model_reset_opt_state', 'tsc_model_debug_read', 'tsc_model_get_params', 'tsc_model_get_opt_state', 'tsc_model_set_opt_state',
            'tsc_model_reset', 'tsc_model_forward', 'tsc_model_forward_sample', 'tsc_model_sample', 'tsc_model_add_transition',
@@ -78,6 +79,10 @@ def lib():
     L.tsc_env_get_state.argtypes = [vp, C.c_int32, _ip, _fp, _fp, _fp, _ip, _ip, _ip, _ip, _ip]
     L.tsc_env_live_vehicles.argtypes = [vp, C.POINTER(C.c_double)]
     L.tsc_env_debug_clock.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64)]
+    L.tsc_env_live_sum.argtypes = [vp, C.POINTER(C.c_double), C.c_int32]
+    L.tsc_env_record.argtypes = [vp, C.c_int32, C.c_int32]
+    L.tsc_env_read_record.argtypes = [vp, vp, vp, vp]
+    L.tsc_env_read_trips.argtypes = [vp, C.c_int32, vp, C.c_int32, C.POINTER(C.c_int32)]
     _LIB = L
     return L
 
@@ -123,7 +128,8 @@ def scenario_struct(scn):
         queue_cap=scn.queue_cap, objective={'queue': 0, 'wait': 1, 'hybrid': 2}[scn.objective],
         agent_kind=agent_kind, realnet_scale=int(scn.reward_scale_realnet),
         coop_gamma=scn.coop_gamma, norm_wave=scn.norm_wave, norm_wait=scn.norm_wait,
-        clip_wave=scn.clip_wave, clip_wait=scn.clip_wait, coef_wait=scn.coef_wait)
+        clip_wave=scn.clip_wave, clip_wait=scn.clip_wait, coef_wait=scn.coef_wait,
+        lane_origin=arr(scn.lane_origin, np.float32, _fp))
     return s, keep
 
 

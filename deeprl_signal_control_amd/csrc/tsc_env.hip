@@ -75,6 +75,17 @@ struct EnvDev {
     double *reward_acc;            // [E] running sum of the global reward (training-curve logging, utils.py:161,296-305)
     const float *fp_bound;         // zero-copy fingerprint source (tsc_env_bind_fingerprint) or null
     long long *dbg;                // optional: shader-clock stamps of workgroup 0 / thread 0 (tsc_env_debug_clock)
+    // ---- evaluation recording (envs/env.py:409-437,498-515; tsc_env_record): off on the training path
+    int rec;                       // per-second network statistics + trip log are being kept
+    int trip_cap;                  // trip records per instance
+    const float *lane_origin;      // [NL] start of the SUMO lane inside the compiled lane (lane.* getters count from here)
+    uint32_t *R0, *R1;             // per vehicle, indexed like X: depart_sec | serial << 16 ; waiting seconds | waiting count << 16
+    long long *rec_int;            // [E][8 sec][4]: vehicles, departed, arrived, sum of waiting times
+    double *rec_speed;             // [E][8 sec]: sum of speeds (per-lane partial sums added in lane order)
+    int *rec_queue;                // [E][8 sec][A * LMAX]: halting vehicles on every incoming lane (whole SUMO lane)
+    int *trips;                    // [E][trip_cap][6]: route, serial, depart, arrival, waiting seconds, waiting count
+    int *n_trips;                  // [E]
+    unsigned long long *live_acc;  // [E] sum over control steps of the vehicles in the network (window-mean V)
 };
 
 __device__ __forceinline__ uint32_t hash32(uint32_t seed, uint32_t route, uint32_t serial, uint32_t stream) {
@@ -138,6 +149,8 @@ struct Smem {
     int *pend, *ser; uint8_t *emit;             // per-route insertion state [NR], emissions [NR*8]
     uint8_t *zip;                               // [NU*NR]
     int *pre, *wtot;                            // wave-local inclusive scan of queued vehicles [NLA], wave totals [16]
+    uint32_t *or0, *or1;                        // outbox of the trip records [kMaxCross*NLA]      (recording only)
+    int *rq; double *rsp; long long *rint;      // per-lane halting [NLA], speed partial sums [NLA], counters [4]  (recording only)
 };
 
 // One layout for the step and the reset kernel.
@@ -157,6 +170,12 @@ __host__ __device__ __forceinline__ void smem_layout(Smem &s, const EnvDev &P, T
     s.pend = (int *)take(4 * P.NR); s.ser = (int *)take(4 * P.NR); s.emit = (uint8_t *)take(8 * P.NR);
     s.zip = (uint8_t *)take((P.NU * P.NR + 3) / 4 * 4);
     s.pre = (int *)take(4 * P.NLA); s.wtot = (int *)take(4 * 16);
+    if (P.rec) {
+        s.or0 = (uint32_t *)take(4 * kMaxCross * P.NLA); s.or1 = (uint32_t *)take(4 * kMaxCross * P.NLA);
+        s.rq = (int *)take(4 * P.NLA); s.rsp = (double *)take(8 * P.NLA); s.rint = (long long *)take(8 * 4);
+    } else {
+        s.or0 = s.or1 = nullptr; s.rq = nullptr; s.rsp = nullptr; s.rint = nullptr;
+    }
 }
 
 __device__ __forceinline__ Smem carve(char *base, const EnvDev &P) {
@@ -226,7 +245,7 @@ __global__ void reset_kernel(EnvDev P, const uint32_t *seeds, float *obs) {
         float p = (float)(1.0 / (double)na);                       // envs/env.py:263-269
         for (int k = 0; k < P.PMAX; ++k) P.fp[((size_t)e * P.A + a) * P.PMAX + k] = k < na - 1 ? p : 0.0f;
     }
-    if (l == 0) { P.tsec[e] = 0; P.seed[e] = seeds[e]; P.arrived[e] = 0ull; }
+    if (l == 0) { P.tsec[e] = 0; P.seed[e] = seeds[e]; P.arrived[e] = 0ull; P.n_trips[e] = 0; P.live_acc[e] = 0ull; }
     __syncthreads();
     emit_obs(P, s, e, obs);
 }
@@ -251,7 +270,7 @@ __global__ void fingerprint_kernel(EnvDev P, const float *pi) {
 // grid fits the chip with no slack, and whenever another kernel ran in between (i.e. always, in the training
 // loop) XCD 0 admitted ~30 workgroups one full round late -> 178 us became 316 us per step
 // (tools/bench_env.py, tsc_env_debug_clock).  The cap costs ~120 B of scratch per lane and 8 % in isolation.
-template <int MAXT, bool HELP>
+template <int MAXT, bool HELP, bool REC = false>      // REC: evaluation recording (plain walk only)
 __global__ void __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1)
 step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, double *__restrict__ reward,
             double *__restrict__ greward, uint8_t *__restrict__ done, int train_mode) {
@@ -268,6 +287,10 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     float *X = P.X + (size_t)e * kCap * NLP, *V = P.V + (size_t)e * kCap * NLP, *SF = P.SF + (size_t)e * kCap * NLP;
     uint32_t *M = P.M + (size_t)e * kCap * NLP;
     float *C = P.C + (size_t)e * kCap * NLP;   // phase A1 -> A2: new speed of a queued vehicle that cannot cross
+    static_assert(!(HELP && REC), "recording uses the plain walk");
+    uint32_t *R0 = REC ? P.R0 + (size_t)e * kCap * NLP : nullptr, *R1 = REC ? P.R1 + (size_t)e * kCap * NLP : nullptr;
+    const float origin = REC && lane ? P.lane_origin[l] : 0.0f;
+    if (REC && l < 4) s.rint[l] = 0;
 
     // ---- prologue.  Everything is requested in two levels -- first all loads that depend on nothing, then (under
     // the table copies) the ones that need a first-level value -- and unconditionally (lane index clamped), so
@@ -424,14 +447,25 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         }
         // ================= phase A2 (K2): advance own vehicles from the OLD state =================
         int kept = 0, nsent = 0;
+        // recording: this lane's share of the per-second network statistics (envs/env.py:409-437)
+        int rq_halt = 0, rq_wait = 0, rq_arr = 0, rq_dep = 0;
+        double rq_speed = 0.0;
+        auto tally = [&](float xn, float vn, uint32_t nmeta) {
+            if constexpr (REC) {
+                rq_wait += (int)(nmeta & 0xFFFFu);
+                rq_speed += (double)vn;
+                if (vn < kHalt && xn >= origin) ++rq_halt;
+            }
+        };
         if (lane) {
             int ncross = 0;
             bool all_crossed = true;
             float pnx = INFINITY, pox = 0.0f, pov = 0.0f;
             // a vehicle that stays on the lane: compact it to slot `kept`, refresh the summary, count detectors
-            auto keep = [&](float xn, float vn, float sf, uint32_t nmeta) {
+            auto keep = [&](float xn, float vn, float sf, uint32_t nmeta, uint32_t r0 = 0u, uint32_t r1 = 0u) {
                 const unsigned ob = (unsigned)(kept * NLP + l) * 4u;
                 stg(X, ob, xn); stg(V, ob, vn); stg(SF, ob, sf); stg(M, ob, nmeta);
+                if constexpr (REC) { stg(R0, ob, r0); stg(R1, ob, r1); tally(xn, vn, nmeta); }
                 if (kept == 0) { hx = xn; hv = vn; hm = nmeta; }
                 tx = xn; tv = vn;
                 ++kept;
@@ -439,13 +473,15 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             };
             // ---- head walk: full evaluation.  Without HELP it covers the whole lane; with HELP only the platoon
             // that is crossing in this second plus the first vehicle that stays (everything behind it is phase A1).
-            struct Raw { float x, v, sf; uint32_t m; };
+            struct Raw { float x, v, sf; uint32_t m, r0, r1; };
             // Loads are UNCONDITIONAL (slot index clamped; every slot is allocated): the compiler can only keep a
             // load in flight across the evaluation of the previous vehicle (s_waitcnt vmcnt(N > 0)) when the
             // number of younger memory operations is known, which a load under `if (i < n)` destroys.
             auto load_raw = [&](int i) {
                 const unsigned ob = (unsigned)((i < kCap ? i : kCap - 1) * NLP + l) * 4u;
                 Raw r; r.x = ldg(X, ob); r.v = ldg(V, ob); r.sf = ldg(SF, ob); r.m = ldg(M, ob);
+                r.r0 = 0u; r.r1 = 0u;
+                if constexpr (REC) { r.r0 = ldg(R0, ob); r.r1 = ldg(R1, ob); }
                 return r;
             };
             int i = 0;
@@ -511,6 +547,10 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 if (!can_cross && xn > L) { xn = L; clamped = true; }
                 if (xn < x) { xn = x; clamped = true; }
                 if (clamped) vn = xn - x;
+                uint32_t r1n = cur.r1;
+                if constexpr (REC) {                   // tripinfo waitingTime / waitingCount
+                    if (vn < kHalt) r1n = (r1n + 1u) + (w == 0 ? 0x10000u : 0u);
+                }
                 w = (vn < kHalt) ? w + 1 : 0;
                 pnx = xn; pox = x; pov = v;
                 const uint32_t nmeta = (uint32_t)w | ((uint32_t)r << 16);
@@ -519,14 +559,24 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                         const int o = nsent * NLA + l;
                         const float ex = xn - L, Lt = s.len[tl];          // rounding of (L + Lt) - L
                         s.ox[o] = ex > Lt ? Lt : ex; s.ov[o] = vn; s.osf[o] = sf; s.om[o] = nmeta; s.oto[o] = tl;
+                        if constexpr (REC) { s.or0[o] = cur.r0; s.or1[o] = r1n; }
                         ++nsent;
                     } else {
                         ++arrived;
+                        if constexpr (REC) {
+                            ++rq_arr;
+                            const int k = atomicAdd(&P.n_trips[e], 1);
+                            if (k < P.trip_cap) {
+                                int *tr = P.trips + ((size_t)e * P.trip_cap + k) * 6;
+                                tr[0] = r; tr[1] = (int)(cur.r0 >> 16); tr[2] = (int)(cur.r0 & 0xFFFFu); tr[3] = t + 1;
+                                tr[4] = (int)(r1n & 0xFFFFu); tr[5] = (int)(r1n >> 16);
+                            }
+                        }
                     }
                     ++ncross;
                 } else {
                     all_crossed = false;
-                    keep(xn, vn, sf, nmeta);
+                    keep(xn, vn, sf, nmeta, cur.r0, r1n);
                 }
                 cur = nxt;
             }
@@ -599,6 +649,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                             if (ax < 0.0f) ax = 0.0f;
                         }
                         X[d] = ax; V[d] = av; SF[d] = s.osf[o]; M[d] = am;
+                        if constexpr (REC) { R0[d] = s.or0[o]; R1[d] = s.or1[o]; tally(ax, av, am); }
                         if (n == 0) { hx = ax; hv = av; hm = am; }
                         tx = ax; tv = av;
                         ++n;
@@ -624,6 +675,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                         const uint32_t am = (uint32_t)r << 16;
                         const int d = n * NLP + l;
                         X[d] = ax; V[d] = 0.0f; SF[d] = asf; M[d] = am;
+                        if constexpr (REC) { R0[d] = (uint32_t)t | ((uint32_t)ser << 16); R1[d] = 0u; tally(ax, 0.0f, am); ++rq_dep; }
                         if (n == 0) { hx = ax; hv = 0.0f; hm = am; }
                         tx = ax; tv = 0.0f;
                         ++n;
@@ -636,12 +688,42 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             }
         }
         publish();
+        if constexpr (REC) {
+            if (lthr) { s.rq[l] = rq_halt; s.rsp[l] = rq_speed; }
+            if (lane) {
+                atomicAdd((unsigned long long *)&s.rint[0], (unsigned long long)n); atomicAdd((unsigned long long *)&s.rint[1], (unsigned long long)rq_dep);
+                atomicAdd((unsigned long long *)&s.rint[2], (unsigned long long)rq_arr); atomicAdd((unsigned long long *)&s.rint[3], (unsigned long long)rq_wait);
+            }
+        }
         TSC_STAMP();
         __syncthreads();
         TSC_STAMP();
+        if constexpr (REC) {
+            // flush second `sub` of this control step: integers, speed (per-lane partial sums added in lane order: the
+            // oracle's association), halting vehicles of every incoming lane in (agent, lane) order
+            const size_t row = (size_t)e * 8 + sub;
+            if (l < 4) P.rec_int[row * 4 + l] = s.rint[l];
+            if (l == 0) {
+                double sp = 0.0;
+                for (int q = 0; q < P.NU; ++q) sp += s.rsp[q];
+                P.rec_speed[row] = sp;
+            }
+            for (int p2 = l; p2 < P.A * P.LMAX; p2 += blockDim.x) {
+                const int ln = P.agent_lanes[p2];
+                P.rec_queue[row * (P.A * P.LMAX) + p2] = (ln >= 0 && ln < P.NU) ? s.rq[ln] : 0;
+            }
+            __syncthreads();
+            if (l < 4) s.rint[l] = 0;
+        }
     }
 
     // ---- K4: detectors (envs/env.py:325-407): wave, halting, wait of the front-most vehicle
+    {   // window-mean live vehicles: one atomic per wavefront
+        int tot = lane ? n : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o, 64);
+        if ((l & 63) == 0 && tot) atomicAdd(&P.live_acc[e], (unsigned long long)tot);
+    }
     if (lane) {
         P.N[(size_t)e * NLP + l] = n;
         // counts were taken while the last simulated second wrote the vehicles; the front-most vehicle is slot 0
@@ -958,6 +1040,14 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     ALLOC(fp, float, (size_t)n_env * A * P.PMAX);
     ALLOC(arrived, unsigned long long, n_env);
     ALLOC(reward_acc, double, n_env);
+    ALLOC(n_trips, int, n_env); ALLOC(live_acc, unsigned long long, n_env);
+    {
+        std::vector<float> org((size_t)NL, 0.0f);
+        if (sc->lane_origin) org.assign(sc->lane_origin, sc->lane_origin + NL);
+        UP(lane_origin, float, org.data(), NL);
+    }
+    P.rec = 0; P.trip_cap = 0; P.R0 = P.R1 = nullptr; P.rec_int = nullptr; P.rec_speed = nullptr; P.rec_queue = nullptr;
+    P.trips = nullptr;
     P.fp_bound = nullptr;
     P.dbg = nullptr;
     TSC_HIP(hipMalloc((void **)&h->d_seeds, sizeof(uint32_t) * n_env));
@@ -981,6 +1071,66 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     *out = h;
+    return 0;
+}
+
+int tsc_env_record(tsc_env *h, int32_t enable, int32_t trip_cap) {
+    if (!h || trip_cap < 0) return tsc::fail("tsc_env_record: bad arguments");
+    EnvDev &P = h->P;
+    TSC_HIP(hipStreamSynchronize(h->stream));
+    if (enable && !P.R0) {
+        const size_t slots = (size_t)P.E * kCap * P.NLP;
+        ALLOC(R0, uint32_t, slots); ALLOC(R1, uint32_t, slots);
+        ALLOC(rec_int, long long, (size_t)P.E * 8 * 4); ALLOC(rec_speed, double, (size_t)P.E * 8);
+        ALLOC(rec_queue, int, (size_t)P.E * 8 * P.A * P.LMAX);
+        P.trip_cap = trip_cap > 0 ? trip_cap : 8192;
+        ALLOC(trips, int, (size_t)P.E * P.trip_cap * 6);
+    }
+    P.rec = enable ? 1 : 0;
+    h->smem = smem_bytes(P);
+    if (h->smem > 160 * 1024) return tsc::fail("tsc_env_record: LDS need %zu B > 160 KiB", h->smem);
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<1024, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    TSC_HIP(hipFuncSetAttribute((const void *)reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    return 0;
+}
+
+int tsc_env_read_record(tsc_env *h, int64_t *ints_host, double *speed_host, int32_t *queue_host) {
+    if (!h || !h->P.rec_int || !ints_host || !speed_host || !queue_host) return tsc::fail("tsc_env_read_record: recording is off");
+    const EnvDev &P = h->P;
+    TSC_HIP(hipStreamSynchronize(h->stream));
+    TSC_HIP(hipMemcpy(ints_host, P.rec_int, sizeof(long long) * (size_t)P.E * 8 * 4, hipMemcpyDeviceToHost));
+    TSC_HIP(hipMemcpy(speed_host, P.rec_speed, sizeof(double) * (size_t)P.E * 8, hipMemcpyDeviceToHost));
+    TSC_HIP(hipMemcpy(queue_host, P.rec_queue, sizeof(int) * (size_t)P.E * 8 * P.A * P.LMAX, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tsc_env_read_trips(tsc_env *h, int32_t e, int32_t *trips_host, int32_t max_trips, int32_t *count) {
+    if (!h || !h->P.trips || e < 0 || e >= h->P.E || !trips_host || !count) return tsc::fail("tsc_env_read_trips: recording is off");
+    const EnvDev &P = h->P;
+    TSC_HIP(hipStreamSynchronize(h->stream));
+    int n = 0;
+    TSC_HIP(hipMemcpy(&n, P.n_trips + e, sizeof(int), hipMemcpyDeviceToHost));
+    *count = n;
+    if (n > P.trip_cap) n = P.trip_cap;
+    if (n > max_trips) n = max_trips;
+    if (n > 0) TSC_HIP(hipMemcpy(trips_host, P.trips + (size_t)e * P.trip_cap * 6, sizeof(int) * (size_t)n * 6, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tsc_env_live_sum(tsc_env *h, double *sum_host, int32_t reset) {
+    if (!h || !sum_host) return tsc::fail("tsc_env_live_sum: bad arguments");
+    TSC_HIP(hipStreamSynchronize(h->stream));
+    std::vector<unsigned long long> acc(h->P.E);
+    TSC_HIP(hipMemcpy(acc.data(), h->P.live_acc, sizeof(unsigned long long) * h->P.E, hipMemcpyDeviceToHost));
+    double t = 0;
+    for (unsigned long long v : acc) t += (double)v;
+    *sum_host = t;
+    if (reset) TSC_HIP(hipMemset(h->P.live_acc, 0, sizeof(unsigned long long) * h->P.E));
     return 0;
 }
 
@@ -1044,8 +1194,13 @@ int tsc_env_step(tsc_env *h, const int32_t *action_dev, float *obs_dev, double *
 #define TSC_STEP(MAXT, HELP)                                                                                       \
     hipLaunchKernelGGL((step_kernel<MAXT, HELP>), dim3(h->P.E), dim3(h->threads), h->smem, h->stream, h->P, action_dev, \
                        obs_dev, reward_dev, global_reward_dev, done_dev, (int)train_mode)
-    if (h->threads <= 256) { if (h->P.help) TSC_STEP(256, true); else TSC_STEP(256, false); }
+#define TSC_STEP_REC(MAXT)                                                                                         \
+    hipLaunchKernelGGL((step_kernel<MAXT, false, true>), dim3(h->P.E), dim3(h->threads), h->smem, h->stream, h->P, action_dev, \
+                       obs_dev, reward_dev, global_reward_dev, done_dev, (int)train_mode)
+    if (h->P.rec) { if (h->threads <= 256) TSC_STEP_REC(256); else TSC_STEP_REC(1024); }
+    else if (h->threads <= 256) { if (h->P.help) TSC_STEP(256, true); else TSC_STEP(256, false); }
     else { if (h->P.help) TSC_STEP(1024, true); else TSC_STEP(1024, false); }
+#undef TSC_STEP_REC
 #undef TSC_STEP
     TSC_HIP(hipGetLastError());
     return 0;

@@ -83,9 +83,77 @@ class VecTrafficEnv:
         self.stream = stream
         _lib.check(self._L.tsc_env_set_stream(self._h, C.c_void_p(stream.cuda_stream)))
 
-    def set_record(self, on):
-        """is_record (envs/env.py:517-528): per-second network statistics are accumulated on the device."""
+    def set_record(self, on, trip_cap=8192):
+        """init_data(is_record=True) (envs/env.py:517-528): the following steps keep, per simulated second, the network
+        statistics of _measure_traffic_step (:409-437), per control step the control log (:581-588) and a log of finished
+        trips (:498-515), per env instance.  Uses the recording instantiation of the step kernel (plain lane walk)."""
         self.is_record = bool(on)
+        if self.is_record or getattr(self, '_rec_alloc', False):
+            _lib.check(self._L.tsc_env_record(self._h, int(self.is_record), int(trip_cap)))
+            self._rec_alloc = True
+        if self.is_record:
+            K = self.scn.agent_lanes.shape[1]
+            self._rec_ints = np.zeros((self.E, 8, 4), np.int64)
+            self._rec_speed = np.zeros((self.E, 8), np.float64)
+            self._rec_queue = np.zeros((self.E, 8, self.A * K), np.int32)
+            self._ild_mask = (np.arange(K)[None, :] < np.asarray(self.scn.agent_nlane)[:, None]).ravel()
+            self.traffic_data = [[] for _ in range(self.E)]
+            self.control_data = [[] for _ in range(self.E)]
+            self.trip_data = [[] for _ in range(self.E)]
+
+    def _record_step(self, action):
+        """Append this control step's rows (reference dict keys; envs/env.py:429-437, :582-587)."""
+        vp = C.c_void_p
+        _lib.check(self._L.tsc_env_read_record(self._h, self._rec_ints.ctypes.data_as(vp), self._rec_speed.ctypes.data_as(vp),
+                                               self._rec_queue.ctypes.data_as(vp)))
+        ctrl = self.scn.control_interval_sec
+        act = action.cpu().numpy()
+        g = self.global_reward.cpu().numpy()
+        for e in range(self.E):
+            for q in range(ctrl):
+                n, dep, arr, wsum = (int(x) for x in self._rec_ints[e, q])
+                queues = self._rec_queue[e, q][self._ild_mask]
+                self.traffic_data[e].append({'episode': self.cur_episode, 'time_sec': self.cur_sec - ctrl + q + 1,
+                                             'number_total_car': n, 'number_departed_car': dep, 'number_arrived_car': arr,
+                                             'avg_wait_sec': wsum / n if n > 0 else 0,
+                                             'avg_speed_mps': self._rec_speed[e, q] / n if n > 0 else 0,
+                                             'std_queue': np.std(queues), 'avg_queue': np.mean(queues)})
+            self.control_data[e].append({'episode': self.cur_episode, 'time_sec': self.cur_sec, 'step': self.cur_sec / ctrl,
+                                         'action': ','.join(['%d' % a for a in act[e]]), 'reward': g[e]})
+
+    def collect_tripinfo(self):
+        """envs/env.py:498-515: the finished trips of the episode just run, in (arrival, route, serial) order; ids are
+        f_<route>.<serial within the route>, times formatted like SUMO's tripinfo attributes."""
+        buf = np.zeros((8192, 6), np.int32)
+        for e in range(self.E):
+            cnt = C.c_int32()
+            while True:
+                _lib.check(self._L.tsc_env_read_trips(self._h, e, buf.ctypes.data_as(C.c_void_p), len(buf), C.byref(cnt)))
+                if cnt.value <= len(buf):
+                    break
+                buf = np.zeros((cnt.value, 6), np.int32)
+            tr = buf[:cnt.value]
+            tr = tr[np.lexsort((tr[:, 1], tr[:, 0], tr[:, 3]))]
+            for r, ser, dep, arr, wsec, wcnt in tr:
+                self.trip_data[e].append({'episode': self.cur_episode, 'id': 'f_%d.%d' % (r, ser), 'depart_sec': '%.2f' % dep,
+                                          'arrival_sec': '%.2f' % arr, 'duration_sec': '%.2f' % (arr - dep),
+                                          'wait_step': '%d' % wcnt, 'wait_sec': '%.2f' % wsec})
+
+    def output_data(self, output_path, e=0, name=None):
+        """envs/env.py:534-542: <name>_<agent>_{control,traffic,trip}.csv with the reference's columns (pandas'
+        alphabetical order, as in real_net_experimental_data/eva_data/)."""
+        import pandas as pd
+        name = name or self.scn.name
+        for kind, rows in (('control', self.control_data[e]), ('traffic', self.traffic_data[e]), ('trip', self.trip_data[e])):
+            df = pd.DataFrame(rows)
+            df = df[sorted(df.columns)] if len(df.columns) else df
+            df.to_csv(output_path + ('%s_%s_%s.csv' % (name, self.agent, kind)))
+
+    def live_vehicle_mean(self, steps, reset=True):
+        """Window mean of the vehicles in the network per env instance over the last `steps` control steps."""
+        v = C.c_double()
+        _lib.check(self._L.tsc_env_live_sum(self._h, C.byref(v), int(reset)))
+        return v.value / max(1, steps * self.E)
 
     # -- reference API, batched ------------------------------------------------------------
     def reset(self, test_ind=0):
@@ -131,6 +199,8 @@ class VecTrafficEnv:
                                         C.c_void_p(self.global_reward.data_ptr()),
                                         C.c_void_p(self.done.data_ptr()), int(self.train_mode)))
         self.cur_sec += self.scn.control_interval_sec
+        if getattr(self, 'is_record', False):
+            self._record_step(action)
         return self.obs, self.reward, self.done, self.global_reward
 
     # -- debug / parity ---------------------------------------------------------------------
@@ -232,6 +302,20 @@ class TrafficEnv:
         """envs/env.py:517-528."""
         self.is_record, self.record_stats, self.output_path = is_record, record_stats, output_path
         self.vec.set_record(bool(is_record))
+
+    traffic_data = property(lambda self: self.vec.traffic_data[0])
+    control_data = property(lambda self: self.vec.control_data[0])
+    trip_data = property(lambda self: self.vec.trip_data[0])
+
+    def collect_tripinfo(self):
+        """envs/env.py:498-515 (call after the episode, like the reference's evaluation scripts)."""
+        self.vec.collect_tripinfo()
+
+    def output_data(self):
+        """envs/env.py:534-542."""
+        if not self.is_record:
+            raise RuntimeError('Env: no record to output!')
+        self.vec.output_data(self.output_path, 0, self.name)
 
     train_mode = property(lambda self: self.vec.train_mode,
                           lambda self, v: setattr(self.vec, 'train_mode', v))

@@ -98,6 +98,12 @@ class Scenario:
     reward_scale_realnet: bool = False
     teleport_sec: int = 600          # --time-to-teleport (env.py:281-284)
     extra: Dict = field(default_factory=dict)
+    lane_origin: np.ndarray = None   # f32 [NL] where the SUMO lane of that name begins inside the compiled lane (0 unless
+                                     # contract_chains merged upstream pieces into it): `lane.*` TraCI getters count from here
+
+    def __post_init__(self):
+        if self.lane_origin is None:
+            self.lane_origin = np.zeros(len(self.lane_names), np.float32)
 
     @property
     def n_lane(self) -> int:
@@ -712,6 +718,7 @@ def contract_chains(scn: Scenario) -> Scenario:
     scn.extra['contracted'] = {scn.lane_names[a]: scn.lane_names[resolve(a)[-1]] for a in into}
     scn.lane_names = [scn.lane_names[l] for l in keep]
     scn.lane_len, scn.lane_det_start = lane_len, det
+    scn.lane_origin = np.array([np.float32(offset[l]) + scn.lane_origin[l] for l in keep], np.float32)
     scn.lane_vmax, scn.lane_node = scn.lane_vmax[keep], scn.lane_node[keep]
     scn.lane_up, scn.mv_next = lane_up, mv_next.astype(np.int32)
     scn.mv_link, scn.mv_prio = scn.mv_link[keep], scn.mv_prio[keep]
@@ -762,7 +769,7 @@ def permute_lanes(scn: Scenario, order) -> Scenario:
         out[m] = new_of[v[m]]
         return out.astype(v.dtype)
     scn.lane_names = [scn.lane_names[i] for i in order]
-    for k in ('lane_len', 'lane_vmax', 'lane_node', 'lane_det_start'):
+    for k in ('lane_len', 'lane_vmax', 'lane_node', 'lane_det_start', 'lane_origin'):
         setattr(scn, k, getattr(scn, k)[order])
     up = remap(scn.lane_up[order])
     for i in range(len(up)):                                    # keep "ascending feeder index" order

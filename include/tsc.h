@@ -68,6 +68,8 @@ typedef struct tsc_scenario {
     int32_t agent_kind;       /* TSC_AGENT_* */
     int32_t realnet_scale;    /* envs/env.py:599-601,625-629 */
     double coop_gamma, norm_wave, norm_wait, clip_wave, clip_wait, coef_wait;
+    const float *lane_origin;  /* [n_lane] or NULL: where the SUMO lane begins inside a contracted lane chain (scenario.py
+                                * contract_chains); the lane.* getters of the recording path count from here */
 } tsc_scenario;
 
 typedef struct tsc_env tsc_env;
@@ -130,6 +132,21 @@ int tsc_env_debug_clock(tsc_env *h, int32_t enable, int64_t *stamps64_host);
 
 /* Mean number of live vehicles per env (roofline bookkeeping). Synchronises. */
 int tsc_env_live_vehicles(tsc_env *h, double *mean_live);
+/* Sum over instances and control steps since the last reset of the accumulator (or tsc_env_reset) of the vehicles in
+ * the network at the end of the step: window-mean V = sum / (steps * E)  (SURVEY.md 8d). Synchronises. */
+int tsc_env_live_sum(tsc_env *h, double *sum_host, int32_t reset);
+
+/* Evaluation recording = init_data(is_record=True) (envs/env.py:517-528): the following steps also keep, per simulated
+ * second, _measure_traffic_step's inputs (envs/env.py:409-437) and a log of finished trips (the --tripinfo-output file
+ * collect_tripinfo parses, :498-515).  Off on the training path (separate kernel instantiation).  Call before reset(). */
+int tsc_env_record(tsc_env *h, int32_t enable, int32_t trip_cap);
+/* Rows of the LAST step: ints [E, 8, 4] = vehicles in the network, departed, arrived, sum of waiting times of second q <
+ * control_interval_sec; speed [E, 8] = sum of speeds; queue [E, 8, A * l_max] = lane.getLastStepHaltingNumber of every
+ * incoming lane in (agent, ild) order (-1-padded lanes report 0).  Host pointers. Synchronises. */
+int tsc_env_read_record(tsc_env *h, int64_t *ints_host, double *speed_host, int32_t *queue_host);
+/* Finished trips of instance e since reset(): rows {route, serial within the route, depart_sec, arrival_sec, waiting
+ * seconds, waiting count}; *count = trips finished (may exceed max_trips / the capacity given to tsc_env_record). */
+int tsc_env_read_trips(tsc_env *h, int32_t e, int32_t *trips_host, int32_t max_trips, int32_t *count);
 
 /* ---- model: replaces IA2C / MA2C (agents/models.py:132-262) + LstmACPolicy / FPLstmACPolicy
  *      (agents/policies.py:75-211) + OnPolicyBuffer (agents/utils.py:182-228) + the TF1 runtime ---- */

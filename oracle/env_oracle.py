@@ -43,13 +43,17 @@ def numpy_pairwise_sum(a):
 class OracleEnv:
     """E = 1 restatement of TrafficSimulator (envs/env.py:82-635) for MARL agents."""
 
-    def __init__(self, scn, seed=12, test_seeds=(10000, 20000), train_mode=True):
+    def __init__(self, scn, seed=12, test_seeds=(10000, 20000), train_mode=True, is_record=False):
         self.scn = scn
+        self.is_record = is_record                     # env.py:517-528
+        self.traffic_data, self.control_data, self.trip_data = [], [], []
         self.agent = scn.agent
         self.seed = seed
         self.test_seeds = list(test_seeds)
         self.train_mode = train_mode
         self.ms = MicroSim(scn)
+        if is_record:
+            self.ms.record()
         self.n_agent = scn.n_agent
         self.node_names = scn.node_names
         self.n_s_ls, self.n_a_ls = scn.n_s_ls, scn.n_a_ls
@@ -135,6 +139,34 @@ class OracleEnv:
             rewards.append(r)
         return np.array(rewards)
 
+    def _simulate(self, num_step):                         # env.py:461-471
+        for _ in range(num_step):
+            self.ms.step(1)
+            self.cur_sec += 1
+            if self.is_record:
+                self._measure_traffic_step()
+
+    def _measure_traffic_step(self):                       # env.py:409-437
+        scn = self.scn
+        n, wsum, ssum = self.ms.network_stats()
+        tot = self.ms.totals()
+        queues = []
+        for a in range(self.n_agent):
+            for k in range(scn.agent_nlane[a]):
+                l = scn.agent_lanes[a, k]
+                queues.append(self.ms.lane_stats(l, float(scn.lane_origin[l]))[1])     # lane.getLastStepHaltingNumber
+        queues = np.array(queues)
+        self.traffic_data.append({'episode': self.cur_episode, 'time_sec': self.cur_sec, 'number_total_car': n,
+                                  'number_departed_car': tot['step_departed'], 'number_arrived_car': tot['step_arrived'],
+                                  'avg_wait_sec': wsum / n if n > 0 else 0, 'avg_speed_mps': ssum / n if n > 0 else 0,
+                                  'std_queue': np.std(queues), 'avg_queue': np.mean(queues)})
+
+    def collect_tripinfo(self):                            # env.py:498-515 (the tripinfo file SUMO writes at close)
+        for r, ser, dep, arr, wsec, wcnt in self.ms.trips():
+            self.trip_data.append({'episode': self.cur_episode, 'id': 'f_%d.%d' % (r, ser), 'depart_sec': '%.2f' % dep,
+                                   'arrival_sec': '%.2f' % arr, 'duration_sec': '%.2f' % (arr - dep), 'wait_step': '%d' % wcnt,
+                                   'wait_sec': '%.2f' % wsec})
+
     def update_fingerprint(self, policy):                  # env.py:633-635
         self.fingerprint = [np.array(pi)[:-1] for pi in policy]
 
@@ -153,17 +185,19 @@ class OracleEnv:
     def step(self, action):                                # env.py:566-631
         scn = self.scn
         self._set_phase(action, 'yellow')
-        self.ms.step(scn.yellow_interval_sec)
-        self.cur_sec += scn.yellow_interval_sec
+        self._simulate(scn.yellow_interval_sec)
         rest = scn.control_interval_sec - scn.yellow_interval_sec
         self._set_phase(action, 'green')
-        self.ms.step(rest)
-        self.cur_sec += rest
+        self._simulate(rest)
         wave, wait, halt = self._measure()
         state = self._get_state(wave, wait)
         reward = self._reward(wait, halt)
         done = self.cur_sec >= scn.episode_length_sec
         global_reward = np.sum(reward)
+        if self.is_record:                                 # env.py:581-588
+            self.control_data.append({'episode': self.cur_episode, 'time_sec': self.cur_sec,
+                                      'step': self.cur_sec / scn.control_interval_sec,
+                                      'action': ','.join(['%d' % a for a in action]), 'reward': global_reward})
         if not self.train_mode:
             return state, reward, done, global_reward
         if self.agent in ('a2c', 'greedy'):

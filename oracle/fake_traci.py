@@ -63,7 +63,7 @@ class _Detector:
     def _start(self, lane):
         # whole lane: the compiled lane may be a contracted chain whose last piece is the SUMO lane (scenario.py
         # contract_chains) -- lane_det_start marks where that piece begins (0 for an uncontracted lane)
-        return float(self.c.scn.lane_det_start[lane]) if self.whole else float(self.c.scn.lane_len[lane] - 50.0)
+        return float(self.c.scn.lane_origin[lane]) if self.whole else float(self.c.scn.lane_len[lane] - 50.0)
 
     def getLastStepVehicleNumber(self, ild):           # env.py:377,379
         l = self.c.lidx[ild]
@@ -80,7 +80,7 @@ class _Detector:
 
     def getLength(self, ild):
         l = self.c.lidx[ild]
-        return float(self.c.scn.lane_len[l] - (self.c.scn.lane_det_start[l] if self.whole else 0.0))
+        return float(self.c.scn.lane_len[l] - (self.c.scn.lane_origin[l] if self.whole else 0.0))
 
 
 class _Vehicle:
@@ -121,10 +121,24 @@ class _Simulation:
         return self.c.ms.totals()['step_arrived']
 
 
+def write_tripinfo(path, trips):
+    """SUMO's --tripinfo-output as far as envs/env.py:498-515 reads it (id, depart, arrival, duration, waitingCount,
+    waitingTime); vehicle ids are f_<route>.<serial within the route>."""
+    with open(path, 'w') as f:
+        f.write('<tripinfos>\n')
+        for r, ser, dep, arr, wsec, wcnt in trips:
+            f.write('    <tripinfo id="f_%d.%d" depart="%.2f" arrival="%.2f" duration="%.2f" waitingCount="%d" waitingTime="%.2f"/>\n'
+                    % (r, ser, dep, arr, arr - dep, wcnt, wsec))
+        f.write('</tripinfos>\n')
+
+
 class Connection:
-    def __init__(self, scn, seed):
+    def __init__(self, scn, seed, tripinfo=None):
         self.scn = scn
         self.ms = MicroSim(scn)
+        self.tripinfo = tripinfo
+        if tripinfo:
+            self.ms.record()
         self.ms.reset(seed)
         self.tl_ids = list(scn.node_names)
         self.aidx = {n: i for i, n in enumerate(scn.node_names)}
@@ -141,7 +155,8 @@ class Connection:
         self.ms.step()
 
     def close(self):                                   # env.py:564
-        pass
+        if self.tripinfo:
+            write_tripinfo(self.tripinfo, self.ms.trips())
 
 
 _SCN_FOR_CONNECT = {}
@@ -153,8 +168,8 @@ def install(scn):
     traci = types.ModuleType('traci')
 
     def connect(port=0, **_kw):
-        seed = _PENDING.pop(port, {}).get('seed', 0)
-        c = Connection(_SCN_FOR_CONNECT['scn'], seed)
+        pend = _PENDING.pop(port, {})
+        c = Connection(_SCN_FOR_CONNECT['scn'], pend.get('seed', 0), pend.get('tripinfo'))
         _SCN_FOR_CONNECT['last'] = c
         return c
     traci.connect = connect
@@ -181,7 +196,8 @@ def install(scn):
     class _FakePopen:
         def __init__(self, cmd, *a, **k):
             port = int(cmd[cmd.index('--remote-port') + 1])
-            _PENDING[port] = {'seed': int(cmd[cmd.index('--seed') + 1])}
+            _PENDING[port] = {'seed': int(cmd[cmd.index('--seed') + 1]),
+                              'tripinfo': cmd[cmd.index('--tripinfo-output') + 1] if '--tripinfo-output' in cmd else None}
     ref_env_mod.subprocess = types.SimpleNamespace(Popen=_FakePopen, check_call=subprocess.check_call)
     ref_env_mod.time = types.SimpleNamespace(sleep=lambda s: None, time=time.time)
     if not hasattr(np, 'bool'):
@@ -206,8 +222,9 @@ def ref_config(scenario, agent, config_name=None):
     return cfg
 
 
-def ref_env(scenario, agent, scn=None, config=None):
-    """Construct the reference's env class (unmodified) over the fake backend."""
+def ref_env(scenario, agent, scn=None, config=None, **env_kw):
+    """Construct the reference's env class (unmodified) over the fake backend.  env_kw: port / output_path / is_record /
+    record_stat of the reference constructors (envs/large_grid_env.py:64-68)."""
     from deeprl_signal_control_amd.scenario import build_scenario
     cfg = config or ref_config(scenario, agent)
     if scn is None:
@@ -215,10 +232,10 @@ def ref_env(scenario, agent, scn=None, config=None):
     install(scn)
     if scenario == 'large_grid':
         from envs.large_grid_env import LargeGridEnv
-        env = LargeGridEnv(cfg['ENV_CONFIG'])
+        env = LargeGridEnv(cfg['ENV_CONFIG'], **env_kw)
     elif scenario == 'real_net':
         from envs.real_net_env import RealNetEnv
-        env = RealNetEnv(cfg['ENV_CONFIG'])
+        env = RealNetEnv(cfg['ENV_CONFIG'], **env_kw)
     else:
         raise ValueError(scenario)
     env._tsc_cfg = cfg

@@ -38,6 +38,9 @@ def lib():
         L.ms_time.argtypes = [C.c_void_p]
         L.ms_totals.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.ms_check.argtypes = [C.c_void_p]
+        L.ms_record.argtypes = [C.c_void_p, C.c_int]
+        L.ms_trips.argtypes = [C.c_void_p, ip, C.c_int]
+        L.ms_network_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
         _LIB = L
     return _LIB
 
@@ -128,3 +131,19 @@ class MicroSim:
 
     def check(self):
         return self.L.ms_check(self.h)
+
+    def record(self, max_trips=16384):
+        """Keep a log of finished trips (the tripinfo file of the reference's evaluation runs)."""
+        self.L.ms_record(self.h, int(max_trips))
+        self._max_trips = int(max_trips)
+
+    def trips(self):
+        """[n, 6] int32: route, serial within the route, depart_sec, arrival_sec, waiting seconds, waiting count."""
+        buf = np.zeros((getattr(self, '_max_trips', 0), 6), np.int32)
+        n = self.L.ms_trips(self.h, buf.ctypes.data_as(C.POINTER(C.c_int32)), len(buf))
+        return buf[:min(n, len(buf))]
+
+    def network_stats(self):
+        n, w, s = C.c_int64(), C.c_int64(), C.c_double()
+        self.L.ms_network_stats(self.h, C.byref(n), C.byref(w), C.byref(s))
+        return n.value, w.value, s.value

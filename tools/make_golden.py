@@ -220,6 +220,44 @@ def learner_fixtures():
     np.savez_compressed(os.path.join(OUT, 'learner_known_answers.npz'), **flat)
 
 
+def eval_fixtures():
+    """The recording path of the reference (is_record=True: envs/env.py:409-437 per-second network statistics, :581-588
+    control log, :498-515 trip info parsed back from the tripinfo file the fake backend writes like SUMO would) under the
+    greedy controllers, one shortened episode per scenario: pins the schema and the arithmetic of the three CSV tables."""
+    import tempfile
+    from deeprl_signal_control_amd.scenario import build_large_grid, build_real_net
+    from deeprl_signal_control_amd.trainer import greedy_actions
+    for scenario, T in (('large_grid', 1200), ('real_net', 900)):
+        cfg = fake_traci.ref_config(scenario, 'greedy', 'config_test_large.ini' if scenario == 'large_grid' else 'config_test_real.ini')
+        cfg['ENV_CONFIG']['episode_length_sec'] = str(T)
+        kw = dict(norm_wave=1.0, norm_wait=1.0, clip_wave=1000.0, clip_wait=1000.0, coop_gamma=0.75, episode_length_sec=T)
+        scn = build_large_grid('greedy', **kw) if scenario == 'large_grid' else build_real_net('greedy', **kw)
+        out = tempfile.mkdtemp(prefix='tsc_eval_') + '/'
+        env = fake_traci.ref_env(scenario, 'greedy', scn=scn, config=cfg, port=0, output_path=out, is_record=True, record_stat=False)
+        env.train_mode = False
+        env.init_test_seeds([10000])
+        ob = env.reset(test_ind=0)
+        L = scn.agent_lanes.shape[1]
+        while True:
+            if scenario == 'large_grid':
+                act = [greedy_large_grid(o[:6]) for o in ob]
+            else:
+                w = np.zeros((scn.n_agent, L))
+                for a, o in enumerate(ob):
+                    w[a, :len(o)] = o
+                act = [int(x) for x in greedy_actions(scn, w)]
+            ob, _, done, _ = env.step(act)
+            if done:
+                break
+        env.terminate()
+        env.collect_tripinfo()
+        rec = {}
+        for name, rows in (('traffic', env.traffic_data), ('control', env.control_data), ('trip', env.trip_data)):
+            for k in rows[0]:
+                rec['%s_%s' % (name, k)] = np.array([r[k] for r in rows])
+        np.savez_compressed(os.path.join(OUT, '%s_eval.npz' % scenario), **rec)
+
+
 def iql_fixtures():
     """Known answers from the reference's ReplayBuffer (agents/utils.py:231-263) under a seeded `random`:
     which transitions survive the ring overwrite and which are drawn into the minibatches."""
@@ -245,7 +283,7 @@ if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])                 # e.g. `python tools/make_golden.py real_net greedy`
     for name, fn in (('env', env_fixtures), ('real_net', real_net_fixtures), ('greedy', greedy_fixtures),
-                     ('iql', iql_fixtures), ('learner', learner_fixtures)):
+                     ('iql', iql_fixtures), ('learner', learner_fixtures), ('eval', eval_fixtures)):
         if not only or name in only:
             fn()
     for f in sorted(os.listdir(OUT)):
