@@ -34,8 +34,10 @@ class Counter:
 
 
 class VecTrainer:
-    def __init__(self, env, model, global_counter=None):
+    def __init__(self, env, model, global_counter=None, log_rewards=False):
         self.env, self.model = env, model
+        self.log_rewards = log_rewards                          # keep the per-step global rewards of the episode (utils.py:161)
+        self._ep_rewards = []
         self.agent = env.agent
         self.n_step = model.n_step
         assert env.T % self.n_step == 0                         # utils.py:121
@@ -59,7 +61,9 @@ class VecTrainer:
         finished = False
         for _ in range(self.n_step):
             action, _ = model.forward(ob, mode='explore')                    # utils.py:159
-            next_ob, reward, done_post, _ = env.step(action)
+            next_ob, reward, done_post, g = env.step(action)
+            if self.log_rewards:
+                self._ep_rewards.append(g.clone())
             self.global_counter.next()
             self.episode_step += 1
             model.add_transition(ob, action, reward, next_ob, done_post)    # utils.py:166-167
@@ -83,6 +87,8 @@ class VecTrainer:
                 env.update_fingerprint(pi, zero_copy=True)       # before step (utils.py:149-151); pi is not
                                                                  # touched again until the next forward
             next_ob, reward, done_post, global_reward = env.step(action)
+            if self.log_rewards:
+                self._ep_rewards.append(global_reward.clone())
             self.global_counter.next()
             self.episode_step += 1
             model.add_transition(ob, done, action, reward, v, done_post)
@@ -117,6 +123,40 @@ class VecTrainer:
             if self.global_counter.should_stop():
                 break
 
+    def run_training(self, run_test=False, output_path=None, policy_type='default'):
+        """Trainer.run (utils.py:255-308): episodes until the counter stops; with run_test the test block every
+        test_interval control steps; one log row per training episode (test_id -1: mean / std over the episode's control
+        steps of the global reward, averaged over the env instances).  Returns the rows of train_reward.csv."""
+        import logging
+        data = []
+        was = self.log_rewards
+        self.log_rewards = True
+        while not self.global_counter.should_stop():
+            if run_test and self.global_counter.should_test():
+                rows = self.evaluate(policy_type, step=self.global_counter.cur_step)
+                data += rows
+                logging.info('Testing: global step %d, avg R: %.2f' % (self.global_counter.cur_step, np.mean([r['avg_reward'] for r in rows])))
+            self.env.train_mode = True
+            self.start_episode()
+            self._ep_rewards = []
+            while True:
+                finished, R = self.explore()
+                if self.agent.endswith('a2c'):
+                    self.model.backward(R)
+                else:
+                    self.model.backward()
+                if finished:
+                    self.env.terminate()
+                    break
+            r = torch.stack(self._ep_rewards)                       # [T, E]
+            mean, std = float(r.mean(0).mean().item()), float(r.std(0, unbiased=False).mean().item())
+            data.append({'agent': self.agent, 'step': self.global_counter.cur_step, 'test_id': -1, 'avg_reward': mean, 'std_reward': std})
+            if self.global_counter.should_log() or True:
+                logging.info('Training: global step %d, episode %d, avg R: %.2f' % (self.global_counter.cur_step, self.env.cur_episode, mean))
+            self.ob = None
+        self.log_rewards = was
+        return data
+
     # ---- evaluation (utils.py:195-234, 257-275) ---------------------------------------------
     def perform(self, test_ind=0, policy_type='default'):
         """Trainer.perform for every env instance at once: one test episode in the env's current mode
@@ -130,7 +170,9 @@ class VecTrainer:
         model.reset()
         rewards = []
         while True:
-            if not self.agent.endswith('a2c'):                   # value-based (utils.py:221-226)
+            if self.agent == 'greedy':                           # utils.py:202-203
+                action = model.forward(ob)
+            elif not self.agent.endswith('a2c'):                 # value-based (utils.py:221-226)
                 action, _ = model.forward(ob, stochastic=policy_type == 'stochastic')
             else:
                 pi = model.forward(ob, done, 'p')
