@@ -34,7 +34,7 @@ constexpr float kLen = 5.0f, kS0 = 2.5f, kAcc = 5.0f, kDec = 10.0f, kTHead = 1.5
 constexpr float kCab = 14.142136f, kHalt = 0.1f, kYieldT = 3.0f, kYieldD = 10.0f;
 constexpr int kCap = TSC_LANE_CAP, kMaxCross = TSC_MAX_CROSS, kMaxUp = TSC_MAX_UP;
 
-constexpr int kMaxEntry = 4;           // routes that may share one entry lane
+constexpr int kMaxEntry = 8;           // routes that may share one entry lane (small_grid: 6 paths leave np1_nt1)
 // movement word of (lane, route):  [11:0] next lane (0xFFF = route ends here, 0xFFE = n/a)
 //   [17:12] signal link (63 = none)   [29:18] lane this movement yields to (0xFFF = none)   [30] priority movement
 __host__ __device__ __forceinline__ int mv_tl(int w) { const int t = w & 0xFFF; return t == 0xFFF ? -1 : t == 0xFFE ? -2 : t; }
@@ -53,7 +53,7 @@ struct EnvDev {
     const int *route_entry;        // [NR]
     const int *flow_ptr;           // [NR+1] CSR over flows sorted by route
     const int *flows;              // [NF*4] begin,end,vph,route (sorted by route, stable)
-    const int *lane_routes;        // [NL][kMaxEntry] routes whose entry lane this is (-1 pad)
+    const uint32_t *lane_routes;   // [NL][2] the (<= kMaxEntry) routes whose entry lane this is, one byte each, 0xFF = none
     const uint8_t *emit_tab;       // [NR][emit_len] vehicles each route's flows emit at second t
     int emit_len;
     const int *agent_lanes, *agent_nlane, *agent_nlink, *agent_nphase;
@@ -305,17 +305,14 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     float L = P.lane_len[lc], vmax = P.lane_vmax[lc], det = P.lane_det[lc];
     int my_node = P.lane_node[lc];
     int up0 = P.lane_up[lc * kMaxUp], up1 = P.lane_up[lc * kMaxUp + 1], up2 = P.lane_up[lc * kMaxUp + 2], up3 = P.lane_up[lc * kMaxUp + 3];
-    int myr[kMaxEntry];
-#pragma unroll
-    for (int q = 0; q < kMaxEntry; ++q) myr[q] = P.lane_routes[lc * kMaxEntry + q];
+    uint32_t myr_lo = P.lane_routes[lc * 2], myr_hi = P.lane_routes[lc * 2 + 1];     // entry routes, a byte each
     int t = P.tsec[e];
     const uint32_t seed = P.seed[e];
     const int rc = l < NR ? l : NR - 1;
     const int pend0 = P.pending[(size_t)e * NR + rc], ser0 = P.serial[(size_t)e * NR + rc];
     if (!lane) {
         n = 0; L = 1.0f; vmax = 1.0f; det = 0.0f; my_node = -1; up0 = up1 = up2 = up3 = -1;
-#pragma unroll
-        for (int q = 0; q < kMaxEntry; ++q) myr[q] = -1;
+        myr_lo = myr_hi = 0xFFFFFFFFu;
     }
     // table copies: four (clamped, unconditional) loads in flight per thread and round instead of one
     auto copy_words = [&](uint32_t *dst, const uint32_t *src, int count) {
@@ -658,9 +655,9 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 }
             }
 #pragma unroll
-            for (int q = 0; q < kMaxEntry; ++q) {               // my entry routes, ascending
-                const int r = myr[q];
-                if (r < 0) continue;
+            for (int q = 0; q < kMaxEntry; ++q) {               // my entry routes, ascending (packed: 0xFF ends the list)
+                const int r = (int)(((q < 4 ? myr_lo : myr_hi) >> (8 * (q & 3))) & 0xFFu);
+                if (r == 0xFF) break;
                 int pend = s.pend[r] + (int)s.emit[r * 8 + sub];
                 int ser = s.ser[r];
                 if (pend > 0 && n < kCap) {
@@ -913,7 +910,7 @@ int tsc_version(void) { return 100; }
 int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_env **out) {
     if (!sc || !out || n_env <= 0) return tsc::fail("tsc_env_create: bad arguments");
     if (sc->n_lane > 1024) return tsc::fail("tsc_env_create: n_lane %d > 1024 unsupported", sc->n_lane);
-    if (sc->n_route > 255) return tsc::fail("tsc_env_create: n_route %d > 255 unsupported", sc->n_route);
+    if (sc->n_route > 254) return tsc::fail("tsc_env_create: n_route %d > 254 unsupported", sc->n_route);
     TSC_HIP(hipSetDevice(device));
     tsc_env *h = new tsc_env();
     h->device = device;
@@ -998,7 +995,12 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
             if (q == kMaxEntry) return tsc::fail("tsc_env_create: more than %d routes enter lane %d", kMaxEntry, l);
             lr[l * kMaxEntry + q] = r;
         }
-        UP(lane_routes, int, lr.data(), lr.size());
+        std::vector<uint32_t> lrp((size_t)NL * 2, 0xFFFFFFFFu);         // one byte per route (n_route <= 255 checked above)
+        for (int l = 0; l < NL; ++l)
+            for (int q = 0; q < kMaxEntry; ++q)
+                if (lr[l * kMaxEntry + q] >= 0)
+                    lrp[l * 2 + q / 4] = (lrp[l * 2 + q / 4] & ~(0xFFu << (8 * (q % 4)))) | ((uint32_t)lr[l * kMaxEntry + q] << (8 * (q % 4)));
+        UP(lane_routes, uint32_t, lrp.data(), lrp.size());
         P.emit_len = sc->episode_length_sec + 64;
         std::vector<uint8_t> em((size_t)NR * P.emit_len, 0);
         for (int f = 0; f < sc->n_flow; ++f) {

@@ -89,9 +89,11 @@ class GreedyPolicy:
     n_step = 1
 
     def __init__(self, scn):
-        from .trainer import greedy_actions, greedy_actions_large_grid, greedy_table
+        from .trainer import greedy_actions, greedy_actions_large_grid, greedy_actions_small_grid, greedy_table
         self.scn, self.table = scn, greedy_table(scn)
-        self._fn = greedy_actions_large_grid if scn.name == 'large_grid' else (lambda ob: greedy_actions(scn, ob, self.table))
+        self._fn = (greedy_actions_large_grid if scn.name == 'large_grid' else
+                    (lambda ob: greedy_actions_small_grid(scn, ob)) if scn.name == 'small_grid' else
+                    (lambda ob: greedy_actions(scn, ob, self.table)))
 
     def forward(self, ob, *_a, **_k):
         return self._fn(ob)

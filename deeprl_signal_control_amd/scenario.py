@@ -742,6 +742,204 @@ def contract_chains(scn: Scenario) -> Scenario:
     return scn
 
 
+# ---------------------------------------------------------------------------
+# small_grid (6 intersections)
+# ---------------------------------------------------------------------------
+SMALL_GRID_NEIGHBOR_MAP = {'nt1': ['npc', 'nt2', 'nt6'], 'nt2': ['nt1', 'nt3'], 'nt3': ['npc', 'nt2', 'nt4'],
+                           'nt4': ['nt3', 'nt5'], 'nt5': ['npc', 'nt4', 'nt6'], 'nt6': ['nt1', 'nt5']}    # envs/small_grid_env.py:20-25
+SMALL_GRID_STATE_PHASE_MAP = {'nt1': [0, 1, 2], 'nt2': [1, 0], 'nt3': [1, 0], 'nt4': [1, 0], 'nt5': [1, 0], 'nt6': [1, 0]}   # :29-30
+SMALL_GRID_PHASES = {2: ['GGrr', 'rrGG'], 3: ['GGGrrrrrr', 'rrrGGGrrr', 'rrrrrrGGG']}                                      # :35-36
+
+
+def small_grid_demand(num_car_hourly: int, episode_length_sec: int = 3600):
+    """The demand of small_grid/data/build_file.py as (edge path, begin, end, vph) elements.
+
+    The reference writes source flows (`from=` only, vehsPerHour per 600 s, :191-210) and lets SUMO's `jtrrouter` draw every
+    vehicle's turns from the ratios of output_turns (:223-307) with a per-episode seed; `jtrrouter` is not in this
+    image.  Here a source flow is split over its possible paths in proportion to the product of the turn ratios
+    (largest remainders, the total is kept): the expectation of the random routing, the same for every seed.  The
+    "mf_" flows (`probability=` num_car_hourly / 3600 per second on explicit routes, :167-190) become
+    vehsPerHour = round(3600 * that two-decimal probability)."""
+    src_flows = [[500, 100, 700, 800, 550, 550, 100, 200, 250, 250, 400, 800],
+                 [600, 700, 100, 200, 50, 100, 1000, 500, 450, 150, 400, 200],
+                 [100, 400, 400, 200, 600, 550, 100, 500, 500, 800, 400, 200],
+                 [100, 200, 300, 300, 300, 400, 600, 600, 800, 500, 400, 300],
+                 [600, 400, 400, 600, 800, 400, 300, 300, 300, 200, 250, 250]]
+    srcs = ['np1_nt1', 'np2_nt1', 'np3_nt1', 'np8_nt4', 'np9_nt4']
+    turns = {'np1_nt1': {'nt1_nt2': 0.2, 'nt1_nt6': 0.5, 'nt1_npc': 0.3},
+             'np2_nt1': {'nt1_nt2': 0.15, 'nt1_nt6': 0.15, 'nt1_npc': 0.7},
+             'np3_nt1': {'nt1_nt2': 0.5, 'nt1_nt6': 0.15, 'nt1_npc': 0.35},
+             'np8_nt4': {'nt4_nt3': 0.4, 'nt4_nt5': 0.6}, 'np9_nt4': {'nt4_nt3': 0.6, 'nt4_nt5': 0.4},
+             'nt3_nt2': {'nt2_np5': 1.0}, 'nt1_nt2': {'nt2_np4': 1.0}, 'nt5_nt6': {'nt6_np12': 1.0}, 'nt1_nt6': {'nt6_np13': 1.0},
+             'npc_nt3': {'nt3_nt2': 0.3, 'nt3_np6': 0.7}, 'npc_nt5': {'nt5_nt6': 0.3, 'nt5_np11': 0.7},
+             # nt4_nt3 / nt4_nt5 have no <fromEdge> entry in the reference's turn file: jtrrouter then splits uniformly
+             'nt4_nt3': {'nt3_nt2': 0.5, 'nt3_np6': 0.5}, 'nt4_nt5': {'nt5_nt6': 0.5, 'nt5_np11': 0.5}}
+    base_probs = np.array([[0.15, 0.15], [0.35, 0.35], [0.15, 0.2]])
+    sinks = {'nt6_np12', 'nt6_np13', 'nt2_np4', 'nt2_np5', 'nt5_np11', 'nt3_np6'}
+
+    def paths(edge, i0):
+        if edge in sinks:
+            return [([edge], 1.0)]
+        if edge == 'nt1_npc':                               # time-variant ratios at npc (:283-293)
+            cur = np.ravel(np.dot(np.array(src_flows[:3])[:, i0].reshape(1, 3), base_probs))
+            cur = cur / np.sum(cur)
+            t = {'npc_nt3': float(cur[0]), 'npc_nt5': float(cur[1])}
+        else:
+            t = turns[edge]
+        out = []
+        for e2, p in t.items():
+            out += [([edge] + q, p * pq) for q, pq in paths(e2, i0)]
+        return out
+    elements = []
+    for i0 in range(12):
+        tb, te = 600 * i0, 600 * (i0 + 1)
+        if tb >= episode_length_sec:
+            break
+        for j, src in enumerate(srcs):
+            vph = int(src_flows[j][i0] * 1.0)                # FLOW_MULTIPLIER = 1.0, "%i"
+            pp = paths(src, i0)
+            raw = [vph * p for _, p in pp]
+            alloc = [int(np.floor(x)) for x in raw]
+            for k in sorted(range(len(pp)), key=lambda k: (-(raw[k] - alloc[k]), k))[:vph - sum(alloc)]:
+                alloc[k] += 1
+            elements += [(tuple(path), tb, te, v) for (path, _), v in zip(pp, alloc) if v > 0]
+    mf_routes = ['nt1_npc npc_nt5 nt5_np11', 'nt1_npc npc_nt5 nt5_nt6 nt6_np12', 'nt4_nt5 nt5_np11', 'nt4_nt5 nt5_nt6 nt6_np12',
+                 'nt1_nt2 nt2_np4', 'nt1_nt6 nt6_np13', 'nt1_npc npc_nt3 nt3_np6', 'nt1_npc npc_nt3 nt3_nt2 nt2_np5',
+                 'nt4_nt3 nt3_np6', 'nt4_nt3 nt3_nt2 nt2_np5']
+    cases = [(3, 4, 5), (0, 3, 4), (1, 2, 5), (4, 5, 9), (5, 6, 9), (4, 7, 8)]
+    mf_vph = int(round(3600 * float('%.2f' % (num_car_hourly / float(3600)))))
+    for i, cs in enumerate(cases):
+        tb, te = 1200 * i, 1200 * (i + 1)
+        if tb >= episode_length_sec or mf_vph <= 0:
+            continue
+        elements += [(tuple(mf_routes[c].split()), tb, te, mf_vph) for c in cs]
+    return elements
+
+
+def build_small_grid(agent: str = 'greedy', num_extra_car_per_hour: int = 1000, sort_lanes: bool = True, **env_kw) -> Scenario:
+    """The 6-intersection benchmark (envs/small_grid_env.py, small_grid/data/build_file.py): 1-lane 20 m/s roads, nt1 with
+    three 1-approach phases, the others with two, lane-area detectors on the last 50 m of every incoming lane, the
+    unsignalised split node npc.  SUMO orders a node's signal links by incoming edge clockwise from north; the
+    hard-coded greedy map SMALL_GRID_STATE_PHASE_MAP is restated as is.  MARL agents: the reference's neighbour map lists
+    the non-signal node 'npc' and crashes; it is dropped from the neighbour lists here."""
+    L0, L1, LE = 200.0, 400.0, 75.0
+    L2, L2E = L0 / np.sqrt(2), LE / np.sqrt(2)
+    pos = {'nt1': (0, 0), 'nt2': (L1, 0), 'nt3': (L1, L0), 'nt4': (L1, L1), 'nt5': (L0, L1), 'nt6': (0, L1),
+           'np1': (0, -LE), 'np2': (-L2E, -L2E), 'np3': (-LE, 0), 'np4': (LE + L1, 0), 'np5': (L1, -LE), 'np6': (LE + L1, L0),
+           'np8': (LE + L1, L1), 'np9': (L1, LE + L1), 'np11': (L0, LE + L1), 'np12': (-LE, L1), 'np13': (0, LE + L1),
+           'npc': (L2, L2)}
+    edge_list = [('np1', 'nt1'), ('np2', 'nt1'), ('np3', 'nt1'), ('np8', 'nt4'), ('np9', 'nt4'), ('nt1', 'nt2'), ('nt1', 'npc'),
+                 ('nt1', 'nt6'), ('npc', 'nt3'), ('npc', 'nt5'), ('nt5', 'nt6'), ('nt4', 'nt3'), ('nt4', 'nt5'), ('nt3', 'nt2'),
+                 ('nt6', 'np12'), ('nt6', 'np13'), ('nt2', 'np4'), ('nt2', 'np5'), ('nt5', 'np11'), ('nt3', 'np6')]
+    elen = {'%s_%s' % e: float(np.hypot(pos[e[1]][0] - pos[e[0]][0], pos[e[1]][1] - pos[e[0]][1])) for e in edge_list}
+    conns = {}                                                    # in-edge -> out-edges (build_file.py:107-152)
+    for e in edge_list:
+        conns['%s_%s' % e] = ['%s_%s' % o for o in edge_list if o[0] == e[1] and o[1] != e[0]]
+    node_names = sorted(['nt%d' % i for i in range(1, 7)])
+    aidx = {n: i for i, n in enumerate(node_names)}
+
+    def bearing(n, frm):                                          # clockwise from north, of the node an edge comes from
+        dx, dy = pos[frm][0] - pos[n][0], pos[frm][1] - pos[n][1]
+        return (np.degrees(np.arctan2(dx, dy)) + 360.0) % 360.0
+    # a lane longer than LANE_CAP standing vehicles is cut into equal pieces joined 1-to-1 (the last piece keeps the
+    # edge's name: it carries the signal and the detector); 200 m lanes stay whole, as in large_grid
+    max_len = LANE_CAP * (VEH_LEN + MIN_GAP)
+    lane_names, lane_len, piece_first, piece_last = [], [], {}, {}
+    for e in ['%s_%s' % x for x in edge_list]:
+        k = int(np.ceil(elen[e] / max_len))
+        names = ['%s_0#%d' % (e, i) for i in range(k - 1)] + ['%s_0' % e]
+        piece_first[e], piece_last[e] = len(lane_names), len(lane_names) + k - 1
+        lane_names += names
+        lane_len += [elen[e] / k] * k
+    NL = len(lane_names)
+    lane_len = np.array(lane_len, np.float32)
+    # signal links: per TL node, incoming edges clockwise from north, their out-edges in the same sense
+    link_edges, phases = {}, []
+    for n in node_names:
+        ins = sorted([e for e in edge_list if e[1] == n], key=lambda e: bearing(n, e[0]))
+        links = []
+        for e in ins:
+            outs = sorted(conns['%s_%s' % e], key=lambda o: bearing(n, o.split('_')[1]))
+            links += [('%s_%s' % e, o) for o in outs]
+        link_edges[n] = links
+        ph = SMALL_GRID_PHASES[len(ins)]
+        assert len(ph[0]) == len(links)
+        phases.append(ph)
+    kmax = max(len(v) for v in link_edges.values())
+    demand = small_grid_demand(num_extra_car_per_hour, env_kw.get('episode_length_sec', 3600))
+    route_paths = []
+    for path, *_ in demand:
+        if path not in route_paths:
+            route_paths.append(path)
+    NR = len(route_paths)
+    mv_next = np.full((NL, NR), -2, np.int32)
+    mv_link = np.full((NL, NR), -1, np.int32)
+    lane_node = np.full(NL, -1, np.int32)
+    for e in ['%s_%s' % x for x in edge_list]:
+        if e.split('_')[1] in aidx:
+            lane_node[piece_last[e]] = aidx[e.split('_')[1]]
+    route_entry = np.zeros(NR, np.int32)
+    for r, path in enumerate(route_paths):
+        route_entry[r] = piece_first[path[0]]
+        for p, e in enumerate(path):
+            for l in range(piece_first[e], piece_last[e]):
+                mv_next[l, r] = l + 1
+            last = piece_last[e]
+            if p + 1 == len(path):
+                mv_next[last, r] = -1
+            else:
+                mv_next[last, r] = piece_first[path[p + 1]]
+                n = e.split('_')[1]
+                if n in aidx:
+                    mv_link[last, r] = link_edges[n].index((e, path[p + 1]))
+    lane_up = np.full((NL, MAX_UP), -1, np.int32)
+    for l2 in range(NL):
+        ups = sorted({l for l in range(NL) if (mv_next[l] == l2).any()})
+        assert len(ups) <= MAX_UP
+        lane_up[l2, :len(ups)] = ups
+    A = len(node_names)
+    link_lane = np.full((A, kmax), -1, np.int32)
+    lanes_per_agent = []
+    for a, n in enumerate(node_names):
+        seq = [piece_last[e] for e, _ in link_edges[n]]
+        link_lane[a, :len(seq)] = seq
+        ded = []
+        for l in seq:
+            if l not in ded:
+                ded.append(l)
+        lanes_per_agent.append(ded)
+    lmax = max(len(x) for x in lanes_per_agent)
+    agent_lanes = np.full((A, lmax), -1, np.int32)
+    for a, ded in enumerate(lanes_per_agent):
+        agent_lanes[a, :len(ded)] = ded
+    nlane = [len(x) for x in lanes_per_agent]
+    neighbors = [[aidx[j] for j in SMALL_GRID_NEIGHBOR_MAP[n] if j in aidx] for n in node_names]
+    n_a_ls = [len(p) for p in phases]
+    a_max = max(n_a_ls)
+    n_s, n_w, n_f = _state_dims(agent, nlane, n_a_ls, neighbors, True)
+    obs_kind, obs_src, lens = _obs_table(agent, agent_lanes, nlane, n_a_ls, neighbors, True, a_max)
+    green, yellow = _signal_tables(phases, kmax)
+    rid = {p: i for i, p in enumerate(route_paths)}
+    flows = np.array([[tb, te, vph, rid[path]] for path, tb, te, vph in demand], np.int32)
+    lane_det = np.where(lane_node >= 0, lane_len - DET_LEN, 0).astype(np.float32)
+    scn = Scenario(
+        name='small_grid', agent=agent, node_names=node_names, n_agent=A,
+        lane_names=lane_names, lane_len=lane_len, lane_vmax=np.full(NL, 20.0, np.float32), lane_node=lane_node,
+        lane_det_start=lane_det, lane_up=lane_up,
+        n_route=NR, mv_next=mv_next, mv_link=mv_link, mv_yield=np.full((NL, NR), -1, np.int32),
+        mv_prio=np.zeros((NL, NR), np.int32), mv_zip=np.zeros((NL, NR), np.int32), route_entry_lane=route_entry,
+        route_names=[(p[0], p[-1]) for p in route_paths],
+        agent_lanes=agent_lanes, agent_nlane=np.array(nlane, np.int32),
+        agent_nlink=np.array([len(link_edges[n]) for n in node_names], np.int32), agent_nphase=np.array(n_a_ls, np.int32),
+        link_lane=link_lane, phases=phases, green_tab=green, yellow_tab=yellow,
+        neighbors=neighbors, n_s_ls=n_s, n_w_ls=n_w, n_f_ls=n_f, n_a_ls=n_a_ls,
+        obs_kind=obs_kind, obs_src=obs_src, flows=flows, obs_len=lens,
+        extra={'num_extra_car_per_hour': num_extra_car_per_hour, 'routes': route_paths, 'demand': demand,
+               'state_phase_map': SMALL_GRID_STATE_PHASE_MAP}, **env_kw)
+    return sort_lanes_by_load(scn) if sort_lanes else scn
+
+
+
 def lane_load(scn: Scenario) -> np.ndarray:
     """Vehicles per episode routed over every lane (static proxy for queue length)."""
     load = np.zeros(scn.n_lane)
@@ -803,4 +1001,6 @@ def build_scenario(name: str, agent: str = 'ma2c', **kw) -> Scenario:
         return build_large_grid(agent, **kw)
     if name == 'real_net':
         return build_real_net(agent, **kw)
-    raise ValueError('unknown scenario %r (large_grid, real_net)' % name)
+    if name == 'small_grid':
+        return build_small_grid(agent, **kw)
+    raise ValueError('unknown scenario %r (large_grid, real_net, small_grid)' % name)

@@ -332,6 +332,29 @@ def greedy_actions_large_grid(obs):
     return flows.argmax(-1).to(torch.int32)
 
 
+def greedy_actions_small_grid(scn, obs):
+    """envs/small_grid_env.py:40-55 SmallGridController on the batched obs tensor [E,A,SMAX] (or a numpy array): the
+    reference's hard-coded map from the index of the fullest incoming lane to a phase (STATE_PHASE_MAP, restated as is --
+    for the two-phase nodes it serves the OTHER lane)."""
+    spm = scn.extra['state_phase_map']
+    A = scn.n_agent
+    k = np.array([len(spm[n]) for n in scn.node_names])
+    tab = np.zeros((A, int(k.max())), np.int64)
+    for a, n in enumerate(scn.node_names):
+        tab[a, :k[a]] = spm[n]
+    if torch.is_tensor(obs):
+        w = obs[..., :tab.shape[1]].clone()
+        valid = torch.as_tensor(np.arange(tab.shape[1])[None, :] < k[:, None], device=obs.device)
+        w = torch.where(valid, w, torch.full_like(w, -1.0))
+        best = w.max(-1, keepdim=True).values
+        rank = torch.arange(tab.shape[1], 0, -1, device=obs.device)
+        idx = ((w == best) * rank).argmax(-1)                           # first maximum, like np.argmax
+        return torch.as_tensor(tab, device=obs.device).expand(idx.shape + (tab.shape[1],)).gather(-1, idx[..., None])[..., 0].to(torch.int32)
+    w = np.where(np.arange(tab.shape[1])[None, :] < k[:, None], np.asarray(obs)[..., :tab.shape[1]], -1.0)
+    idx = w.argmax(-1)
+    return np.take_along_axis(np.broadcast_to(tab, idx.shape + (tab.shape[1],)), idx[..., None], -1)[..., 0].astype(np.int32)
+
+
 def greedy_table(scn):
     """[A, PMAX, LMAX] 0/1: lane j (ild order) of agent a has a 'G' link in phase p -- every lane once, as
     RealNetController.greedy counts it (envs/real_net_env.py:96-111; lower-case 'g' links do not count)."""

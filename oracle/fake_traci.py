@@ -211,6 +211,7 @@ def ref_config(scenario, agent, config_name=None):
                            ('large_grid', 'ia2c'): 'config_ia2c_large.ini',
                            ('large_grid', 'greedy'): 'config_test_large.ini',
                            ('large_grid', 'iqll'): 'config_iqll_large.ini',
+                           ('small_grid', 'greedy'): 'config_test_small.ini',
                            ('real_net', 'ma2c'): 'config_ma2c_real.ini',
                            ('real_net', 'ia2c'): 'config_ia2c_real.ini'}[(scenario, agent)]
     cfg = configparser.ConfigParser()
@@ -236,6 +237,13 @@ def ref_env(scenario, agent, scn=None, config=None, **env_kw):
     elif scenario == 'real_net':
         from envs.real_net_env import RealNetEnv
         env = RealNetEnv(cfg['ENV_CONFIG'], **env_kw)
+    elif scenario == 'small_grid':
+        import envs.small_grid_env as sg
+        # small_grid/data/build_file.py:310-335 shells out to SUMO's jtrrouter and parses its output; neither exists here and
+        # the demand lives in the compiled scenario tables (scenario.small_grid_demand) -- only the returned path is used
+        sg.gen_rou_file = lambda seed=None, thread=None, path=None, num_car_hourly=0: path + ('exp_%d.sumocfg' % thread)
+        cfg['ENV_CONFIG']['scenario'] = 'small_grid'          # config_test_small.ini says large_grid
+        env = sg.SmallGridEnv(cfg['ENV_CONFIG'], **env_kw)
     else:
         raise ValueError(scenario)
     env._tsc_cfg = cfg

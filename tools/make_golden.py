@@ -220,6 +220,44 @@ def learner_fixtures():
     np.savez_compressed(os.path.join(OUT, 'learner_known_answers.npz'), **flat)
 
 
+def small_grid_fixtures():
+    """envs/small_grid_env.py SmallGridEnv + SmallGridController unmodified over the fake TraCI (greedy agent: the only
+    one the reference can run on this scenario): node order, lanes, action counts, yellow strings, one full
+    greedy episode of observations / rewards."""
+    from deeprl_signal_control_amd.scenario import build_small_grid
+    kw = dict(norm_wave=1.0, norm_wait=1.0, clip_wave=1000.0, clip_wait=1000.0, coop_gamma=0.75)
+    scn = build_small_grid('greedy', **kw)
+    env = fake_traci.ref_env('small_grid', 'greedy', scn=scn)
+    from envs.small_grid_env import SmallGridController
+    ctrl = SmallGridController(env.node_names)
+    env.train_mode = False
+    rec = dict(actions=[], obs=[], reward=[], global_reward=[], done=[])
+    ob = env.reset(test_ind=0)
+    rec['obs'].append(np.concatenate(ob))
+    while True:
+        act = [int(a) for a in ctrl.forward(ob)]
+        ob, r, done, g = env.step(act)
+        rec['actions'].append(act); rec['obs'].append(np.concatenate(ob)); rec['reward'].append(np.asarray(r, np.float64))
+        rec['global_reward'].append(float(g)); rec['done'].append(bool(done))
+        if done:
+            break
+    env.terminate()
+    np.savez_compressed(os.path.join(OUT, 'small_grid_greedy.npz'), **{k: np.array(v) for k, v in rec.items()})
+    static = dict(node_names=env.node_names, n_s_ls=[int(x) for x in env.n_s_ls], n_a_ls=[int(x) for x in env.n_a_ls],
+                  n_w_ls=[int(x) for x in env.n_w_ls], T=float(env.T),
+                  ilds_in={n: list(env.nodes[n].ilds_in) for n in env.node_names},
+                  lanes_in={n: list(env.nodes[n].lanes_in) for n in env.node_names})
+    ys = {}
+    for n in env.node_names:
+        for p in range(env.nodes[n].n_a):
+            for q in range(env.nodes[n].n_a):
+                env.nodes[n].prev_action = p
+                ys['%s:%d->%d' % (n, p, q)] = env._get_node_phase(q, n, 'yellow')
+    static['yellow'] = ys
+    with open(os.path.join(OUT, 'small_grid_static.json'), 'w') as f:
+        json.dump(static, f, indent=1)
+
+
 def eval_fixtures():
     """The recording path of the reference (is_record=True: envs/env.py:409-437 per-second network statistics, :581-588
     control log, :498-515 trip info parsed back from the tripinfo file the fake backend writes like SUMO would) under the
@@ -283,7 +321,8 @@ if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])                 # e.g. `python tools/make_golden.py real_net greedy`
     for name, fn in (('env', env_fixtures), ('real_net', real_net_fixtures), ('greedy', greedy_fixtures),
-                     ('iql', iql_fixtures), ('learner', learner_fixtures), ('eval', eval_fixtures)):
+                     ('iql', iql_fixtures), ('learner', learner_fixtures), ('eval', eval_fixtures),
+                     ('small_grid', small_grid_fixtures)):
         if not only or name in only:
             fn()
     for f in sorted(os.listdir(OUT)):
