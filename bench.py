@@ -139,6 +139,50 @@ def cpu_baseline(n_env=48, n_step=120, threads=8):
             'sim_only_sample': 'oracle/microsim.c alone, 1 instance, 1 core, 3600 simulated seconds, %.2f s' % sim_dt}
 
 
+def extra_lines(env, model, scn, n_ctrl=240):
+    """SURVEY 8d asks for the simulator alone and simulator + policy forward next to the training figure: the same env
+    instances, `n_ctrl` control steps each, actions pre-generated (uniform) for the sim-only line so that nothing but
+    tsc_env_step is on the stream; env-steps/s = agents x instances x simulated seconds / wall time."""
+    E, A, ctrl = env.E, scn.n_agent, scn.control_interval_sec
+    out = {}
+    g = torch.Generator(device='cuda'); g.manual_seed(1)
+    na = torch.as_tensor(np.asarray(scn.n_a_ls), device='cuda')
+    acts = (torch.rand(16, E, A, generator=g, device='cuda') * na).to(torch.int32).contiguous()
+    env.reset(); model.reset()
+    for t in range(20):
+        env.step(acts[t % 16])
+    torch.cuda.synchronize()
+    env.live_vehicle_mean(1)
+    t0 = time.perf_counter()
+    for t in range(n_ctrl):
+        env.step(acts[t % 16])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out['sim_only'] = {'value': A * E * n_ctrl * ctrl / dt, 'unit': 'env-steps/s', 'us_per_control_step': 1e6 * dt / n_ctrl,
+                       'actions': 'uniform random, pre-generated on the device', 'mean_live_vehicles_per_env': env.live_vehicle_mean(n_ctrl)}
+    ob = env.reset(); model.reset()
+    done = True
+    for t in range(20):
+        pi, v, a = model.forward_sample(ob, done, cache=False)
+        if scn.agent == 'ma2c':
+            env.update_fingerprint(pi, zero_copy=True)
+        ob, _, done, _ = env.step(a)
+    torch.cuda.synchronize()
+    env.live_vehicle_mean(1)
+    t0 = time.perf_counter()
+    for t in range(n_ctrl):
+        pi, v, a = model.forward_sample(ob, done, cache=False)
+        if scn.agent == 'ma2c':
+            env.update_fingerprint(pi, zero_copy=True)
+        ob, _, done, _ = env.step(a)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out['sim_forward'] = {'value': A * E * n_ctrl * ctrl / dt, 'unit': 'env-steps/s', 'us_per_control_step': 1e6 * dt / n_ctrl,
+                          'actions': 'sampled from the (random-init) policy: fused forward + sampling, fingerprint push, env step',
+                          'mean_live_vehicles_per_env': env.live_vehicle_mean(n_ctrl)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -150,6 +194,7 @@ def main():
     ap.add_argument('--policy', default='lstm', choices=['lstm', 'fc'], help='fc = FcACPolicy (BASELINE configs[1], ia2c only)')
     ap.add_argument('--batches', type=int, default=1, help='independent half-batches per GPU on separate HIP streams')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra', action='store_true', help='skip the sim-only / sim+forward lines (SURVEY 8d)')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--profile-stride', type=int, default=8,
                     help='HIP-event timing of every n-th launch of the per-control-step kernels (1 = all; the pairs serialise dependent kernels)')
@@ -185,9 +230,9 @@ def main():
     for b in range(B):
         envs.append(VecTrafficEnv(scn, Eb, device=local, seed=seed0 + rank * E + b * Eb, seed_stride=E * world,
                                   test_seeds=tseeds))
+        # same weight-init seed on every rank / half-batch (replicas of one learner), own action stream each
         mdl = VecA2C(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, scn.n_f_ls, Eb, scn.s_max, int(scn.green_tab.shape[1]), mcfg,
-                     device=local, seed=0, name=args.agent, policy=args.policy)
-        mdl.sample_seed = 1000 + rank * B + b
+                     device=local, seed=0, name=args.agent, policy=args.policy, replica=b)
         models.append(mdl)
     env, model = envs[0], models[0]
     tr = VecTrainer(env, model) if B == 1 else MultiBatchTrainer(envs, models)
@@ -200,6 +245,8 @@ def main():
     for _ in range(args.warmup):
         tr.run_iteration()
     sync()
+    for e_ in envs:
+        e_.live_vehicle_mean(1)                       # reset the window accumulators
     live = []
     if not args.no_profile:
         _lib.profile(enable=max(1, args.profile_stride), reset=True)
@@ -210,7 +257,12 @@ def main():
     dt = time.perf_counter() - t0
     prof = {} if args.no_profile else _lib.profile()
     _lib.profile(enable=False)
-    live.append(float(np.mean([e_.mean_live_vehicles() for e_ in envs])))
+    # window mean over the timed region of the vehicles in the network per env instance (SURVEY 8d's V)
+    live.append(float(np.mean([e_.live_vehicle_mean(args.steps * model.n_step) for e_ in envs])))
+    msr = tr.mean_step_reward()
+    extra = {}
+    if rank == 0 and world == 1 and B == 1 and not args.no_extra:
+        extra = extra_lines(env, model, scn)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -230,16 +282,27 @@ def main():
                                          ' (neighbour fingerprint gather)' if args.agent == 'ma2c' else '', E, n_step, ctrl,
                                          'BPTT, ' if args.policy == 'lstm' else '', ', RCCL grad all-reduce' if world > 1 else ''),
                           'envs_per_gpu': E, 'n_step': n_step, 'agents': scn.n_agent,
-                          'parallelism': 'env-sharded x%d%s' % (world, ', %d half-batches on separate streams' % B if B > 1 else ''), 'mean_live_vehicles_per_env': live[-1],
-                          'mean_step_reward': tr.mean_step_reward()}}
+                          'parallelism': 'env-sharded x%d%s' % (world, ', %d half-batches on separate streams' % B if B > 1 else ''),
+                          'mean_live_vehicles_per_env': live[-1], 'live_vehicles': 'window mean over the timed region',
+                          'mean_step_reward': msr}}
         if prof:
             total = sum(ms for ms, _ in prof.values())
             dom = max(prof, key=lambda k: prof[k][0])
             ms, cnt = prof[dom]
             avg_s = ms / cnt * 1e-3
             kern = {k: {'ms_total': round(v[0], 3), 'launches': v[1]} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+            # per-kernel roofline fraction: MFMA kernels against the fp32 MFMA peak, the simulator against HBM
+            fl_all = algorithmic_flops(model, E * n_step)
+            for k, d in kern.items():
+                avg = d['ms_total'] / d['launches'] * 1e-3
+                if k == 'env_step':
+                    d['frac_hbm'] = round((32.0 * live[-1] + 16.0 * scn.n_lane + scn.n_agent * 52.0 / 5.0) * ctrl * E / avg / 1e9 / PEAK_HBM_GBS, 4)
+                elif k == 'policy_fwd_fused':
+                    d['frac_mfma'] = round(algorithmic_flops(model, E)[k] / avg / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+                elif fl_all.get(k, 0.0) > 0 and d['launches'] == args.steps:
+                    d['frac_mfma'] = round(fl_all[k] / avg / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
             if dom == 'env_step':
-                V, Ln, A = live[-1], scn.n_lane, scn.n_agent           # 32 V + 16 L + A*52/5 B per env-sim-step
+                V, Ln, A = live[-1], scn.n_lane, scn.n_agent           # 32 V + 16 L + A*52/5 B per env-sim-step (V = window mean)
                 bytes_launch = (32.0 * V + 16.0 * Ln + A * 52.0 / 5.0) * ctrl * E
                 ach = bytes_launch / avg_s / 1e9
                 roof = {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
@@ -264,6 +327,8 @@ def main():
             roof['kernel_time_ms_total'] = total
             out['roofline'] = roof
             out['kernels'] = kern
+        if extra:
+            out['extra'] = extra
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))

@@ -44,7 +44,7 @@ SYMBOLS = ['tsc_last_error', 'tsc_version', 'tsc_profile_enable', 'tsc_profile_r
            'tsc_model_create', 'tsc_model_destroy', 'tsc_model_set_stream', 'tsc_model_layout',
            'tsc_model_set_params', 'tsc_model_reset_opt_state', 'tsc_model_debug_read', 'tsc_model_get_params', 'tsc_model_get_opt_state', 'tsc_model_set_opt_state',
            'tsc_model_reset', 'tsc_model_forward', 'tsc_model_forward_sample', 'tsc_model_sample', 'tsc_model_add_transition',
-           'tsc_model_compute_grads', 'tsc_model_grad_buffer', 'tsc_model_apply_grads', 'tsc_model_get_returns', 'tsc_model_debug_clock',
+           'tsc_model_rollout_slot', 'tsc_model_compute_grads', 'tsc_model_grad_buffer', 'tsc_model_apply_grads', 'tsc_model_get_returns', 'tsc_model_debug_clock',
            'tsc_gemm_grouped_f32',
            'tsc_iql_create', 'tsc_iql_destroy', 'tsc_iql_set_stream', 'tsc_iql_layout', 'tsc_iql_set_params', 'tsc_iql_get_params',
            'tsc_iql_get_opt_state', 'tsc_iql_set_opt_state', 'tsc_iql_forward', 'tsc_iql_add_transition', 'tsc_iql_replay_size',

@@ -199,6 +199,7 @@ def _setup_lib(L):
     L.tsc_model_sample.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64]
     L.tsc_model_forward_sample.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, C.c_int32]
     L.tsc_model_add_transition.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp]
+    L.tsc_model_rollout_slot.argtypes = [vp, C.c_int32, C.POINTER(vp)]
     L.tsc_model_compute_grads.argtypes = [vp, vp, C.c_double]
     L.tsc_model_grad_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
     L.tsc_model_apply_grads.argtypes = [vp, C.c_double, C.c_double, vp]
@@ -368,6 +369,30 @@ class VecA2C:
         self._grad_t = torch.as_tensor(hold, device=self.device)
         return self._grad_t
 
+    def _view(self, ptr, shape, typestr, dtype):
+        class _Holder:
+            pass
+        hold = _Holder()
+        hold.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': typestr, 'data': (ptr, False), 'version': 3, 'strides': None}
+        t = torch.as_tensor(hold, device=self.device)
+        assert t.dtype == dtype and t.data_ptr() == ptr
+        return t
+
+    def rollout_slots(self):
+        """Zero-copy rollouts (include/tsc.h tsc_model_rollout_slot): torch views of the on-policy buffer itself --
+        obs [T+1,E,A,SMAX] f32, action [T,E,A] i32, value [T,E,A] f32, reward [T,E,A] f64 (raw), done [T+1,E] u8
+        (done[t] = before step t, done[t+1] = after it).  The trainer lets the forward and the env write them in place."""
+        if getattr(self, '_slots', None) is None:
+            p = (C.c_void_p * 6)()
+            _lib.check(self._L.tsc_model_rollout_slot(self._h, 0, p))
+            T, E, A = self.n_step, self.E, self.n_agent
+            self._slots = dict(obs=self._view(p[0], (T + 1, E, A, self.s_max), '<f4', torch.float32),
+                               action=self._view(p[1], (T, E, A), '<i4', torch.int32),
+                               value=self._view(p[2], (T, E, A), '<f4', torch.float32),
+                               reward=self._view(p[3], (T, E, A), '<f8', torch.float64),
+                               done=self._view(p[4], (T + 1, E), '|u1', torch.uint8))
+        return self._slots
+
     # ---- reference API (batched) ------------------------------------------------------------
     def reset(self):
         """agents/models.py:218-220."""
@@ -386,17 +411,24 @@ class VecA2C:
             return self.pi, self.v
         return self.pi if out_type == 'p' else v_out
 
-    def forward_sample(self, obs, done, cache=True):
+    def forward_sample(self, obs, done, cache=True, v_out=None, action_out=None):
         """forward(obs, done, 'pv') + sample() in one launch -> (pi, v, action).  cache=True keeps this step's
-        activations (slot = the transition add_transition fills next) so backward() skips the re-forward."""
+        activations (slot = the transition add_transition fills next) so backward() skips the re-forward.
+        v_out / action_out: write the value and the action somewhere else (the rollout slot, rollout_slots())."""
         if not torch.is_tensor(done):
             done = torch.full((self.E,), int(bool(done)), dtype=torch.uint8, device=self.device)
+        v = self.v if v_out is None else v_out
+        act = self.action if action_out is None else action_out
         _lib.check(self._L.tsc_model_forward_sample(
             self._h, C.c_void_p(obs.data_ptr()), C.c_void_p(done.data_ptr()), C.c_void_p(self.pi.data_ptr()),
-            C.c_void_p(self.v.data_ptr()), C.c_void_p(self.action.data_ptr()), self.sample_seed, self.sample_step,
+            C.c_void_p(v.data_ptr()), C.c_void_p(act.data_ptr()), self.sample_seed, self.sample_step,
             self.cur_t if cache else -1))
         self.sample_step += 1
-        return self.pi, self.v, self.action
+        return self.pi, v, act
+
+    def commit_transition(self):
+        """The transition of slot cur_t was written in place (rollout_slots): only the slot counter moves."""
+        self.cur_t += 1
 
     def sample(self, pi=None):
         """np.random.choice per agent (utils.py:155-157), counter-based RNG."""

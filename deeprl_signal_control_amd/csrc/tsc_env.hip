@@ -245,7 +245,7 @@ __global__ void reset_kernel(EnvDev P, const uint32_t *seeds, float *obs) {
         float p = (float)(1.0 / (double)na);                       // envs/env.py:263-269
         for (int k = 0; k < P.PMAX; ++k) P.fp[((size_t)e * P.A + a) * P.PMAX + k] = k < na - 1 ? p : 0.0f;
     }
-    if (l == 0) { P.tsec[e] = 0; P.seed[e] = seeds[e]; P.arrived[e] = 0ull; P.n_trips[e] = 0; P.live_acc[e] = 0ull; }
+    if (l == 0) { P.tsec[e] = 0; P.seed[e] = seeds[e]; P.arrived[e] = 0ull; P.n_trips[e] = 0; }
     __syncthreads();
     emit_obs(P, s, e, obs);
 }

@@ -949,15 +949,20 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
 
 // n-step returns and advantages (agents/utils.py:202-228): float64 recursion from the back with
 // POST-step dones, Adv = R - v, cast to float32.   rew f64 [T][E][A], val f32, done_all u8 [T+1][E]
+// The buffer holds the env's RAW rewards (so that the env can write them in place, tsc_model_rollout_slot); the
+// reward / reward_norm and clip of IA2C.add_transition (agents/models.py:223-226) are applied here, same float64 operations.
 __global__ void returns_kernel(const double *rew, const float *val, const uint8_t *done_all, const float *Rboot,
-                               int T, int E, int A, double gamma, float *Rs, float *Advs) {
+                               int T, int E, int A, double gamma, double rnorm, double rclip, float *Rs, float *Advs) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= E * A) return;
     const int e = idx / A;
     double R = (double)Rboot[idx];
     for (int t = T - 1; t >= 0; --t) {
         const double d = (double)done_all[(long long)(t + 1) * E + e];
-        R = rew[(long long)t * E * A + idx] + gamma * R * (1.0 - d);
+        double r = rew[(long long)t * E * A + idx];
+        if (rnorm != 0.0) r = r / rnorm;                         // agents/models.py:223-224
+        if (rclip != 0.0) r = fmin(fmax(r, -rclip), rclip);      // :225-226
+        R = r + gamma * R * (1.0 - d);
         const double adv = R - (double)val[(long long)t * E * A + idx];
         Rs[(long long)t * E * A + idx] = (float)R;
         Advs[(long long)t * E * A + idx] = (float)adv;
@@ -966,18 +971,21 @@ __global__ void returns_kernel(const double *rew, const float *val, const uint8_
 
 __global__ void add_transition_kernel(int E, int A, int SMAX, const float *obs, const uint8_t *done_pre,
                                       const int *action, const double *reward, const float *value,
-                                      const uint8_t *done_post, double rnorm, double rclip, float *obs_t,
+                                      const uint8_t *done_post, float *obs_t,
                                       int *act_t, double *rew_t, float *val_t, uint8_t *done_t, uint8_t *done_t1) {
+    // every source may already BE the slot (tsc_model_rollout_slot): then there is nothing to copy
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long no = (long long)E * A * SMAX;
-    if (i < no) obs_t[i] = obs[i];
+    if (i < no && obs_t != obs) obs_t[i] = obs[i];
     if (i < (long long)E * A) {
-        double r = reward[i];
-        if (rnorm != 0.0) r = r / rnorm;                         // agents/models.py:223-224
-        if (rclip != 0.0) r = fmin(fmax(r, -rclip), rclip);      // :225-226
-        rew_t[i] = r; act_t[i] = action[i]; val_t[i] = value[i];
+        if (rew_t != reward) rew_t[i] = reward[i];               // raw: normalised / clipped by returns_kernel
+        if (act_t != action) act_t[i] = action[i];
+        if (val_t != value) val_t[i] = value[i];
     }
-    if (i < E) { done_t[i] = done_pre[i]; done_t1[i] = done_post[i]; }
+    if (i < E) {
+        if (done_t != done_pre) done_t[i] = done_pre[i];
+        if (done_t1 != done_post) done_t1[i] = done_post[i];
+    }
 }
 
 __global__ void sample_kernel(const float *pi, const int *n_act, int E, int A, int AMAX, unsigned long long seed,
@@ -990,19 +998,29 @@ __global__ void sample_kernel(const float *pi, const int *n_act, int E, int A, i
 }
 
 // per-agent global norm (tf.clip_by_global_norm over both towers, agents/policies.py:54-57)
-__global__ void grad_norm_kernel(const float *grad, long long per_agent, double gscale, double *norm2) {
+// kNormParts workgroups per agent, each a fixed slice; partial sums folded in slice order (deterministic)
+constexpr int kNormParts = 16;
+__global__ void grad_norm_kernel(const float *grad, long long per_agent, double gscale, double *part) {
     __shared__ double red[256];
-    const int a = blockIdx.x;
+    const int a = blockIdx.x, c = blockIdx.y;
+    const long long len = (per_agent + kNormParts - 1) / kNormParts, lo = c * len, hi = lo + len < per_agent ? lo + len : per_agent;
     const float *gp = grad + (long long)a * per_agent;
     double s = 0.0;
-    for (long long i = threadIdx.x; i < per_agent; i += 256) { const double v = (double)gp[i] * gscale; s += v * v; }
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) { const double v = (double)gp[i] * gscale; s += v * v; }
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) norm2[a] = red[0];
+    if (threadIdx.x == 0) part[a * kNormParts + c] = red[0];
+}
+__global__ void grad_norm_fold_kernel(const double *part, int A, double *norm2) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= A) return;
+    double s = 0.0;
+    for (int c = 0; c < kNormParts; ++c) s += part[a * kNormParts + c];
+    norm2[a] = s;
 }
 
 // TF1 RMSPropOptimizer (momentum 0, not centred): ms = a ms + (1-a) g^2 ; w -= lr g / sqrt(ms + eps)
@@ -1370,7 +1388,7 @@ struct tsc_model {
     float *Rs, *Advs;
     // activations
     float *X1, *Z, *Hh, *Cc, *Hp, *dHh, *dL;
-    double *norm2, *stats;
+    double *norm2, *stats, *norm_part;
     float *ws, *wsc;            // split-K workspace
     size_t ws_floats, wsc_floats;
     size_t lds_fwd, lds_bwd, lds_fused, lds_ws;
@@ -1466,13 +1484,14 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     m->wg_dirty = 1;
     MALLOC(m->state_fw, float, G * E * 2 * kL); MALLOC(m->state_bw, float, G * E * 2 * kL);
     MALLOC(m->state_tmp, float, G * E * 2 * kL);
-    MALLOC(m->r_obs, float, N * A * L.SMAX); MALLOC(m->r_act, int, N * A); MALLOC(m->r_rew, double, N * A);
+    MALLOC(m->r_obs, float, (N + E) * A * L.SMAX);          // T + 1 slots: slot t + 1 receives the obs the env returns at step t
+    MALLOC(m->r_act, int, N * A); MALLOC(m->r_rew, double, N * A);
     MALLOC(m->r_val, float, N * A); MALLOC(m->r_done, uint8_t, (T + 1) * E);
     MALLOC(m->Rs, float, N * A); MALLOC(m->Advs, float, N * A);
     MALLOC(m->X1, float, G * N * L.H); MALLOC(m->Z, float, G * N * kG4);
     MALLOC(m->Hh, float, G * N * kL); MALLOC(m->Cc, float, G * N * kL); MALLOC(m->Hp, float, G * N * kL);
     MALLOC(m->dHh, float, G * N * kL); MALLOC(m->dL, float, G * N * kOut);
-    MALLOC(m->norm2, double, A); MALLOC(m->stats, double, A * 4);
+    MALLOC(m->norm2, double, A); MALLOC(m->stats, double, A * 4); MALLOC(m->norm_part, double, A * kNormParts);
     m->ws_floats = (size_t)48 << 20; m->wsc_floats = (size_t)1 << 20;      // 192 MiB + 4 MiB
     MALLOC(m->ws, float, m->ws_floats); MALLOC(m->wsc, float, m->wsc_floats);
     m->lds_fwd = sizeof(float) * (64 * kWhLd + 64 * kHsLd);
@@ -1666,11 +1685,25 @@ int tsc_model_add_transition(tsc_model *m, int32_t t, const float *obs, const ui
     const long long E = m->E, A = L.A, no = E * A * L.SMAX;
     tsc::ProfScope ps5(tsc::KID_ADD_TRANS, m->stream);
     hipLaunchKernelGGL(add_transition_kernel, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, m->stream, (int)E, (int)A,
-                       L.SMAX, obs, done_pre, action, reward, value, done_post, m->rnorm, m->rclip, m->r_obs + t * no,
+                       L.SMAX, obs, done_pre, action, reward, value, done_post, m->r_obs + t * no,
                        m->r_act + t * E * A, m->r_rew + t * E * A, m->r_val + t * E * A, m->r_done + t * E,
                        m->r_done + (t + 1) * E);
     ps5.stop();
     TSC_HIP(hipGetLastError());
+    return 0;
+}
+
+int tsc_model_rollout_slot(tsc_model *m, int32_t t, void *ptrs[6]) {
+    if (!m || !ptrs || t < 0 || t > m->T) return tsc::fail("tsc_model_rollout_slot: slot %d outside [0,%d]", t, m ? m->T : 0);
+    const Layout &L = m->lay;
+    const long long E = m->E, A = L.A, no = E * A * L.SMAX;
+    const bool in = t < m->T;
+    ptrs[0] = m->r_obs + t * no;                            // obs        f32 [E,A,SMAX]   (slot T: only the obs exists)
+    ptrs[1] = in ? (void *)(m->r_act + t * E * A) : nullptr;   // action     i32 [E,A]
+    ptrs[2] = in ? (void *)(m->r_val + t * E * A) : nullptr;   // value      f32 [E,A]
+    ptrs[3] = in ? (void *)(m->r_rew + t * E * A) : nullptr;   // reward     f64 [E,A]  (raw)
+    ptrs[4] = m->r_done + t * E;                            // done before the step  u8 [E]
+    ptrs[5] = in ? (void *)(m->r_done + (t + 1) * E) : nullptr;  // done after the step   u8 [E]
     return 0;
 }
 
@@ -1683,7 +1716,7 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
     TSC_HIP(hipMemsetAsync(m->stats, 0, sizeof(double) * A * 4, st));
     tsc::ProfScope ps6(tsc::KID_RETURNS, m->stream);
     hipLaunchKernelGGL(returns_kernel, dim3((unsigned)((E * A + 255) / 256)), dim3(256), 0, st, m->r_rew, m->r_val, m->r_done,
-                       R_boot, (int)T, (int)E, (int)A, m->gamma, m->Rs, m->Advs);
+                       R_boot, (int)T, (int)E, (int)A, m->gamma, m->rnorm, m->rclip, m->Rs, m->Advs);
     ps6.stop();
     float *g = m->grads;
     if (L.fc) {
@@ -1798,7 +1831,8 @@ int tsc_model_apply_grads(tsc_model *m, double lr, double grad_scale, double *st
     const long long per_agent = 2 * L.stride;
     hipStream_t st = m->stream;
     tsc::ProfScope ps10(tsc::KID_GRADNORM, m->stream);
-    hipLaunchKernelGGL(grad_norm_kernel, dim3(L.A), dim3(256), 0, st, m->grads, per_agent, grad_scale, m->norm2);
+    hipLaunchKernelGGL(grad_norm_kernel, dim3(L.A, kNormParts), dim3(256), 0, st, m->grads, per_agent, grad_scale, m->norm_part);
+    hipLaunchKernelGGL(grad_norm_fold_kernel, dim3((L.A + 63) / 64), dim3(64), 0, st, m->norm_part, L.A, m->norm2);
     ps10.stop();
     tsc::ProfScope ps11(tsc::KID_RMSPROP, m->stream);
     hipLaunchKernelGGL(rmsprop_kernel, dim3((unsigned)((m->nparam + 255) / 256)), dim3(256), 0, st, m->params, m->ms, m->grads,
@@ -1810,6 +1844,9 @@ int tsc_model_apply_grads(tsc_model *m, double lr, double grad_scale, double *st
     // states_bw <- states_fw (policies.py:153); buffer.reset(dones[-1]) (utils.py:227)
     TSC_HIP(hipMemcpyAsync(m->state_bw, m->state_fw, sizeof(float) * (size_t)L.G * m->E * 2 * kL, hipMemcpyDeviceToDevice, st));
     TSC_HIP(hipMemcpyAsync(m->r_done, m->r_done + (size_t)m->T * m->E, m->E, hipMemcpyDeviceToDevice, st));
+    // zero-copy rollouts: the observation the env wrote into slot T is the first observation of the next rollout
+    TSC_HIP(hipMemcpyAsync(m->r_obs, m->r_obs + (size_t)m->T * m->E * L.A * L.SMAX, sizeof(float) * (size_t)m->E * L.A * L.SMAX,
+                           hipMemcpyDeviceToDevice, st));
     if (stats_host) {
         std::vector<double> s(L.A * 4), n2(L.A);
         TSC_HIP(hipStreamSynchronize(st));

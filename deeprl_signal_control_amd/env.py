@@ -156,8 +156,9 @@ class VecTrafficEnv:
         return v.value / max(1, steps * self.E)
 
     # -- reference API, batched ------------------------------------------------------------
-    def reset(self, test_ind=0):
-        """envs/env.py:544-561 -> obs float32 [E, A, SMAX]."""
+    def reset(self, test_ind=0, obs_out=None):
+        """envs/env.py:544-561 -> obs float32 [E, A, SMAX] (written to obs_out if given)."""
+        self.obs = self._obs2[self._flip] if obs_out is None else obs_out
         if self.train_mode:
             seeds = self.seeds.copy()
             self.seeds += self.seed_stride                      # `self.seed += 1`, env.py:560
@@ -187,21 +188,24 @@ class VecTrafficEnv:
         _lib.check(self._L.tsc_env_reward_sum(self._h, C.byref(v), int(reset)))
         return v.value
 
-    def step(self, action):
+    def step(self, action, obs_out=None, reward_out=None, done_out=None):
         """envs/env.py:566-631; action int32 [E, A] on the device.  Returns the env's own
         output buffers (obs f32 [E,A,SMAX], reward f64 [E,A], done u8 [E], global f64 [E]);
-        obs / done alternate between two buffers, reward / global are overwritten by the next call."""
+        obs / done alternate between two buffers, reward / global are overwritten by the next call.
+        obs_out / reward_out / done_out: write there instead (e.g. the learner's rollout slots, zero copy)."""
         assert action.dtype == torch.int32 and action.is_contiguous() and tuple(action.shape) == (self.E, self.A)
         self._flip ^= 1
-        self.obs, self.done = self._obs2[self._flip], self._done2[self._flip]
+        self.obs = self._obs2[self._flip] if obs_out is None else obs_out
+        self.done = self._done2[self._flip] if done_out is None else done_out
+        reward = self.reward if reward_out is None else reward_out
         _lib.check(self._L.tsc_env_step(self._h, C.c_void_p(action.data_ptr()), C.c_void_p(self.obs.data_ptr()),
-                                        C.c_void_p(self.reward.data_ptr()),
+                                        C.c_void_p(reward.data_ptr()),
                                         C.c_void_p(self.global_reward.data_ptr()),
                                         C.c_void_p(self.done.data_ptr()), int(self.train_mode)))
         self.cur_sec += self.scn.control_interval_sec
         if getattr(self, 'is_record', False):
             self._record_step(action)
-        return self.obs, self.reward, self.done, self.global_reward
+        return self.obs, reward, self.done, self.global_reward
 
     # -- debug / parity ---------------------------------------------------------------------
     def get_state(self, e=0):

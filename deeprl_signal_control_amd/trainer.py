@@ -46,10 +46,17 @@ class VecTrainer:
         self.done = True
         self.episode_step = 0
         self.zero_R = torch.zeros(env.E, env.A, dtype=torch.float32, device=env.device)
+        # zero-copy rollouts: forward and env write the transition straight into the learner's on-policy buffer
+        self.slots = model.rollout_slots() if (self.agent.endswith('a2c') and hasattr(model, 'rollout_slots')) else None
 
     def start_episode(self):
         """utils.py:277-283: env.reset(); done = True (pre-decision, resets LSTM state); model.reset()."""
-        self.ob = self.env.reset()
+        if self.slots is not None:
+            self.ob = self.env.reset(obs_out=self.slots['obs'][0])
+            self.slots['done'][0].fill_(1)                        # pre-decision done of the first step
+            self.model.cur_t = 0
+        else:
+            self.ob = self.env.reset()
         self.done = True
         self.model.reset()
         self.episode_step = 0
@@ -74,10 +81,38 @@ class VecTrainer:
         self.ob, self.done = ob, done_post
         return finished, None
 
+    def _explore_slots(self):
+        """explore() with the transition written in place: slot t of the on-policy buffer receives the action and value
+        (by the fused forward), the raw reward and the post-step done (by the env), slot t + 1 the next observation -- no
+        add_transition copy (agents/models.py:222-229 reduces to the reward normalisation, done when the returns are taken)."""
+        env, model, sl = self.env, self.model, self.slots
+        finished = False
+        assert model.cur_t == 0
+        for t in range(self.n_step):
+            pi, v, action = model.forward_sample(sl['obs'][t], sl['done'][t], v_out=sl['value'][t], action_out=sl['action'][t])
+            if self.agent == 'ma2c':
+                env.update_fingerprint(pi, zero_copy=True)
+            _, _, _, global_reward = env.step(action, obs_out=sl['obs'][t + 1], reward_out=sl['reward'][t], done_out=sl['done'][t + 1])
+            if self.log_rewards:
+                self._ep_rewards.append(global_reward.clone())
+            self.global_counter.next()
+            self.episode_step += 1
+            model.commit_transition()
+            finished = env.cur_sec >= env.scn.episode_length_sec
+            if finished:
+                break
+        assert model.cur_t == self.n_step, 'episodes end on a rollout boundary (T %% n_step == 0, utils.py:121)'
+        self.ob, self.done = sl['obs'][self.n_step], sl['done'][self.n_step]
+        R = self.zero_R if finished else model.forward(self.ob, False, 'v')
+        # after backward() the library copies slot n_step -> slot 0 (obs) and done[n_step] -> done[0]
+        return finished, R
+
     def explore(self):
         """utils.py:142-193.  Returns (episode_finished, R) with R the bootstrap values."""
         if not self.agent.endswith('a2c'):
             return self._explore_q()
+        if self.slots is not None:
+            return self._explore_slots()
         env, model = self.env, self.model
         ob, done = self.ob, self.done
         finished = False

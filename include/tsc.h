@@ -132,8 +132,9 @@ int tsc_env_debug_clock(tsc_env *h, int32_t enable, int64_t *stamps64_host);
 
 /* Mean number of live vehicles per env (roofline bookkeeping). Synchronises. */
 int tsc_env_live_vehicles(tsc_env *h, double *mean_live);
-/* Sum over instances and control steps since the last reset of the accumulator (or tsc_env_reset) of the vehicles in
- * the network at the end of the step: window-mean V = sum / (steps * E)  (SURVEY.md 8d). Synchronises. */
+/* sum over instances and control steps since the last reset of the accumulator of the vehicles in
+ * the network at the end of the step: window-mean V = sum / (steps * E)  (SURVEY.md 8d); reset() does not clear it.
+ * Synchronises. */
 int tsc_env_live_sum(tsc_env *h, double *sum_host, int32_t reset);
 
 /* Evaluation recording = init_data(is_record=True) (envs/env.py:517-528): the following steps also keep, per simulated
@@ -209,6 +210,13 @@ int tsc_model_sample(tsc_model *m, const float *pi_dev, int32_t *action_dev, uin
 int tsc_model_add_transition(tsc_model *m, int32_t t, const float *obs_dev, const uint8_t *done_pre_dev,
                              const int32_t *action_dev, const double *reward_dev, const float *value_dev,
                              const uint8_t *done_post_dev);
+
+/* Zero-copy rollouts: device pointers of transition slot t of the on-policy buffer, ptrs[6] = {obs f32 [E,A,SMAX],
+ * action i32 [E,A], value f32 [E,A], reward f64 [E,A] (raw; normalised / clipped when the returns are computed), done before
+ * the step u8 [E], done after the step u8 [E]}.  A caller that lets tsc_model_forward_sample write action / value and
+ * tsc_env_step write reward / done / the next observation (slot t + 1; slot n_step exists for that, and is copied to slot
+ * 0 by tsc_model_apply_grads) straight into the slots has nothing left for tsc_model_add_transition to do. */
+int tsc_model_rollout_slot(tsc_model *m, int32_t t, void *ptrs[6]);
 
 /* IA2C.backward part 1 (agents/models.py:174-183 -> utils.py:202-228 -> policies.py:41-57,138-152):
  * n-step returns/advantages (float64, bootstrap R_boot dev f32 [E,A], ignored where the last
