@@ -63,7 +63,6 @@ struct EnvDev {
     int ctrl, yellow, episode, teleport, queue_cap, objective, agent_kind, realnet_scale;
     double coop_gamma, norm_wave, norm_wait, clip_wave, clip_wait, coef_wait;
     float *X, *V, *SF;
-    float *C;                      // [E][kCap][NLP] scratch of step_kernel's phase A1 (same indexing as X)
     uint32_t *M;                   // w | route << 16
     int *N;                        // [E][NLP]
     int *pending, *serial;         // [E][NR]
@@ -149,6 +148,8 @@ struct Smem {
     int *pend, *ser; uint8_t *emit;             // per-route insertion state [NR], emissions [NR*8]
     uint8_t *zip;                               // [NU*NR]
     int *pre, *wtot;                            // wave-local inclusive scan of queued vehicles [NLA], wave totals [16]
+    int *nc; float *seed;                       // per lane: vehicles ahead of the first one that stays; its chain key [NLA]
+    float *wtail, *hz;                          // wave tails of the chain scan [2][16]; old (x, v) across super-rounds [2]
     uint32_t *or0, *or1;                        // outbox of the trip records [kMaxCross*NLA]      (recording only)
     int *rq; double *rsp; long long *rint;      // per-lane halting [NLA], speed partial sums [NLA], counters [4]  (recording only)
 };
@@ -170,6 +171,7 @@ __host__ __device__ __forceinline__ void smem_layout(Smem &s, const EnvDev &P, T
     s.pend = (int *)take(4 * P.NR); s.ser = (int *)take(4 * P.NR); s.emit = (uint8_t *)take(8 * P.NR);
     s.zip = (uint8_t *)take((P.NU * P.NR + 3) / 4 * 4);
     s.pre = (int *)take(4 * P.NLA); s.wtot = (int *)take(4 * 16);
+    s.nc = (int *)take(4 * P.NLA); s.seed = (float *)take(4 * P.NLA); s.wtail = (float *)take(4 * 32); s.hz = (float *)take(4 * 4);
     if (P.rec) {
         s.or0 = (uint32_t *)take(4 * kMaxCross * P.NLA); s.or1 = (uint32_t *)take(4 * kMaxCross * P.NLA);
         s.rq = (int *)take(4 * P.NLA); s.rsp = (double *)take(8 * P.NLA); s.rint = (long long *)take(8 * 4);
@@ -286,7 +288,6 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     if (P.dbg && threadIdx.x == 0) P.dbg[64 + 2 * blockIdx.x] = wall_clock64();
     float *X = P.X + (size_t)e * kCap * NLP, *V = P.V + (size_t)e * kCap * NLP, *SF = P.SF + (size_t)e * kCap * NLP;
     uint32_t *M = P.M + (size_t)e * kCap * NLP;
-    float *C = P.C + (size_t)e * kCap * NLP;   // phase A1 -> A2: new speed of a queued vehicle that cannot cross
     static_assert(!(HELP && REC), "recording uses the plain walk");
     uint32_t *R0 = REC ? P.R0 + (size_t)e * kCap * NLP : nullptr, *R1 = REC ? P.R1 + (size_t)e * kCap * NLP : nullptr;
     const float origin = REC && lane ? P.lane_origin[l] : 0.0f;
@@ -388,62 +389,13 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     for (int sub = 0; sub < P.ctrl; ++sub, ++t) {
         const uint8_t *link = sub < P.yellow ? s.link_y : s.link_g;
         const bool last = sub == P.ctrl - 1;
-        // ================= phase A1: car-following of the queued vehicles, one per thread =================
-        if constexpr (HELP) {
-            const int nseg = NLA >> 6;
-            int total = 0;
-            for (int w = 0; w < nseg; ++w) total += s.wtot[w];
-            // kA1 vehicles per thread and round: all locates and loads are issued before the first evaluation
-            // (consecutive k = consecutive slots of one lane: the loads are strided, ~64 lines per instruction,
-            // which still costs far less than the latency of doing them one vehicle at a time)
-            constexpr int kA1 = 4;
-            for (int k0 = l; k0 < total; k0 += kA1 * (int)blockDim.x) {
-                int ql[kA1], qo[kA1];
-                float x[kA1], v[kA1], sf[kA1], px[kA1], pv[kA1];
-                uint32_t m[kA1];
-#pragma unroll
-                for (int u = 0; u < kA1; ++u) {
-                    const int k = k0 + u * (int)blockDim.x;
-                    int w = 0, kk = k < total ? k : total - 1;    // clamped: locate and load unconditionally
-                    for (; w < nseg - 1; ++w) {
-                        const int c = s.wtot[w];
-                        if (kk < c) break;
-                        kk -= c;
-                    }
-                    const int *pre = s.pre + (w << 6);
-                    int lo = 0;                                   // smallest j with pre[j] > kk
-#pragma unroll
-                    for (int st = 32; st; st >>= 1) if (pre[lo + st - 1] <= kk) lo += st;
-                    const int q = (w << 6) + lo;
-                    const int i = kk - (lo ? pre[lo - 1] : 0) + 1;
-                    const unsigned ob = (unsigned)(i * NLP + q) * 4u, pb = ob - (unsigned)NLP * 4u;
-                    qo[u] = (int)ob;
-                    x[u] = ldg(X, ob); v[u] = ldg(V, ob); sf[u] = ldg(SF, ob); m[u] = ldg(M, ob);
-                    px[u] = ldg(X, pb); pv[u] = ldg(V, pb);
-                    ql[u] = k < total ? q : -1;
-                }
-#pragma unroll
-                for (int u = 0; u < kA1; ++u) {
-                    if (ql[u] < 0) continue;
-                    const int q = ql[u];
-                    const float Lq = s.len[q];
-                    const int mvp = s.mv[q * NR + (int)(m[u] >> 16)];
-                    const float v0 = s.vmax[q] * sf[u];
-                    const bool open = sig_open(mv_tl(mvp), mv_k(mvp), s.node[q], (int)(m[u] & 0xFFFFu), x[u], v[u], Lq, link, P.KMAX, P.teleport);
-                    float vn = follow(v[u], v0, true, (px[u] - kLen) - x[u], pv[u], kS0);
-                    if (!open) {
-                        const float v2 = follow(v[u], v0, true, Lq - x[u], 0.0f, 0.0f);
-                        if (v2 < vn) vn = v2;
-                    }
-                    stg(C, (unsigned)qo[u], vn);
-                }
-            }
-            TSC_STAMP();
-            __syncthreads();
-            TSC_STAMP();
-        }
-        // ================= phase A2 (K2): advance own vehicles from the OLD state =================
+        // ================= phase H (K2): the platoon that crosses in this second and the first vehicle that stays,
+        // from the OLD state (without HELP: the whole lane, sequentially) =================
         int kept = 0, nsent = 0;
+        bool has_first = false;                        // HELP: the first stayer is written in phase B (its old slot is
+        float fxn = 0.0f, fvn = 0.0f, fsf = 0.0f;      // still read by the flat phase)
+        uint32_t fmeta = 0u;
+        int i0 = 0;
         // recording: this lane's share of the per-second network statistics (envs/env.py:409-437)
         int rq_halt = 0, rq_wait = 0, rq_arr = 0, rq_dep = 0;
         double rq_speed = 0.0;
@@ -458,6 +410,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             int ncross = 0;
             bool all_crossed = true;
             float pnx = INFINITY, pox = 0.0f, pov = 0.0f;
+            float K = INFINITY;                            // plain walk: running min of the chain keys (DESIGN.md rule 4)
             // a vehicle that stays on the lane: compact it to slot `kept`, refresh the summary, count detectors
             auto keep = [&](float xn, float vn, float sf, uint32_t nmeta, uint32_t r0 = 0u, uint32_t r1 = 0u) {
                 const unsigned ob = (unsigned)(kept * NLP + l) * 4u;
@@ -531,19 +484,33 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     if (v2 < vn) vn = v2;
                 }
                 float xn = x + vn;
-                bool clamped = false;
-                if (xn > pnx - kLen) { xn = pnx - kLen; clamped = true; }
-                if (tgt_lead) {
-                    const float lim = L + (s.tx[tl] - kLen);
-                    if (xn > lim) { xn = lim; clamped = true; }
+                if (!HELP && !all_crossed) {
+                    // behind the first vehicle that stays: x' = min(x + v', L, K - 5 i), K = exclusive prefix-min of the
+                    // keys a_j + 5 j (the closed form of x'_i = min(a_i, x'_{i-1} - 5); the flat phase scans it)
+                    const float xf = xn;
+                    float a = xf;
+                    if (a > L) a = L;
+                    const float lim = K - (float)(5 * i);
+                    xn = a < lim ? a : lim;
+                    if (xn < x) xn = x;
+                    if (xn != xf) vn = xn - x;
+                    const float key = a + (float)(5 * i);
+                    if (key < K) K = key;
+                } else {
+                    bool clamped = false;
+                    if (xn > pnx - kLen) { xn = pnx - kLen; clamped = true; }
+                    if (tgt_lead) {
+                        const float lim = L + (s.tx[tl] - kLen);
+                        if (xn > lim) { xn = lim; clamped = true; }
+                    }
+                    if (can_cross && !sink) {                          // target lane shorter than one step's travel
+                        const float far = L + s.len[tl];
+                        if (xn > far) { xn = far; clamped = true; }
+                    }
+                    if (!can_cross && xn > L) { xn = L; clamped = true; }
+                    if (xn < x) { xn = x; clamped = true; }
+                    if (clamped) vn = xn - x;
                 }
-                if (can_cross && !sink) {                          // target lane shorter than one step's travel
-                    const float far = L + s.len[tl];
-                    if (xn > far) { xn = far; clamped = true; }
-                }
-                if (!can_cross && xn > L) { xn = L; clamped = true; }
-                if (xn < x) { xn = x; clamped = true; }
-                if (clamped) vn = xn - x;
                 uint32_t r1n = cur.r1;
                 if constexpr (REC) {                   // tripinfo waitingTime / waitingCount
                     if (vn < kHalt) r1n = (r1n + 1u) + (w == 0 ? 0x10000u : 0u);
@@ -572,63 +539,154 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     }
                     ++ncross;
                 } else {
+                    if (all_crossed) K = xn + (float)(5 * i);      // the first vehicle that stays seeds the chain
                     all_crossed = false;
-                    keep(xn, vn, sf, nmeta, cur.r0, r1n);
+                    if constexpr (HELP) {
+                        has_first = true; i0 = i; fxn = xn; fvn = vn; fsf = sf; fmeta = nmeta;
+                        if (last && xn >= det) { ++d_wave; if (vn < kHalt) ++d_halt; }
+                    } else {
+                        keep(xn, vn, sf, nmeta, cur.r0, r1n);
+                    }
                 }
                 cur = nxt;
             }
-            // ---- tail walk (HELP): the new speed comes from phase A1; only the clamps and the bookkeeping are
-            // sequential (~50 instructions per vehicle).  The state is fetched in chunks of four vehicles, one chunk
-            // ahead (a register ring rotated every vehicle makes each iteration wait for the youngest load), and
-            // every memory operation in the loop is unconditional so that the compiler can wait with vmcnt(N > 0).
             if constexpr (HELP) {
-                struct Lite { float x, sf, c; uint32_t m; };
-                const unsigned rowb = (unsigned)NLP * 4u, lb = (unsigned)l * 4u;
-                auto load_lite = [&](int j) {
-                    const unsigned ob = (unsigned)(j < kCap ? j : kCap - 1) * rowb + lb;
-                    Lite r; r.x = ldg(X, ob); r.sf = ldg(SF, ob); r.c = ldg(C, ob); r.m = ldg(M, ob);
-                    return r;
-                };
-                unsigned sb = (unsigned)kept * rowb + lb;             // byte offset of slot `kept`
-                auto step = [&](const Lite &c) {
-                    const float x = c.x;
-                    float vn = c.c, xn = x + vn;
-                    bool clamped = false;
-                    if (xn > pnx - kLen) { xn = pnx - kLen; clamped = true; }
-                    if (xn > L) { xn = L; clamped = true; }
-                    if (xn < x) { xn = x; clamped = true; }
-                    if (clamped) vn = xn - x;
-                    const uint32_t w = (vn < kHalt) ? (c.m & 0xFFFFu) + 1u : 0u;
-                    const uint32_t nmeta = w | (c.m & 0xFFFF0000u);
-                    pnx = xn;
-                    stg(X, sb, xn); stg(V, sb, vn); stg(SF, sb, c.sf); stg(M, sb, nmeta);
-                    sb += rowb;
-                    if (kept == 0) { hx = xn; hv = vn; hm = nmeta; }
-                    tx = xn; tv = vn;
-                    ++kept;
-                    if (last && xn >= det) { ++d_wave; if (vn < kHalt) ++d_halt; }
-                };
-                Lite c0 = load_lite(i), c1 = load_lite(i + 1), c2 = load_lite(i + 2), c3 = load_lite(i + 3);
-                for (; i + 4 <= n; i += 4) {
-                    const Lite n0 = load_lite(i + 4), n1 = load_lite(i + 5), n2 = load_lite(i + 6), n3 = load_lite(i + 7);
-                    step(c0); step(c1); step(c2); step(c3);
-                    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-                }
-                if (i < n) {
-                    step(c0);
-                    if (i + 1 < n) {
-                        step(c1);
-                        if (i + 2 < n) step(c2);
-                    }
-                }
+                if (!has_first) i0 = n;                            // everybody crossed
+                s.nc[l] = i0;
+                s.seed[l] = has_first ? fxn + (float)(5 * i0) : INFINITY;
             }
             s.nout[l] = nsent;
         }
         TSC_STAMP();
         __syncthreads();
         TSC_STAMP();
+        // ================= phase F (K2, HELP): every vehicle behind the first stayer, one per thread slot =============
+        // Nobody behind a vehicle that stays can cross, so such a vehicle's new speed depends only on OLD state (itself, the
+        // vehicle ahead, the signal) and its new position on the chain clamp x'_i = min(a_i, x'_{i-1} - 5), a_i = min(x_i +
+        // v'_i, L).  The clamp is an exclusive prefix-min over the keys a_j + 5 j within a lane (DESIGN.md rule 4): all
+        // queued vehicles of the instance are laid out flat over the workgroup (prefix sum of the lane counts + binary
+        // search), kF consecutive ones per thread, and the chain is a segmented min-scan -- in the thread, then over
+        // the wavefront by shuffles, then across wavefronts through one LDS word per wave (a lane's <= 27 queued
+        // vehicles touch at most two wavefronts).  Replaces the A1 scratch round trip through HBM and the 28-deep
+        // sequential lane walk of round 1.
+        if constexpr (HELP) {
+            const int nseg = NLA >> 6;
+            int total = 0;
+            for (int w = 0; w < nseg; ++w) total += s.wtot[w];
+            constexpr int kF = 4;
+            const int wv = l >> 6, wl = l & 63, nwv = (int)blockDim.x >> 6;
+            int round = 0;
+            for (int base = 0; base < total; base += kF * (int)blockDim.x, ++round) {
+                const float carry_round = round > 0 ? s.wtail[((round - 1) & 1) * 16 + nwv - 1] : INFINITY;
+                int eq[kF], ei[kF];
+                float x[kF], v[kF], sf[kF], px[kF], pv[kF];
+                uint32_t m[kF];
+                bool act[kF];
+#pragma unroll
+                for (int u = 0; u < kF; ++u) {
+                    const int k = base + kF * l + u;
+                    act[u] = k < total;
+                    int w = 0, kk = act[u] ? k : total - 1;       // clamped: locate and load unconditionally
+                    for (; w < nseg - 1; ++w) {
+                        const int c = s.wtot[w];
+                        if (kk < c) break;
+                        kk -= c;
+                    }
+                    const int *pre = s.pre + (w << 6);
+                    int lo = 0;                                   // smallest j with pre[j] > kk
+#pragma unroll
+                    for (int st = 32; st; st >>= 1) if (pre[lo + st - 1] <= kk) lo += st;
+                    const int q = (w << 6) + lo;
+                    const int i = kk - (lo ? pre[lo - 1] : 0) + 1;
+                    eq[u] = q; ei[u] = i;
+                    const unsigned ob = (unsigned)(i * NLP + q) * 4u, pb = ob - (unsigned)NLP * 4u;
+                    x[u] = ldg(X, ob); v[u] = ldg(V, ob); sf[u] = ldg(SF, ob); m[u] = ldg(M, ob);
+                    px[u] = ldg(X, pb); pv[u] = ldg(V, pb);
+                }
+                if (round > 0 && l == 0 && ei[0] > 1) { px[0] = s.hz[0]; pv[0] = s.hz[1]; }   // overwritten by the previous super-round
+                float vn[kF], a[kF], key[kF], loc[kF];
+                bool run0[kF];
+                float run = INFINITY;
+                bool first_run = true;
+#pragma unroll
+                for (int u = 0; u < kF; ++u) {
+                    const int q = eq[u];
+                    const float Lq = s.len[q];
+                    const int mvp = s.mv[q * NR + (int)(m[u] >> 16)];
+                    const float v0 = s.vmax[q] * sf[u];
+                    const bool open = sig_open(mv_tl(mvp), mv_k(mvp), s.node[q], (int)(m[u] & 0xFFFFu), x[u], v[u], Lq, link, P.KMAX, P.teleport);
+                    float vv = follow(v[u], v0, true, (px[u] - kLen) - x[u], pv[u], kS0);
+                    if (!open) {
+                        const float v2 = follow(v[u], v0, true, Lq - x[u], 0.0f, 0.0f);
+                        if (v2 < vv) vv = v2;
+                    }
+                    vn[u] = vv;
+                    float aa = x[u] + vv;
+                    if (aa > Lq) aa = Lq;
+                    a[u] = aa;
+                    const bool live = act[u] && ei[u] > s.nc[q];
+                    act[u] = live;
+                    key[u] = live ? aa + (float)(5 * ei[u]) : INFINITY;
+                    if (u > 0 && eq[u] != eq[u - 1]) { run = INFINITY; first_run = false; }
+                    loc[u] = run; run0[u] = first_run;
+                    run = fminf(run, key[u]);
+                }
+                // segmented inclusive min-scan of the threads' last runs over the wavefront
+                float sv = run;
+                int sfl = (!first_run || ei[0] == 1) ? 1 : 0;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const float ov = __shfl_up(sv, d, 64);
+                    const int of = __shfl_up(sfl, d, 64);
+                    if (wl >= d && !sfl) { sv = fminf(sv, ov); sfl |= of; }
+                }
+                const float pvs = __shfl_up(sv, 1, 64);
+                const int pfs = __shfl_up(sfl, 1, 64);
+                if (wl == 63) s.wtail[(round & 1) * 16 + wv] = sv;
+                if (l == (int)blockDim.x - 1) { s.hz[2] = x[kF - 1]; s.hz[3] = v[kF - 1]; }
+                __syncthreads();
+                if (l == 0) { s.hz[0] = s.hz[2]; s.hz[1] = s.hz[3]; }       // read by thread 0 after the next barrier only
+                const float prev_tail = wv > 0 ? s.wtail[(round & 1) * 16 + wv - 1] : carry_round;
+                const float carry = ei[0] > 1 ? (wl == 0 ? prev_tail : (pfs ? pvs : fminf(pvs, prev_tail))) : INFINITY;
+#pragma unroll
+                for (int u = 0; u < kF; ++u) {
+                    if (!act[u]) continue;
+                    const int q = eq[u], i = ei[u];
+                    const float Kp = fminf(s.seed[q], fminf(run0[u] ? carry : INFINITY, loc[u]));
+                    const float xf = x[u] + vn[u];
+                    const float lim = Kp - (float)(5 * i);
+                    float xn = a[u] < lim ? a[u] : lim;
+                    if (xn < x[u]) xn = x[u];
+                    float vv = vn[u];
+                    if (xn != xf) vv = xn - x[u];
+                    const uint32_t w = (vv < kHalt) ? (m[u] & 0xFFFFu) + 1u : 0u;
+                    const uint32_t nmeta = w | (m[u] & 0xFFFF0000u);
+                    const int shift = s.nc[q];
+                    const unsigned ob = (unsigned)((i - shift) * NLP + q) * 4u;
+                    stg(X, ob, xn); stg(V, ob, vv); stg(M, ob, nmeta);
+                    if (shift) stg(SF, ob, sf[u]);
+                    if (i == s.n[q] - 1) { s.tx[q] = xn; s.tv[q] = vv; }
+                    if (last && xn >= P.lane_det[q]) { atomicAdd(&s.wave[q], 1); if (vv < kHalt) atomicAdd(&s.halt[q], 1); }
+                }
+                if (base + kF * (int)blockDim.x < total) __syncthreads();     // next super-round reads what this one stored
+            }
+            TSC_STAMP();
+            __syncthreads();
+            TSC_STAMP();
+        }
         // ================= phase B (K3): gather hand-offs from feeder lanes, then demand =========
         if (lane) {
+            if constexpr (HELP) {
+                // the first vehicle that stays becomes slot 0 now that nobody reads its old slot any more; the rest of the
+                // lane was compacted behind it by the flat phase
+                kept = has_first ? n - i0 : 0;
+                if (has_first) {
+                    const unsigned ob0 = (unsigned)l * 4u;
+                    stg(X, ob0, fxn); stg(V, ob0, fvn); stg(SF, ob0, fsf); stg(M, ob0, fmeta);
+                    hx = fxn; hv = fvn; hm = fmeta;
+                    if (kept >= 2) { tx = s.tx[l]; tv = s.tv[l]; } else { tx = fxn; tv = fvn; }
+                }
+            }
             n = kept;
             for (int u = 0; u < kMaxUp; ++u) {
                 const int src = u == 0 ? up0 : u == 1 ? up1 : u == 2 ? up2 : up3;
@@ -725,7 +783,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         P.N[(size_t)e * NLP + l] = n;
         // counts were taken while the last simulated second wrote the vehicles; the front-most vehicle is slot 0
         const int hw = (n > 0 && hx >= det && hx > 0.0f) ? (int)(hm & 0xFFFFu) : 0;
-        s.wave[l] = d_wave; s.halt[l] = d_halt; s.hwait[l] = hw;
+        s.wave[l] += d_wave; s.halt[l] += d_halt; s.hwait[l] = hw;       // the flat phase added its vehicles with LDS atomics
     }
     for (int r = l; r < NR; r += blockDim.x) { P.pending[(size_t)e * NR + r] = s.pend[r]; P.serial[(size_t)e * NR + r] = s.ser[r]; }
     if (arrived) atomicAdd(&P.arrived[e], (unsigned long long)arrived);
@@ -1034,7 +1092,7 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     }
 
     const size_t slots = (size_t)n_env * kCap * P.NLP;
-    ALLOC(X, float, slots); ALLOC(C, float, slots); ALLOC(V, float, slots); ALLOC(SF, float, slots); ALLOC(M, uint32_t, slots);
+    ALLOC(X, float, slots); ALLOC(V, float, slots); ALLOC(SF, float, slots); ALLOC(M, uint32_t, slots);
     ALLOC(N, int, (size_t)n_env * P.NLP);
     ALLOC(pending, int, (size_t)n_env * NR); ALLOC(serial, int, (size_t)n_env * NR);
     ALLOC(tsec, int, n_env); ALLOC(seed, uint32_t, n_env);
