@@ -272,7 +272,7 @@ __global__ void fingerprint_kernel(EnvDev P, const float *pi) {
 // grid fits the chip with no slack, and whenever another kernel ran in between (i.e. always, in the training
 // loop) XCD 0 admitted ~30 workgroups one full round late -> 178 us became 316 us per step
 // (tools/bench_env.py, tsc_env_debug_clock).  The cap costs ~120 B of scratch per lane and 8 % in isolation.
-template <int MAXT, bool HELP, bool REC = false>      // REC: evaluation recording (plain walk only)
+template <int MAXT, bool HELP, bool REC = false, int KF = 4>      // REC: evaluation recording (plain walk only); KF: vehicles per thread and super-round of the flat phase
 __global__ void __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1)
 step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, double *__restrict__ reward,
             double *__restrict__ greward, uint8_t *__restrict__ done, int train_mode) {
@@ -573,7 +573,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             const int nseg = NLA >> 6;
             int total = 0;
             for (int w = 0; w < nseg; ++w) total += s.wtot[w];
-            constexpr int kF = 4;
+            constexpr int kF = KF;
             const int wv = l >> 6, wl = l & 63, nwv = (int)blockDim.x >> 6;
             int round = 0;
             for (int base = 0; base < total; base += kF * (int)blockDim.x, ++round) {
@@ -897,6 +897,7 @@ struct tsc_env {
     std::vector<void *> allocs;
     size_t smem;
     int threads;                    // workgroup size of step_kernel
+    int kf;                         // flat-phase vehicles per thread (measurement knob TSC_ENV_KF)
     uint32_t *d_seeds;
 };
 
@@ -1121,6 +1122,12 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     h->smem = smem_bytes(P);
     if (h->smem > 160 * 1024) return tsc::fail("tsc_env_create: LDS need %zu B > 160 KiB", h->smem);
     h->threads = (P.help && P.NLA < 256) ? 256 : P.NLA;
+    // vehicles per thread and super-round of the flat phase: 1 measured best (296 M env-steps/s; 2: 294, 4: 284 -- fewer
+    // barriers do not pay for the registers); TSC_ENV_KF = 2 / 4 keep the wider variants for A/B runs
+    h->kf = 1;
+    if (const char *ev = getenv("TSC_ENV_KF")) { const int kv = atoi(ev); h->kf = (kv == 2 || kv == 4) ? kv : 1; }
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     if (const char *ev = getenv("TSC_ENV_THREADS")) {       // measurement knob: extra helper wavefronts
         const int tv = atoi(ev);
         if (tv >= P.NLA && tv <= 1024 && tv % 64 == 0) h->threads = tv;
@@ -1152,6 +1159,8 @@ int tsc_env_record(tsc_env *h, int32_t enable, int32_t trip_cap) {
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<1024, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
@@ -1258,6 +1267,12 @@ int tsc_env_step(tsc_env *h, const int32_t *action_dev, float *obs_dev, double *
     hipLaunchKernelGGL((step_kernel<MAXT, false, true>), dim3(h->P.E), dim3(h->threads), h->smem, h->stream, h->P, action_dev, \
                        obs_dev, reward_dev, global_reward_dev, done_dev, (int)train_mode)
     if (h->P.rec) { if (h->threads <= 256) TSC_STEP_REC(256); else TSC_STEP_REC(1024); }
+#define TSC_STEP_KF(KF)                                                                                           \
+    hipLaunchKernelGGL((step_kernel<256, true, false, KF>), dim3(h->P.E), dim3(h->threads), h->smem, h->stream, h->P, action_dev, \
+                       obs_dev, reward_dev, global_reward_dev, done_dev, (int)train_mode)
+    else if (h->threads <= 256 && h->P.help && h->kf == 1) TSC_STEP_KF(1);
+    else if (h->threads <= 256 && h->P.help && h->kf == 2) TSC_STEP_KF(2);
+#undef TSC_STEP_KF
     else if (h->threads <= 256) { if (h->P.help) TSC_STEP(256, true); else TSC_STEP(256, false); }
     else { if (h->P.help) TSC_STEP(1024, true); else TSC_STEP(1024, false); }
 #undef TSC_STEP_REC

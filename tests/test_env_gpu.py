@@ -147,3 +147,39 @@ def test_helper_threads_equal_plain_walk(monkeypatch):
         for k in ('n', 'x', 'v', 'sf', 'w', 'r'):
             np.testing.assert_array_equal(sa[k], sb[k], err_msg='state %s e=%d' % (k, e))
     a.close(); b.close()
+
+
+@pytest.mark.parametrize('kf', ['1', '2', '4'])
+def test_flat_phase_super_rounds_at_saturation(kf, monkeypatch):
+    """More queued vehicles than one super-round of the flat phase holds (kF x 256 per round): tripled demand and random
+    phases fill most lanes to capacity.  The chain scan then crosses wavefronts and super-rounds (LDS carries, the saved
+    old state of the previous round's last vehicle); obs, rewards and the full vehicle state stay bit-identical to the
+    oracle's sequential walk, for every kF variant of the kernel."""
+    from deeprl_signal_control_amd.env import VecTrafficEnv
+    from oracle.env_oracle import OracleEnv
+    monkeypatch.setenv('TSC_ENV_KF', kf)
+    scn = build_large_grid('ma2c', peak_flow1=3300, peak_flow2=2800)
+    E = 6
+    env = VecTrafficEnv(scn, E, seed=9)
+    orc = [OracleEnv(scn, seed=9 + e) for e in range(E)]
+    env.reset()
+    for o in orc:
+        o.reset()
+    rng = np.random.RandomState(5)
+    peak = 0.0
+    for t in range(260):
+        act = rng.randint(0, 5, (E, 25)).astype(np.int32)
+        o, r, d, g = env.step(torch.from_numpy(act).cuda())
+        o, r = o.cpu().numpy(), r.cpu().numpy()
+        for e in range(E):
+            oo, orr, _, _ = orc[e].step(list(act[e]))
+            for a in range(25):
+                np.testing.assert_array_equal(o[e, a, :scn.n_s_ls[a]], oo[a].astype(np.float32), err_msg='t=%d e=%d a=%d' % (t, e, a))
+            np.testing.assert_array_equal(r[e], orr, err_msg='t=%d e=%d' % (t, e))
+        peak = max(peak, env.mean_live_vehicles())
+    assert peak > 600, peak                      # 3 super-rounds at kF = 1, 2 at kF = 2 (entry lanes cap the inflow)
+    for e in range(E):
+        st, sn = env.get_state(e), orc[e].ms.snapshot()
+        for k in ('n', 'x', 'v', 'sf', 'w', 'r'):
+            np.testing.assert_array_equal(st[k], sn[k], err_msg='state %s e=%d' % (k, e))
+    env.close()
