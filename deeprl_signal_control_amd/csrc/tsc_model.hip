@@ -728,7 +728,7 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
                      int E, int S, float *__restrict__ pi_out, float *__restrict__ v_out, int *action_out,
                      unsigned long long seed, unsigned long long step,
                      int tslot, long long Ntot, float *X1c, float *Zc, float *Hhc, float *Ccc, float *Hpc,
-                     long long *dbg) {
+                     long long *dbg, const float *__restrict__ Wr) {
     constexpr int H = 2 * KS2 - 64, NCT = H / 32;
     const bool stamp = dbg && blockIdx.x == 0 && threadIdx.x == 0;
     int nstamp = 0;
@@ -792,10 +792,14 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
     float bwg[KS2];
     {
         // contraction index of MFMA step s2 in lane half kh: k = 8 * (s2 / 4) + 4 * kh + s2 % 4, so that a lane's A
-        // operands of four consecutive steps are one 16-byte LDS read
-        const float *src = P + lay.oWx + col;
+        // operands of four consecutive steps are one 16-byte LDS read; the weights come from the register-order copy
+        // (register_order_kernel): one coalesced 16-byte load per four steps
+        const float4 *src4 = reinterpret_cast<const float4 *>(Wr) + ((long long)(g * 8 + wave) * (KS2 / 4)) * 64 + lane;
 #pragma unroll
-        for (int s2 = 0; s2 < KS2; ++s2) bwg[s2] = src[(long long)(8 * (s2 >> 2) + 4 * kh + (s2 & 3)) * kG4];
+        for (int j4 = 0; j4 < KS2 / 4; ++j4) {
+            const float4 w4 = src4[(long long)j4 * 64];
+            bwg[4 * j4] = w4.x; bwg[4 * j4 + 1] = w4.y; bwg[4 * j4 + 2] = w4.z; bwg[4 * j4 + 3] = w4.w;
+        }
     }
     // softmax + action of the buffered tiles (~600 instructions per instance, half of them float64): one instance
     // per thread for up to kWsBuf tiles at once instead of 32 threads after every tile
@@ -1058,6 +1062,21 @@ __global__ void interleave_gates_kernel(const float *params, Layout lay, float *
     const long long g = i / per, r = i % per;
     const int k = (int)(r / kG4), c = (int)(r % kG4), u = c >> 2, q = c & 3;
     Wg[i] = params[g * lay.stride + lay.oWx + (long long)k * kG4 + 64 * q + u];
+}
+
+// Wr[g][wave w][j4][lane][c] = [Wx ; Wh][g][k = 8 j4 + 4 (lane / 32) + c][col = 32 w + lane % 32]: the stationary operand of
+// policy_fwd_ws_kernel in REGISTER order, so that its prologue is KS2 / 4 fully coalesced 16-byte loads per lane (1 KB
+// per wavefront instruction) instead of KS2 dword loads that each touch two 128-byte row segments.
+__global__ void register_order_kernel(const float *params, Layout lay, float *Wr) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per = (long long)(lay.H + kL) * kG4;
+    if (i >= per * lay.G) return;
+    const long long g = i / per, r = i % per;
+    const int c = (int)(r & 3), lane = (int)((r >> 2) & 63);
+    const long long rest = r >> 8;                       // w * (KS2 / 4) + j4
+    const int nj = (lay.H + kL) / 8, w = (int)(rest / nj), j4 = (int)(rest % nj);
+    const int k = 8 * j4 + 4 * (lane >> 5) + c, col = 32 * w + (lane & 31);
+    Wr[i] = params[g * lay.stride + lay.oWx + (long long)k * kG4 + col];
 }
 
 __global__ void fill_kernel(float *p, long long n, float v) {
@@ -1608,9 +1627,12 @@ static int model_forward(tsc_model *m, const float *obs, const uint8_t *done, fl
     }
     if (m->fused_fwd) {
         const int n_tiles = (E + 63) / 64, per_xcd = (L.G + 7) / 8;
-        if (m->wg_dirty && m->fused_fwd == 1) {             // parameters changed since the interleaved copy was made
+        if (m->wg_dirty) {                                  // parameters changed since the re-laid-out copy was made
             const long long tot = (long long)L.G * (L.H + kL) * kG4;
-            hipLaunchKernelGGL(interleave_gates_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, m->stream, m->params, L, m->Wg);
+            if (m->fused_fwd == 1)
+                hipLaunchKernelGGL(interleave_gates_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, m->stream, m->params, L, m->Wg);
+            else
+                hipLaunchKernelGGL(register_order_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, m->stream, m->params, L, m->Wg);
             m->wg_dirty = 0;
         }
         tsc::ProfScope ps(tsc::KID_FUSED_FWD, m->stream);
@@ -1620,7 +1642,7 @@ static int model_forward(tsc_model *m, const float *obs, const uint8_t *done, fl
             if (S > (E + 31) / 32) S = (E + 31) / 32;
 #define TSC_WS(KS2) hipLaunchKernelGGL(policy_fwd_ws_kernel<KS2>, dim3((unsigned)(L.G * S)), dim3(512), m->lds_ws, m->stream, m->params, \
                                        L, m->n_act, obs, done, m->state_fw, (int)advance, E, S, pi, v, action, (unsigned long long)seed,     \
-                                       (unsigned long long)step, (int)tslot, (long long)m->T * E, m->X1, m->Z, m->Hh, m->Cc, m->Hp, m->dbg)
+                                       (unsigned long long)step, (int)tslot, (long long)m->T * E, m->X1, m->Z, m->Hh, m->Cc, m->Hp, m->dbg, m->Wg)
             if (L.H == 224) TSC_WS(144); else TSC_WS(112);
 #undef TSC_WS
             ps.stop();
