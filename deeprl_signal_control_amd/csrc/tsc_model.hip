@@ -428,6 +428,209 @@ __global__ void __launch_bounds__(64) head_bwd_kernel(const float *__restrict__ 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// head_bwd, second form: loss gradient + dH + dWo / dbo of BOTH towers of an agent in one persistent pass.
+// Thread = (sample, quad of 4 hidden units): the 16 lanes of a sample read its h row as one coalesced 16-byte load per
+// lane (no LDS transpose, so nothing limits the waves per SIMD), reduce their partial logits with four xor-shuffles, all
+// evaluate the softmax / loss gradient of the sample, write their quad of dH, and accumulate h^T dL (= dWo, dWv) and
+// colsum(dL) (= dbo, dbv) in registers over the workgroup's fixed slice of the samples.  The slices' partial sums are
+// added in slice order by head_bwd2_reduce_kernel (deterministic), which replaces the separate split-K dWo GEMM and
+// its second pass over h and dL.  grid = (slices, agents), 256 threads.
+// ------------------------------------------------------------------------------------------------
+constexpr int kHbPer = kL * kOut + kOut + kL + 1;      // partial record of a slice: dWo [64][8] | dbo [8] | dWv [64] | dbv
+
+__global__ void __launch_bounds__(256, 3)
+head_bwd2_kernel(const float *__restrict__ params, Layout lay, const int *__restrict__ n_act, const float *__restrict__ Hh,
+                 const int *__restrict__ act, const float *__restrict__ Rs, const float *__restrict__ Advs, long long N,
+                 long long rows_per_slice, float v_coef, float beta, float *__restrict__ dH, float *__restrict__ part,
+                 double *stats) {
+    __shared__ float red[4][16][36];
+    const int a = blockIdx.y, sp = blockIdx.x, na = n_act[a];
+    const int tid = threadIdx.x, c = tid & 15, grp = tid >> 4;          // 16 sample groups per workgroup
+    const float *Pp = params + (long long)(2 * a) * lay.stride, *Pv = params + (long long)(2 * a + 1) * lay.stride;
+    float wo[4][kOut], wv[4], bo[kOut];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int k = 0; k < kOut; ++k) wo[u][k] = Pp[lay.oWo + (4 * c + u) * kOut + k];
+        wv[u] = Pv[lay.oWo + (4 * c + u) * kOut];
+    }
+#pragma unroll
+    for (int k = 0; k < kOut; ++k) bo[k] = Pp[lay.obo + k];
+    const float bv = Pv[lay.obo];
+    float aw[4][kOut], awv[4], ab[kOut], abv = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        awv[u] = 0.f;
+#pragma unroll
+        for (int k = 0; k < kOut; ++k) aw[u][k] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < kOut; ++k) ab[k] = 0.f;
+    float lp = 0.f, lv = 0.f, le = 0.f;
+    const long long n0 = (long long)sp * rows_per_slice;
+    long long n1 = n0 + rows_per_slice;
+    if (n1 > N) n1 = N;
+    const float *hp = Hh + (long long)(2 * a) * N * kL + 4 * c, *hq = Hh + (long long)(2 * a + 1) * N * kL + 4 * c;
+    float *dp = dH + (long long)(2 * a) * N * kL + 4 * c, *dq = dH + (long long)(2 * a + 1) * N * kL + 4 * c;
+    const float invN = 1.0f / (float)N;
+    for (long long nb = n0; nb < n1; nb += 16) {
+        const long long n = nb + grp;
+        const bool in = n < n1;
+        const long long nc = in ? n : n1 - 1;                           // clamped: unconditional loads
+        const float4 h4 = *reinterpret_cast<const float4 *>(hp + nc * kL);
+        const float4 g4 = *reinterpret_cast<const float4 *>(hq + nc * kL);
+        const long long idx = nc * lay.A + a;
+        const int ac = act[idx];
+        const float adv = Advs[idx], R = Rs[idx];
+        const float hh[4] = {h4.x, h4.y, h4.z, h4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
+        float lg[kOut], vv = 0.f;
+#pragma unroll
+        for (int k = 0; k < kOut; ++k) lg[k] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int k = 0; k < kOut; ++k) lg[k] += hh[u] * wo[u][k];
+            vv += gg[u] * wv[u];
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {                              // the 16 lanes of a sample are one shuffle row
+#pragma unroll
+            for (int k = 0; k < kOut; ++k) lg[k] += __shfl_xor(lg[k], o, 64);
+            vv += __shfl_xor(vv, o, 64);
+        }
+        const float v = vv + bv;
+        // softmax / loss gradient: lane c of the sample's 16 handles action k = c & 7 (one exp, one log, one division per
+        // lane instead of eight of each), sums go over the 8-lane row by xor-shuffles, then every lane collects all dl[k]
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < kOut; ++k) { lg[k] += bo[k]; if (k < na && lg[k] > mx) mx = lg[k]; }
+        const int km = c & 7;
+        float lgm = lg[0];
+#pragma unroll
+        for (int k = 1; k < kOut; ++k) lgm = km == k ? lg[k] : lgm;
+        const bool valid = km < na;
+        const float pk = valid ? expf(lgm - mx) : 0.f;
+        float sum = pk;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) sum += __shfl_xor(sum, o, 64);
+        const float pim = pk / sum;
+        const bool inr = pim >= 1e-10f;                                  // tf.clip_by_value(pi, 1e-10, 1)
+        const float logpm = valid ? logf(fminf(fmaxf(pim, 1e-10f), 1.0f)) : 0.f;
+        float gpi = 0.f;
+        if (valid) {
+            if (km == ac && inr) gpi += -adv * invN / fmaxf(pim, 1e-10f);
+            gpi += beta * invN * (logpm + (inr ? 1.0f : 0.f));
+        }
+        float dot = pim * gpi, ent = valid ? -pim * logpm : 0.f, lpa = (km == (ac < na ? ac : 0)) ? logpm : 0.f;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            dot += __shfl_xor(dot, o, 64); ent += __shfl_xor(ent, o, 64); lpa += __shfl_xor(lpa, o, 64);
+        }
+        const float dlm = (in && valid) ? pim * (gpi - dot) : 0.f;
+        float dl[kOut];
+        const int row0 = (tid & 63) & ~15;
+#pragma unroll
+        for (int k = 0; k < kOut; ++k) dl[k] = __shfl(dlm, row0 + k, 64);
+        const float dv = in ? v_coef * (v - R) * invN : 0.f;
+        // dH of my quad (FC policy: the head input is relu(.), fold its derivative in), dWo / dWv accumulation
+        float o4[4], q4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int k = 0; k < kOut; ++k) { sacc += dl[k] * wo[u][k]; aw[u][k] += hh[u] * dl[k]; }
+            o4[u] = (lay.fc && !(hh[u] > 0.f)) ? 0.f : sacc;
+            q4[u] = (lay.fc && !(gg[u] > 0.f)) ? 0.f : dv * wv[u];
+            awv[u] += gg[u] * dv;
+        }
+        if (in) {
+            *reinterpret_cast<float4 *>(dp + n * kL) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+            *reinterpret_cast<float4 *>(dq + n * kL) = make_float4(q4[0], q4[1], q4[2], q4[3]);
+        }
+        if (c == 0) {
+#pragma unroll
+            for (int k = 0; k < kOut; ++k) ab[k] += dl[k];
+            abv += dv;
+            if (in) {
+                lp += -lpa * adv * invN;
+                lv += 0.5f * v_coef * (R - v) * (R - v) * invN;
+                le += -beta * ent * invN;
+            }
+        }
+    }
+    // fold the 16 sample groups: across the wave's four groups by shuffles, across the four waves through LDS
+    const int wave = tid >> 6;
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int k = 0; k < kOut; ++k) aw[u][k] += __shfl_xor(aw[u][k], o, 64);
+            awv[u] += __shfl_xor(awv[u], o, 64);
+        }
+#pragma unroll
+        for (int k = 0; k < kOut; ++k) ab[k] += __shfl_xor(ab[k], o, 64);
+        abv += __shfl_xor(abv, o, 64);
+        lp += __shfl_xor(lp, o, 64); lv += __shfl_xor(lv, o, 64); le += __shfl_xor(le, o, 64);
+    }
+    if ((tid & 63) < 16) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int k = 0; k < kOut; ++k) red[wave][c][u * kOut + k] = aw[u][k];
+            red[wave][c][32 + u] = awv[u];
+        }
+    }
+    __shared__ float redb[4][kOut + 1];
+    __shared__ float redl[4][3];
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < kOut; ++k) redb[wave][k] = ab[k];
+        redb[wave][kOut] = abv;
+        redl[wave][0] = lp; redl[wave][1] = lv; redl[wave][2] = le;
+    }
+    __syncthreads();
+    float *out = part + ((long long)sp * lay.A + a) * kHbPer;
+    for (int j = tid; j < kHbPer; j += 256) {
+        float acc = 0.f;
+        if (j < kL * kOut) {                       // dWo[jj][k]: jj = 4 c + u
+            const int jj = j / kOut, k = j % kOut;
+            for (int w = 0; w < 4; ++w) acc += red[w][jj >> 2][(jj & 3) * kOut + k];
+        } else if (j < kL * kOut + kOut) {
+            for (int w = 0; w < 4; ++w) acc += redb[w][j - kL * kOut];
+        } else if (j < kL * kOut + kOut + kL) {
+            const int jj = j - (kL * kOut + kOut);
+            for (int w = 0; w < 4; ++w) acc += red[w][jj >> 2][32 + (jj & 3)];
+        } else {
+            for (int w = 0; w < 4; ++w) acc += redb[w][kOut];
+        }
+        out[j] = acc;
+    }
+    if (stats && tid == 0) {     // logging only (policies.py:63-72)
+        double a0 = 0, a1 = 0, a2 = 0;
+        for (int w = 0; w < 4; ++w) { a0 += redl[w][0]; a1 += redl[w][1]; a2 += redl[w][2]; }
+        atomicAdd(&stats[a * 4 + 0], a0); atomicAdd(&stats[a * 4 + 1], a1); atomicAdd(&stats[a * 4 + 2], a2);
+    }
+}
+
+// grads[g][oWo .. obo + 8) of both towers of every agent = sum over slices, in slice order
+__global__ void head_bwd2_reduce_kernel(const float *__restrict__ part, int A, int S, float *__restrict__ grads, Layout lay) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = kL * kOut + kOut;                 // entries per tower: Wo [64][8] | bo [8]
+    if (i >= A * 2 * per) return;
+    const int a = i / (2 * per), r = i % (2 * per), tower = r / per, j = r % per;
+    int src = -1;                                      // index into the slice record, -1: structurally zero
+    if (tower == 0) src = j;                           // dWo | dbo
+    else if (j < kL * kOut) { if (j % kOut == 0) src = kL * kOut + kOut + j / kOut; }     // dWv in column 0
+    else if (j == kL * kOut) src = kL * kOut + kOut + kL;                                 // dbv
+    float acc = 0.f;
+    if (src >= 0)
+        for (int s2 = 0; s2 < S; ++s2) acc += part[((long long)s2 * A + a) * kHbPer + src];
+    grads[(long long)(2 * a + tower) * lay.stride + lay.oWo + j] = acc;
+}
+
 // np.random.choice(n, p=pi): cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, u, 'right')
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
     x += 0x9E3779B97F4A7C15ull;
@@ -1715,6 +1918,37 @@ int tsc_model_add_transition(tsc_model *m, int32_t t, const float *obs, const ui
     return 0;
 }
 
+static int launch_head_bwd(tsc_model *m, long long N, double beta) {
+    const Layout &L = m->lay;
+    hipStream_t st = m->stream;
+    if (getenv("TSC_HEAD_BWD_V1")) {                 // round-1 form (one wave per 64-sample tile + split-K dWo GEMM), for A/B runs
+        {
+            tsc::ProfScope ps7(tsc::KID_HEAD_BWD, m->stream);
+            hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)L.A), dim3(64), 0, st, m->params, L, m->n_act,
+                               m->Hh, m->r_act, m->Rs, m->Advs, N, (float)m->vcoef, (float)beta, m->dL, m->dHh, m->stats);
+        }
+        float *g = m->grads;
+        return gemm(m, tsc::KID_DWO_GEMM, true, tsc::EPI_NONE, (int)L.G, kL, kOut, (int)N, m->Hh, N * kL, kL, 1, m->dL, N * kOut, kOut, g + L.oWo,
+                    L.stride, kOut, nullptr, 0, nullptr, 0, 0, nullptr, 0, g + L.obo, L.stride);
+    }
+    int S = (int)((8 * 256 + L.A - 1) / L.A);        // ~8 workgroups per CU
+    long long rps = (N + S - 1) / S;
+    rps = (rps + 15) / 16 * 16;
+    S = (int)((N + rps - 1) / rps);
+    if ((size_t)((long long)S * L.A * kHbPer) > m->ws_floats) return tsc::fail("head_bwd: workspace too small");
+    {
+        tsc::ProfScope ps7(tsc::KID_HEAD_BWD, m->stream);
+        hipLaunchKernelGGL(head_bwd2_kernel, dim3((unsigned)S, (unsigned)L.A), dim3(256), 0, st, m->params, L, m->n_act, m->Hh, m->r_act,
+                           m->Rs, m->Advs, N, rps, (float)m->vcoef, (float)beta, m->dHh, m->ws, m->stats);
+    }
+    {
+        tsc::ProfScope ps(tsc::KID_DWO_GEMM, m->stream);
+        const int tot = L.A * 2 * (kL * kOut + kOut);
+        hipLaunchKernelGGL(head_bwd2_reduce_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, m->ws, L.A, S, m->grads, L);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+
 int tsc_model_rollout_slot(tsc_model *m, int32_t t, void *ptrs[6]) {
     if (!m || !ptrs || t < 0 || t > m->T) return tsc::fail("tsc_model_rollout_slot: slot %d outside [0,%d]", t, m ? m->T : 0);
     const Layout &L = m->lay;
@@ -1744,16 +1978,11 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
     if (L.fc) {
         // FcACPolicy (agents/policies.py:214-256): Hh = relu(X1 Wfc + bfc); dZ = dH * (Hh > 0) comes out of head_bwd
         if (dense_forward(m, m->r_obs, N, m->X1, m->Hh)) return tsc::fail("gemm launch failed");
-        tsc::ProfScope ps7(tsc::KID_HEAD_BWD, m->stream);
-        hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)A), dim3(64), 0, st, m->params, L, m->n_act,
-                           m->Hh, m->r_act, m->Rs, m->Advs, N, (float)m->vcoef, (float)beta, m->dL, m->dHh, m->stats);
-        ps7.stop();
+        if (launch_head_bwd(m, N, beta)) return tsc::fail("head_bwd failed");       // + dWo, dbo
         tsc::ProfScope ps9(tsc::KID_TRANSPOSE, m->stream);
         hipLaunchKernelGGL(transpose_wx_kernel, dim3((unsigned)((G * L.H * L.NZ + 255) / 256)), dim3(256), 0, st, m->params, L, m->WxT);
         ps9.stop();
         TSC_HIP(hipGetLastError());
-        if (gemm(m, tsc::KID_DWO_GEMM, true, tsc::EPI_NONE, (int)G, kL, kOut, (int)N, m->Hh, N * kL, kL, 1, m->dL, N * kOut, kOut, g + L.oWo,
-                 L.stride, kOut, nullptr, 0, nullptr, 0, 0, nullptr, 0, g + L.obo, L.stride)) return tsc::fail("gemm failed");
         if (gemm(m, tsc::KID_DWX_GEMM, true, tsc::EPI_NONE, (int)G, L.H, kL, (int)N, m->X1, N * L.H, L.H, 1, m->dHh, N * kL, kL, g + L.oWx,
                  L.stride, kL, nullptr, 0, nullptr, 0, 0, nullptr, 0, g + L.obl, L.stride)) return tsc::fail("gemm failed");
         if (gemm(m, tsc::KID_DX1_GEMM, false, tsc::EPI_MASK_POS, (int)G, (int)N, L.H, kL, m->dHh, N * kL, kL, 1, m->WxT, (long long)L.H * kL, L.H,
@@ -1769,10 +1998,7 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
                            m->Z, m->state_bw, (float *)nullptr, m->Hh, m->Cc, m->Hp, m->r_done, (int)T, (int)E, 1);
         ps2.stop();
     }
-    tsc::ProfScope ps7(tsc::KID_HEAD_BWD, m->stream);
-    hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)A), dim3(64), 0, st, m->params, L, m->n_act,
-                       m->Hh, m->r_act, m->Rs, m->Advs, N, (float)m->vcoef, (float)beta, m->dL, m->dHh, m->stats);
-    ps7.stop();
+    if (launch_head_bwd(m, N, beta)) return tsc::fail("head_bwd failed");           // + dWo, dbo
     tsc::ProfScope ps8(tsc::KID_LSTM_BWD, m->stream);
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)G, (unsigned)((E + 63) / 64)), dim3(256), m->lds_bwd, st, m->params, L,
                        m->Z, m->Cc, m->state_bw, m->dHh, m->r_done, (int)T, (int)E);
@@ -1781,9 +2007,7 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
     hipLaunchKernelGGL(transpose_wx_kernel, dim3((unsigned)((G * L.H * kG4 + 255) / 256)), dim3(256), 0, st, m->params, L, m->WxT);
     ps9.stop();
     TSC_HIP(hipGetLastError());
-    // dWo = Hh^T dL (+ dbo) ; dWh = Hp^T dZ (+ dbl) ; dWx = X1^T dZ
-    if (gemm(m, tsc::KID_DWO_GEMM, true, tsc::EPI_NONE, (int)G, kL, kOut, (int)N, m->Hh, N * kL, kL, 1, m->dL, N * kOut, kOut, g + L.oWo,
-             L.stride, kOut, nullptr, 0, nullptr, 0, 0, nullptr, 0, g + L.obo, L.stride)) return tsc::fail("gemm failed");
+    // dWh = Hp^T dZ (+ dbl) ; dWx = X1^T dZ        (dWo = Hh^T dL and dbo came out of head_bwd)
     const int NT = (L.H + kL) / 32;
     int S = 256 / (int)G;                       // ~ one workgroup per CU
     if (S < 1) S = 1;
