@@ -35,11 +35,11 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (profiles/r01_pmc.json: separate
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (profiles/r02_pmc.json: separate
     FETCH_SIZE / WRITE_SIZE passes, KB units; the gfx950 x2 FETCH correction only applies to 16 B/lane streams and
     is NOT applied to these dword-per-lane kernels) or None."""
     try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc.json')))
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc.json')))
         k = d['kernels'][kernel]
         return (k['fetch_kb'] + k['write_kb']) * 1024.0
     except Exception:

@@ -13,7 +13,8 @@ import json
 import sqlite3
 import sys
 
-NAMES = [('step_kernel', 'env_step'), ('policy_fwd_fused', 'policy_fwd_fused'), ('policy_fwd_ws', 'policy_fwd_fused'), ('dwxh_kernel', 'dwx_gemm'),
+NAMES = [('step_kernel', 'env_step'), ('head_bwd2_reduce', 'dwo_gemm'), ('head_bwd2', 'head_bwd'), ('register_order', 'register_order'),
+         ('grad_norm_fold', 'grad_norm'), ('policy_fwd_fused', 'policy_fwd_fused'), ('policy_fwd_ws', 'policy_fwd_fused'), ('dwxh_kernel', 'dwx_gemm'),
          ('dx1w1_kernel', 'dx1_gemm'), ('lstm_bwd', 'lstm_bwd'), ('lstm_fwd', 'lstm_fwd'), ('head_bwd', 'head_bwd'),
          ('head_fwd', 'head_fwd'), ('add_transition', 'add_transition'), ('dwxh_reduce', 'dwh_gemm'),
          ('dx1w1_reduce', 'dw1_gemm'), ('returns_kernel', 'returns'), ('rmsprop', 'rmsprop'), ('grad_norm', 'grad_norm'),
@@ -47,8 +48,8 @@ def traffic(fetch_db, write_db, out_path):
         ft, fn = f.get(k, (0.0, 0))
         wt, wn = w.get(k, (0.0, 0))
         kern[k] = {'fetch_kb': ft / max(fn, 1), 'write_kb': wt / max(wn, 1), 'launches': max(fn, wn)}
-    doc = {'command': 'rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python bench.py --steps 1 --warmup 1 '
-                      '--no-cpu-baseline --no-profile; folded by tools/rocpd_pmc.py',
+    doc = {'command': 'tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python bench.py --steps 1 '
+                      '--warmup 1 --no-cpu-baseline --no-extra --no-profile; folded by tools/rocpd_pmc.py',
            'units': 'KB per launch (average over launches)', 'kernels': kern}
     json.dump(doc, open(out_path, 'w'), indent=1)
     print('%d kernels -> %s' % (len(kern), out_path))
