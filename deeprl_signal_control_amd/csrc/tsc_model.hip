@@ -920,6 +920,15 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
 // G x S workgroups (S = 256 / G) ~ one per CU, every instance tile of a tower is a loop iteration instead of a
 // workgroup, the next tile's obs / state are prefetched under the gate MFMAs.
 // ------------------------------------------------------------------------------------------------
+// The activation cache is written once per control step and not read before the update: streaming (non-temporal) stores
+// keep its 160 MB per launch from evicting the simulator's vehicle state out of L2 / the infinity cache between two
+// tsc_env_step launches (measured in bench.py: env_step 112 -> ... us in the training loop).
+__device__ __forceinline__ void st_stream(float *p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void st_stream4(float *p, const float4 &v) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f4 *>(p));
+}
 constexpr int kWsLdx = 36;       // activations [k][32 instances + 4]
 constexpr int kWsLdg = 33;       // gate pre-activations [256 columns][32 instances + 1]
 constexpr int kWsBuf = 8;        // tiles whose logits are buffered before the softmax / sampling pass
@@ -1064,7 +1073,7 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
                 float v0 = acc[r] + b1c;
                 v0 = v0 > 0.f ? v0 : 0.f;
                 XH[row * LDK + col] = v0;
-                if (tslot >= 0 && e0 + row < E) stg(x1b, (unsigned)(row * H + col) * 4u, v0);
+                if (tslot >= 0 && e0 + row < E) st_stream(x1b + (row * H + col), v0);
             }
         }
         // ---- phase 1.5: done-masked h_prev -> columns [H, H+64) of the instance's row (no barrier before: phase 1
@@ -1072,7 +1081,7 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
         const float4 hm = make_float4(h4.x * keep, h4.y * keep, h4.z * keep, h4.w * keep);
         const float4 cm = make_float4(c4.x * keep, c4.y * keep, c4.z * keep, c4.w * keep);
         *reinterpret_cast<float4 *>(XH + ce * LDK + H + cu) = hm;
-        if (tslot >= 0 && e0 + ce < E) *reinterpret_cast<float4 *>(Hpc + (nb0 + ce) * kL + cu) = hm;
+        if (tslot >= 0 && e0 + ce < E) st_stream4(Hpc + (nb0 + ce) * kL + cu, hm);
         __syncthreads();
         WSTAMP();
         // next tile's inputs: in flight under the gate MFMAs
@@ -1120,12 +1129,12 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
                 }
                 if (tslot >= 0) {                                  // what lstm_fwd_kernel<true> would store
                     float *zr = Zc + (nb0 + ce) * kG4 + cu;
-                    *reinterpret_cast<float4 *>(zr) = make_float4(gi[0], gi[1], gi[2], gi[3]);
-                    *reinterpret_cast<float4 *>(zr + 64) = make_float4(gf[0], gf[1], gf[2], gf[3]);
-                    *reinterpret_cast<float4 *>(zr + 128) = make_float4(go[0], go[1], go[2], go[3]);
-                    *reinterpret_cast<float4 *>(zr + 192) = make_float4(gu[0], gu[1], gu[2], gu[3]);
-                    *reinterpret_cast<float4 *>(Ccc + (nb0 + ce) * kL + cu) = c4n;
-                    *reinterpret_cast<float4 *>(Hhc + (nb0 + ce) * kL + cu) = h4n;
+                    st_stream4(zr, make_float4(gi[0], gi[1], gi[2], gi[3]));
+                    st_stream4(zr + 64, make_float4(gf[0], gf[1], gf[2], gf[3]));
+                    st_stream4(zr + 128, make_float4(go[0], go[1], go[2], go[3]));
+                    st_stream4(zr + 192, make_float4(gu[0], gu[1], gu[2], gu[3]));
+                    st_stream4(Ccc + (nb0 + ce) * kL + cu, c4n);
+                    st_stream4(Hhc + (nb0 + ce) * kL + cu, h4n);
                 }
             }
         }
