@@ -64,7 +64,7 @@ def algorithmic_flops(model, rows):
             'lstm_fwd': G * 2 * L * 4 * L * rows, 'lstm_bwd': G * 2 * L * 4 * L * rows,
             'dwx_gemm': dwx + dwh if fused_update else dwx, 'dwh_gemm': 0.0 if fused_update else dwh,
             'dx1_gemm': dwx + fc * rows if fused_update else dwx, 'dw1_gemm': 0.0 if fused_update else fc * rows,
-            'dwo_gemm': out * rows}
+            'dwo_gemm': 0.0}          # dWo = h^T dL is accumulated inside head_bwd (VALU); 'dwo_gemm' now times its slice reduction
 
 
 def cpu_baseline(n_env=48, n_step=120, threads=8):
