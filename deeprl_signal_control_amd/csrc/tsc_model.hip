@@ -940,9 +940,10 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
                      int E, int S, float *__restrict__ pi_out, float *__restrict__ v_out, int *action_out,
                      unsigned long long seed, unsigned long long step,
                      int tslot, long long Ntot, float *X1c, float *Zc, float *Hhc, float *Ccc, float *Hpc,
-                     long long *dbg, const float *__restrict__ Wr) {
+                     long long *dbg, const float *__restrict__ Wr, const int *__restrict__ kr, int dbg_tid) {
     constexpr int H = 2 * KS2 - 64, NCT = H / 32;
-    const bool stamp = dbg && blockIdx.x == 0 && threadIdx.x == 0;
+    static_assert((32 * (H / 4)) % 512 == 0 || (32 * (H / 4)) % 512 == 256, "X1 store: duplicates come from 256 lanes below");
+    const bool stamp = dbg && blockIdx.x == 0 && (int)threadIdx.x == dbg_tid;
     int nstamp = 0;
 #define WSTAMP() do { if (stamp && nstamp < 60) dbg[nstamp++] = clock64(); } while (0)
     WSTAMP();
@@ -953,9 +954,9 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
     float *Hn = Hs + 64 * kWsLdx;                       // [64 units][kWsLdg]: new h, k-major for the head
     float *Gz = Hn + kL * kWsLdg;                       // [256][kWsLdg]
     float *WoS = Gz + kG4 * kWsLdg;                     // [64][8] + [8] (+ pad to 528)
-    float *LG = WoS + 528;                              // [kWsBuf tiles][32][8] logits, then [32][8] partial sums
+    float *LG = WoS + 528;                              // [kWsBuf tiles][32][8] logits, then [2 halves of the units][32][8] partial sums
     float *LGp = LG + kWsBuf * 32 * kOut;
-    float *W1s = LGp + 32 * kOut;                        // [SMAX][H]: W1 is small enough to sit in LDS for the whole launch
+    float *W1s = LGp + 2 * 32 * kOut;                    // [SMAX][H]: W1 is small enough to sit in LDS for the whole launch
     // (numbering the S workgroups of a tower onto one XCD so that four of the five weight reads hit its L2 halves the
     //  prologue but leaves two XCDs with 35 workgroups for 32 CUs: 126 -> 207 us)
     const int g = blockIdx.x % lay.G, sp = blockIdx.x / lay.G;
@@ -985,16 +986,19 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
     const bool ob_on = tid < 32 * q4;
     const int om = ob_on ? tid / q4 : 0, ok4 = ob_on ? (tid % q4) * 4 : 0;
     const int ce = tid >> 4, cu = (tid & 15) * 4;
-    const float *stb = state + (long long)g * E * 2 * kL;
+    // addressing: workgroup-uniform 64-bit base (SGPRs) + 32-bit lane offset, so that no per-array 64-bit lane
+    // address is hoisted out of the tile loop into (spilled) VGPRs
+    float *stb = state + (long long)g * E * 2 * kL;
+    const float *obs_a = obs + a * SMAX;
     auto fetch_obs = [&](int e0) {
-        const int e = e0 + om < E ? e0 + om : E - 1;
-        return *reinterpret_cast<const float4 *>(obs + (long long)e * AS + a * SMAX + ok4);
+        const unsigned e = (unsigned)(e0 + om < E ? e0 + om : E - 1);
+        return *reinterpret_cast<const float4 *>(obs_a + (e * (unsigned)AS + (unsigned)ok4));
     };
     auto fetch_state = [&](int e0, int off) {
-        const int e = e0 + ce < E ? e0 + ce : E - 1;
-        return *reinterpret_cast<const float4 *>(stb + (long long)e * 2 * kL + off + cu);
+        const unsigned e = (unsigned)(e0 + ce < E ? e0 + ce : E - 1);
+        return *reinterpret_cast<const float4 *>(stb + (e * (unsigned)(2 * kL) + (unsigned)(off + cu)));
     };
-    auto fetch_keep = [&](int e0) { return 1.0f - (float)done[e0 + ce < E ? e0 + ce : E - 1]; };
+    auto fetch_keep = [&](int e0) { return 1.0f - (float)done[(unsigned)(e0 + ce < E ? e0 + ce : E - 1)]; };
     float4 ov = make_float4(0.f, 0.f, 0.f, 0.f), c4 = ov, h4 = ov;
     float keep = 0.f;
     if (t0 >= t1) return;                                      // fewer tiles than workgroups per tower
@@ -1036,128 +1040,228 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
         }
     };
     WSTAMP();
-    for (int tt = t0; tt < t1; ++tt) {
-        const int e0 = 32 * tt;
-        const long long nb0 = (long long)g * Ntot + (long long)(tslot < 0 ? 0 : tslot) * E + e0;   // first cache row of the tile
-        // ---- phase 0: obs tile -> LDS, k-major; rows [SMAX, 64) of the staging area are zero
+    // Software pipeline over the tiles: the first layer of tile tt + 1 shares a barrier interval with the cell update of
+    // tile tt (one is a dependent MFMA chain, the other a chain of exp / rcp: waves w and w + 4 sit on the same SIMD and
+    // run the two in opposite order), so a tile costs three barrier intervals -- gate GEMM | cell + next first layer |
+    // head -- instead of six.
+    // rows [SMAX, 64) of the obs staging area stay zero for the whole launch
+    for (int idx = tid; idx < (64 - SMAX) * 32; idx += 512) Hs[(SMAX + (idx >> 5)) * kWsLdx + (idx & 31)] = 0.f;
+    // the K range of this wave's first-layer tile: W1 is block-structured (obs rows of one kind feed one block of hidden
+    // columns, agents/policies.py:41-61), rows outside the range only multiply stored zeros
+    int ks_lo = 0, ks_hi = (SMAX + 1) >> 1;
+    if (kr && wave < NCT) { ks_lo = kr[(a * 8 + wave) * 2]; ks_hi = kr[(a * 8 + wave) * 2 + 1]; }
+    // Per-thread LDS / cache offsets are re-derived from an OPAQUE copy of the thread index inside each interval: hoisted
+    // out of the tile loop they cost ~20 VGPRs the kernel does not have (144 hold the weights), and a spilled VGPR is
+    // reloaded through vmcnt, i.e. behind every streaming store still in flight.
+    auto opaque_tid = [&]() { int t_ = tid; asm volatile("" : "+v"(t_)); return t_; };
+    auto stage_obs = [&]() {                                   // obs tile held in `ov` -> LDS, k-major
         if (ob_on) {
             Hs[(ok4 + 0) * kWsLdx + om] = ov.x; Hs[(ok4 + 1) * kWsLdx + om] = ov.y;
             Hs[(ok4 + 2) * kWsLdx + om] = ov.z; Hs[(ok4 + 3) * kWsLdx + om] = ov.w;
         }
-        for (int idx = tid; idx < (64 - SMAX) * 32; idx += 512) Hs[(SMAX + (idx >> 5)) * kWsLdx + (idx & 31)] = 0.f;
-        __syncthreads();
-        WSTAMP();
-        // ---- phase 1: X1 = relu(obs W1 + b1): wave w < NCT owns column tile w
+    };
+    // X1 = relu(obs W1 + b1) of the tile staged in Hs: wave w < NCT owns column tile w.  All LDS operands of eight
+    // steps are requested first, then the dependent MFMA chain runs without waiting; the tile goes to XH only -- its
+    // copy for the update's activation cache is streamed out of XH under the NEXT gate GEMM (store_x1)
+    auto first_layer = [&]() {
         if (wave < NCT) {
+            const int t_ = opaque_tid(), li = t_ & 31, kh = (t_ >> 5) & 1, col = 32 * (t_ >> 6) + li;
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const int ks1 = (SMAX + 1) >> 1;                       // obs rows past SMAX are zero; W1 rows clamped
-            auto w1row = [&](int s2) { return 2 * s2 + kh < SMAX ? 2 * s2 + kh : SMAX - 1; };
-            int s2 = 0;
-            for (; s2 + 4 <= ks1; s2 += 4) {                       // four steps: all LDS operands first, then the MFMAs
-                float av[4], bv[4];
+            for (int sb = ks_lo; sb < ks_hi; sb += 8) {
+                float av[8], bv[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { av[q] = Hs[(2 * (s2 + q) + kh) * kWsLdx + li]; bv[q] = W1s[w1row(s2 + q) * H + col]; }
+                for (int q = 0; q < 8; ++q) {
+                    const bool on = sb + q < ks_hi;                // steps past the range: a zero A operand
+                    const int s2 = on ? sb + q : ks_hi - 1;
+                    const int row = 2 * s2 + kh < SMAX ? 2 * s2 + kh : SMAX - 1;   // obs rows past SMAX are zero; W1 rows clamped
+                    const float x = Hs[(2 * s2 + kh) * kWsLdx + li];
+                    av[q] = on ? x : 0.f;
+                    bv[q] = W1s[row * H + col];
+                }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+                for (int q4 = 0; q4 < 2; ++q4) {
+                    if (sb + 4 * q4 < ks_hi) {                         // wave-uniform
+#pragma unroll
+                        for (int q = 4 * q4; q < 4 * q4 + 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+                    }
+                }
             }
-            for (; s2 < ks1; ++s2)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Hs[(2 * s2 + kh) * kWsLdx + li], W1s[w1row(s2) * H + col], acc, 0, 0, 0);
-            float *x1b = X1c + nb0 * H;
-            int z1 = 0;
-            asm volatile("" : "+v"(z1));
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * kh + z1;
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
                 float v0 = acc[r] + b1c;
                 v0 = v0 > 0.f ? v0 : 0.f;
                 XH[row * LDK + col] = v0;
-                if (tslot >= 0 && e0 + row < E) st_stream(x1b + (row * H + col), v0);
             }
         }
-        // ---- phase 1.5: done-masked h_prev -> columns [H, H+64) of the instance's row (no barrier before: phase 1
-        // writes columns [0, H))
+    };
+    // done-masked previous state of the tile held in c4 / h4 / keep: h -> columns [H, H + 64) of the instance's row;
+    // returns the masked c (the cell update's input)
+    float4 cm = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto stage_state = [&](int e0n, long long nbn, bool on) {
         const float4 hm = make_float4(h4.x * keep, h4.y * keep, h4.z * keep, h4.w * keep);
-        const float4 cm = make_float4(c4.x * keep, c4.y * keep, c4.z * keep, c4.w * keep);
-        *reinterpret_cast<float4 *>(XH + ce * LDK + H + cu) = hm;
-        if (tslot >= 0 && e0 + ce < E) st_stream4(Hpc + (nb0 + ce) * kL + cu, hm);
-        __syncthreads();
-        WSTAMP();
-        // next tile's inputs: in flight under the gate MFMAs
-        float4 nov = ov, nc4 = c4, nh4 = h4;
-        float nkeep = keep;
-        if (tt + 1 < t1) { nov = fetch_obs(e0 + 32); nc4 = fetch_state(e0 + 32, 0); nh4 = fetch_state(e0 + 32, kL); nkeep = fetch_keep(e0 + 32); }
-        // ---- phase 2: gate tile of this wave = bl + [X1 | h] [Wx ; Wh][:, 32w .. 32w+32)
+        const float4 cmn = make_float4(c4.x * keep, c4.y * keep, c4.z * keep, c4.w * keep);
+        if (on) {
+            const int t_ = opaque_tid(), ce = t_ >> 4, cu = (t_ & 15) * 4;
+            *reinterpret_cast<float4 *>(XH + ce * LDK + H + cu) = hm;
+            if (tslot >= 0 && e0n + ce < E) st_stream4(Hpc + nbn * kL + (unsigned)(ce * kL + cu), hm);
+        }
+        return cmn;
+    };
+    // cell update of (instance ce, units cu..cu+3) from the gate pre-activations in Gz; h -> LDS rows [0, 64)
+    auto cell = [&](int e0c, long long nbc) {
+        const int t_ = opaque_tid(), ce = t_ >> 4, cu = (t_ & 15) * 4;
+        const unsigned st_lane = (unsigned)(ce * 2 * kL + cu), z_lane = (unsigned)(ce * kG4 + cu), c_lane = (unsigned)(ce * kL + cu);
+        float gi[4], gf[4], go[4], gu[4], cn[4], hn[4];
+        const float cin[4] = {cm.x, cm.y, cm.z, cm.w};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int u = cu + jj;
+            gi[jj] = sigmoidf_(Gz[u * kWsLdg + ce]); gf[jj] = sigmoidf_(Gz[(64 + u) * kWsLdg + ce]);
+            go[jj] = sigmoidf_(Gz[(128 + u) * kWsLdg + ce]); gu[jj] = tanhf_(Gz[(192 + u) * kWsLdg + ce]);
+            cn[jj] = gf[jj] * cin[jj] + gi[jj] * gu[jj];
+            hn[jj] = go[jj] * tanhf_(cn[jj]);
+            Hn[u * kWsLdg + ce] = hn[jj];
+        }
+        if (e0c + ce < E) {
+            const float4 c4n = make_float4(cn[0], cn[1], cn[2], cn[3]), h4n = make_float4(hn[0], hn[1], hn[2], hn[3]);
+            if (advance) {
+                float *st = stb + (long long)e0c * 2 * kL;
+                *reinterpret_cast<float4 *>(st + st_lane) = c4n; *reinterpret_cast<float4 *>(st + (st_lane + kL)) = h4n;
+            }
+            if (tslot >= 0) {                                  // what lstm_fwd_kernel<true> would store
+                float *zr = Zc + nbc * kG4;
+                st_stream4(zr + z_lane, make_float4(gi[0], gi[1], gi[2], gi[3]));
+                st_stream4(zr + (z_lane + 64), make_float4(gf[0], gf[1], gf[2], gf[3]));
+                st_stream4(zr + (z_lane + 128), make_float4(go[0], go[1], go[2], go[3]));
+                st_stream4(zr + (z_lane + 192), make_float4(gu[0], gu[1], gu[2], gu[3]));
+                st_stream4(Ccc + nbc * kL + c_lane, c4n);
+                st_stream4(Hhc + nbc * kL + c_lane, h4n);
+            }
+        }
+    };
+    // head, second half: logits of tile tj = (units 0..31) + (units 32..63) + bias -> slot of the buffer
+    auto head_finish = [&](int tj) {
+        if (tid < 256) {
+            const int e = tid & 31, k0 = (tid >> 5) & 7, slot = (tj - t0) % kWsBuf;
+            LG[(slot * 32 + e) * kOut + k0] = (LGp[tid] + LGp[256 + tid]) + WoS[kL * kOut + k0];
+        }
+    };
+    const long long nbase = (long long)g * Ntot + (long long)(tslot < 0 ? 0 : tslot) * E;   // cache row of instance 0
+    // ---- pipeline fill: tile t0 staged, first layer + state in place, tile t0 + 1 requested
+    stage_obs();
+    __syncthreads();
+    first_layer();
+    cm = stage_state(32 * t0, nbase + 32 * t0, true);
+    // (all prefetches are unconditional -- the instance index is clamped -- so that each prefetched register has ONE
+    //  definition per iteration and is waited for where it is consumed, not at a control-flow join)
+    ov = fetch_obs(32 * t0 + 32);
+    __syncthreads();
+    WSTAMP();
+    for (int tt = t0; tt < t1; ++tt) {
+        const int e0 = 32 * tt;
+        const long long nb0 = nbase + e0;                         // first cache row of the tile
+        const bool more = tt + 1 < t1;
+        // ---- interval 1: next tile's obs -> LDS (the staging area is free since its first layer ran), the obs of the
+        // tile after it requested; gate tile of this wave = bl + [X1 | h] [Wx ; Wh][:, 32w .. 32w+32)
+        // the group of kWsBuf tiles whose last logits were written two intervals ago: softmax + action (LG is rewritten
+        // only after this interval's barrier)
+        if (tt - t0 >= 2 && (tt - 2 - t0) % kWsBuf == kWsBuf - 1) emit(32 * (tt - 1 - kWsBuf), kWsBuf);
+        if (more) stage_obs();
+        ov = fetch_obs(e0 + 64);
+        c4 = fetch_state(e0 + 32, 0); h4 = fetch_state(e0 + 32, kL); keep = fetch_keep(e0 + 32);   // consumed right after the GEMM
+        // head of the PREVIOUS tile, first half: thread -> (instance, output, half of the units): 8 batches of 4 LDS
+        // operand pairs, placed by hand between the MFMAs of the gate GEMM (whose dependent chain leaves the issue slots
+        // free); unconditional -- the result of the first iteration is never read
+        float hs0 = 0.f;
         {
+            const int t_ = opaque_tid(), li = t_ & 31, kh = (t_ >> 5) & 1, col = 32 * (t_ >> 6) + li;
+            const float *hp = Hn + (32 * (t_ >> 8)) * kWsLdg + (t_ & 31), *wp = WoS + (32 * (t_ >> 8)) * kOut + ((t_ >> 5) & 7);
             f32x16 acc;
+            float bl_ = blc;
+            asm volatile("" : "+v"(bl_));                          // (a hoisted 16-register splat would be spilled)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = blc;
+            for (int r = 0; r < 16; ++r) acc[r] = bl_;
             const float4 *As = reinterpret_cast<const float4 *>(XH + li * LDK + 4 * kh);
+            constexpr int NJ = KS2 / 4, PER = NJ / 4, HP = NJ / 8;
+            float hv[4], wv[4];
+            float4 x1q = make_float4(0.f, 0.f, 0.f, 0.f);
+            unsigned x1o = 0;
+            float *x1b = tslot >= 0 ? X1c + nb0 * H : X1c + (long long)lay.G * Ntot * H;   // cache off: the spare tile behind the buffer
+            float4 a4 = As[0];
 #pragma unroll
-            for (int j4 = 0; j4 < KS2 / 4; ++j4) {
-                const float4 a4 = As[2 * j4];
+            for (int j4 = 0; j4 < NJ; ++j4) {
+                const float4 an = As[2 * (j4 + 1 < NJ ? j4 + 1 : j4)];   // next quad in flight under this one's MFMAs
+                if (j4 % HP == 0 && j4 / HP < 8) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { hv[q] = hp[(4 * (j4 / HP) + q) * kWsLdg]; wv[q] = wp[(4 * (j4 / HP) + q) * kOut]; }
+                }
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bwg[4 * j4], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bwg[4 * j4 + 1], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bwg[4 * j4 + 2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bwg[4 * j4 + 3], acc, 0, 0, 0);
+                if (j4 % HP == HP - 1 && j4 / HP < 8) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) hs0 += hv[q] * wv[q];
+                }
+                // this tile's X1 (in XH, row-major) -> the update's activation cache, 16 bytes per lane and quarter.  Branch-free:
+                // lanes past the tile re-store the quad of the lane 256 below, rows past E the last valid row (same values;
+                // distinct addresses, so that the duplicates do not serialise on one)
+                if (j4 % PER == 3 && j4 / PER < (32 * (H / 4) + 511) / 512) {
+                    int f = t_ + 512 * (j4 / PER);
+                    f = f < 32 * (H / 4) ? f : f - 256;
+                    int row = f / (H / 4);
+                    const int c4i = f - row * (H / 4);
+                    row = e0 + row < E ? row : E - 1 - e0;
+                    x1q = *reinterpret_cast<const float4 *>(XH + row * LDK + 4 * c4i);
+                    x1o = (unsigned)(row * H + 4 * c4i);
+                }
+                if (j4 % PER == 5 && j4 / PER < (32 * (H / 4) + 511) / 512 ) st_stream4(x1b + x1o, x1q);
+                a4 = an;
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) Gz[col * kWsLdg + (r & 3) + 8 * (r >> 2) + 4 * kh] = acc[r];
+            LGp[t_] = hs0;                                        // [half][output][instance]
+            // what was requested before the GEMM has long arrived: wait for it HERE, in front of the stores below (vmcnt
+            // retires in order and the stores are conditional, so a later wait would be a wait for the stores)
+            asm volatile("" :: "v"(ov.x), "v"(ov.y), "v"(ov.z), "v"(ov.w), "v"(c4.x), "v"(c4.y), "v"(c4.z), "v"(c4.w),
+                         "v"(h4.x), "v"(h4.y), "v"(h4.z), "v"(h4.w), "v"(keep));
         }
         WSTAMP();
         __syncthreads();
         WSTAMP();
-        // ---- phase 3: cell update of (instance ce, units cu..cu+3); h -> LDS rows [0, 64)
-        {
-            float gi[4], gf[4], go[4], gu[4], cn[4], hn[4];
-            const float cin[4] = {cm.x, cm.y, cm.z, cm.w};
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int u = cu + jj;
-                gi[jj] = sigmoidf_(Gz[u * kWsLdg + ce]); gf[jj] = sigmoidf_(Gz[(64 + u) * kWsLdg + ce]);
-                go[jj] = sigmoidf_(Gz[(128 + u) * kWsLdg + ce]); gu[jj] = tanhf_(Gz[(192 + u) * kWsLdg + ce]);
-                cn[jj] = gf[jj] * cin[jj] + gi[jj] * gu[jj];
-                hn[jj] = go[jj] * tanhf_(cn[jj]);
-                Hn[u * kWsLdg + ce] = hn[jj];
-            }
-            if (e0 + ce < E) {
-                const float4 c4n = make_float4(cn[0], cn[1], cn[2], cn[3]), h4n = make_float4(hn[0], hn[1], hn[2], hn[3]);
-                if (advance) {
-                    float *st = state + ((long long)g * E + e0 + ce) * 2 * kL + cu;
-                    *reinterpret_cast<float4 *>(st) = c4n; *reinterpret_cast<float4 *>(st + kL) = h4n;
-                }
-                if (tslot >= 0) {                                  // what lstm_fwd_kernel<true> would store
-                    float *zr = Zc + (nb0 + ce) * kG4 + cu;
-                    st_stream4(zr, make_float4(gi[0], gi[1], gi[2], gi[3]));
-                    st_stream4(zr + 64, make_float4(gf[0], gf[1], gf[2], gf[3]));
-                    st_stream4(zr + 128, make_float4(go[0], go[1], go[2], go[3]));
-                    st_stream4(zr + 192, make_float4(gu[0], gu[1], gu[2], gu[3]));
-                    st_stream4(Ccc + (nb0 + ce) * kL + cu, c4n);
-                    st_stream4(Hhc + (nb0 + ce) * kL + cu, h4n);
-                }
-            }
+        if (tt > t0) head_finish(tt - 1);
+        // ---- interval 2: cell update of this tile | first layer of the next one (XH is free: the gate GEMM is done).
+        // vmcnt retires in order and counts stores: what was requested before the GEMM is consumed (or at least waited
+        // for) BEFORE this interval's ~30 streaming stores are issued, never behind them
+        const float4 cmn = stage_state(e0 + 32, nb0 + 32, more);
+#pragma unroll 1
+        for (int ph = 0; ph < 2; ++ph) {
+            if ((ph == 0) == (wave < 4)) cell(e0, nb0);
+            else if (more) first_layer();
+            WSTAMP();
         }
+        cm = cmn;
         __syncthreads();
         WSTAMP();
-        // ---- phase 4: head.  thread -> (instance tid & 31, output (tid >> 5) & 7, half of the units tid >> 8)
-        {
-            const int e = tid & 31, k0 = (tid >> 5) & 7, hf = tid >> 8;
-            float s0 = 0.f;
+    }
+    // ---- drain: a full group still waiting for its softmax, then the head of the last tile and its group
+    {
+        const int tl = t1 - 1;
+        if (tl - t0 >= 1 && (tl - 1 - t0) % kWsBuf == kWsBuf - 1) emit(32 * (tl - kWsBuf), kWsBuf);
+        float hs0 = 0.f;
+        const int e = tid & 31, k0 = (tid >> 5) & 7, hf = tid >> 8;
 #pragma unroll 8
-            for (int jj = 32 * hf; jj < 32 * hf + 32; ++jj) s0 += Hn[jj * kWsLdg + e] * WoS[jj * kOut + k0];
-            if (hf) LGp[e * kOut + k0] = s0;
-            __syncthreads();
-            const int slot = (tt - t0) % kWsBuf;
-            if (!hf) LG[(slot * 32 + e) * kOut + k0] = (s0 + LGp[e * kOut + k0]) + WoS[kL * kOut + k0];
-            if (slot == kWsBuf - 1 || tt == t1 - 1) {            // buffer full or last tile: emit (uniform branch)
-                __syncthreads();
-                emit(32 * (tt - slot), slot + 1);
-            }
-        }
+        for (int jj = 0; jj < 32; ++jj) hs0 += Hn[(32 * hf + jj) * kWsLdg + e] * WoS[(32 * hf + jj) * kOut + k0];
+        LGp[tid] = hs0;
         __syncthreads();
-        ov = nov; c4 = nc4; h4 = nh4; keep = nkeep;
-        WSTAMP();
+        head_finish(tl);
+        __syncthreads();
+        const int slot = (tl - t0) % kWsBuf;
+        emit(32 * (tl - slot), slot + 1);
     }
     if (stamp) dbg[63] = nstamp;
 #undef WSTAMP
@@ -1610,6 +1714,8 @@ struct tsc_model {
     std::vector<void *> allocs;
     int *n_act;
     int16_t *rowrange;          // [A][SMAX][2]
+    int dbg_tid;                // thread of workgroup 0 that writes the clock stamps (TSC_DBG_THREAD)
+    int *krange;                // [A][8][2]: first-layer MFMA steps (2 obs rows each) that feed hidden column tile w (ws forward)
     float *params, *grads, *ms, *WxT;
     float *Wg;                  // gate-interleaved copy of [Wx ; Wh] for the fused forward (interleave_gates_kernel)
     int wg_dirty;
@@ -1707,6 +1813,20 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
         }
     }
     TSC_HIP(tsc::upload<int16_t>(&m->rowrange, rr.data(), rr.size())); m->allocs.push_back(m->rowrange);
+    {   // per (agent, 32-column tile of the first layer): the obs rows with a structural non-zero in the tile, in MFMA steps
+        std::vector<int> kr((size_t)L.A * 8 * 2, 0);
+        for (int a = 0; a < L.A; ++a)
+            for (int w = 0; w < 8; ++w) {
+                int j0 = L.SMAX, j1 = 0;
+                for (int j = 0; j < L.SMAX; ++j) {
+                    const int lo = rr[((size_t)a * L.SMAX + j) * 2], hi = rr[((size_t)a * L.SMAX + j) * 2 + 1];
+                    if (lo < 32 * w + 32 && hi > 32 * w) { if (j < j0) j0 = j; j1 = j + 1; }
+                }
+                if (j1 <= j0) { j0 = 0; j1 = 0; }
+                kr[((size_t)a * 8 + w) * 2] = j0 / 2; kr[((size_t)a * 8 + w) * 2 + 1] = (j1 + 1) / 2;
+            }
+        TSC_HIP(tsc::upload<int>(&m->krange, kr.data(), kr.size())); m->allocs.push_back(m->krange);
+    }
     TSC_HIP(tsc::upload<int>(&m->n_act, cfg->n_act, L.A)); m->allocs.push_back(m->n_act);
     const long long E = n_env, T = m->T, N = E * T, G = L.G, A = L.A;
     MALLOC(m->params, float, m->nparam); MALLOC(m->grads, float, m->nparam); MALLOC(m->ms, float, m->nparam);
@@ -1719,7 +1839,8 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     MALLOC(m->r_act, int, N * A); MALLOC(m->r_rew, double, N * A);
     MALLOC(m->r_val, float, N * A); MALLOC(m->r_done, uint8_t, (T + 1) * E);
     MALLOC(m->Rs, float, N * A); MALLOC(m->Advs, float, N * A);
-    MALLOC(m->X1, float, G * N * L.H); MALLOC(m->Z, float, G * N * kG4);
+    MALLOC(m->X1, float, G * N * L.H + 32 * L.H);        // + one tile nobody reads: the ws forward's branch-free X1 store when the cache is off
+    MALLOC(m->Z, float, G * N * kG4);
     MALLOC(m->Hh, float, G * N * kL); MALLOC(m->Cc, float, G * N * kL); MALLOC(m->Hp, float, G * N * kL);
     MALLOC(m->dHh, float, G * N * kL); MALLOC(m->dL, float, G * N * kOut);
     MALLOC(m->norm2, double, A); MALLOC(m->stats, double, A * 4); MALLOC(m->norm_part, double, A * kNormParts);
@@ -1734,6 +1855,7 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     m->cached_next = 0;
     m->lds_fused = sizeof(float) * ((size_t)(L.H + 64) * kXLd + kL * kOut + kOut + 8);   // activations + head weights
     m->fused_fwd = !L.fc && (L.H % 32 == 0) && (L.SMAX <= 64) && (L.SMAX % 4 == 0) && ((L.H + 64) % 8 == 0) && m->lds_fused <= 160 * 1024;
+    if (const char *ev = getenv("TSC_DBG_THREAD")) m->dbg_tid = atoi(ev);
     if (const char *ev = getenv("TSC_UNFUSED_FWD")) if (atoi(ev)) m->fused_fwd = 0;
     m->fused_dw = !L.fc && (L.H == 224 || L.H == 160);
     if (const char *ev = getenv("TSC_UNFUSED_DW")) if (atoi(ev)) m->fused_dw = 0;
@@ -1744,7 +1866,7 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
         TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
-    m->lds_ws = sizeof(float) * ((size_t)32 * (L.H + 64 + 4) + 64 * kWsLdx + (size_t)kL * kWsLdg + (size_t)kG4 * kWsLdg + 528 + (kWsBuf + 1) * 32 * kOut + (size_t)L.SMAX * L.H);
+    m->lds_ws = sizeof(float) * ((size_t)32 * (L.H + 64 + 4) + 64 * kWsLdx + (size_t)kL * kWsLdg + (size_t)kG4 * kWsLdg + 528 + (kWsBuf + 2) * 32 * kOut + (size_t)L.SMAX * L.H);
     if (m->fused_fwd && (L.H == 224 || L.H == 160) && m->lds_ws <= 160 * 1024) {
         // weight-stationary variant (TSC_FWD_WS=0 falls back to the tile-per-workgroup kernel)
         const char *ev = getenv("TSC_FWD_WS");
@@ -1854,7 +1976,7 @@ static int model_forward(tsc_model *m, const float *obs, const uint8_t *done, fl
             if (S > (E + 31) / 32) S = (E + 31) / 32;
 #define TSC_WS(KS2) hipLaunchKernelGGL(policy_fwd_ws_kernel<KS2>, dim3((unsigned)(L.G * S)), dim3(512), m->lds_ws, m->stream, m->params, \
                                        L, m->n_act, obs, done, m->state_fw, (int)advance, E, S, pi, v, action, (unsigned long long)seed,     \
-                                       (unsigned long long)step, (int)tslot, (long long)m->T * E, m->X1, m->Z, m->Hh, m->Cc, m->Hp, m->dbg, m->Wg)
+                                       (unsigned long long)step, (int)tslot, (long long)m->T * E, m->X1, m->Z, m->Hh, m->Cc, m->Hp, m->dbg, m->Wg, m->krange, m->dbg_tid)
             if (L.H == 224) TSC_WS(144); else TSC_WS(112);
 #undef TSC_WS
             ps.stop();

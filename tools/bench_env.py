@@ -16,8 +16,8 @@ from deeprl_signal_control_amd.trainer import greedy_actions_large_grid
 
 
 def phase_names(n):
-    """Labels of the shader-clock stamps of step_kernel (with / without phase A1)."""
-    per = ['A1_%d', 'bar', 'A2_%d', 'bar', 'B%d', 'bar'] if n >= 1 + 5 * 6 + 4 else ['A%d', 'bar', 'B%d', 'bar']
+    """Labels of the shader-clock stamps of step_kernel (with / without the flat phase)."""
+    per = ['H%d', 'bar', 'F%d', 'bar', 'B%d', 'bar'] if n >= 1 + 5 * 6 + 4 else ['A%d', 'bar', 'B%d', 'bar']
     names = ['prologue'] + sum([[p % k if '%' in p else p for p in per] for k in range(5)], [])
     names += ['detectors', 'bar', 'obs', 'reward']
     return names + ['?'] * max(0, n - len(names))

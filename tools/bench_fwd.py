@@ -38,10 +38,12 @@ for label, fn in (('back to back', lambda: None), ('64 MB memset between', lambd
     n = buf[63]
     names = ['obs->LDS', 'fc (X1)', 'state', 'gates MFMA', 'barrier', 'cell', 'head']
     if n > 9:                                            # weight-stationary kernel: prologue, then 6 stamps per tile
-        names = ['prologue'] + sum([['obs%d' % i, 'fc+h%d' % i, 'gates%d' % i, 'bar%d' % i, 'cell%d' % i, 'head%d' % i] for i in range(10)], [])
+        names = ['prologue', 'fill'] + sum([['gates+head%d' % i, 'bar%d' % i, 'cell%d' % i, 'fc%d' % i, 'bar2_%d' % i] for i in range(12)], [])
     print('   phases (cycles): ' + ', '.join('%s=%d' % (names[i], buf[i + 1] - buf[i]) for i in range(n - 1)) + '  total=%d' % (buf[n - 1] - buf[0]))
     w = np.array(buf[64:], dtype=np.int64).reshape(nblk, 2)
     live = w[:, 1] > 0
+    if not live.any():
+        continue
     st = (w[live, 0] - w[live, 0].min()) / 100.0
     en = (w[live, 1] - w[live, 0].min()) / 100.0
     dur = en - st
