@@ -16,13 +16,13 @@
 // all-reduce.  The three input FCs (wave / fingerprint / wait) are one block-diagonal
 // [SMAX x H] matrix with structural zeros (kept zero by a row-range mask on its gradient).
 // Kernels (all fp32, v_mfma_f32_32x32x2_f32 for every contraction):
-//   rollout ......... policy_fwd_ws_kernel: one launch per control step, [Wx ; Wh] stationary in registers, also
-//                     fills the activation cache the update reads (policy_fwd_fused_kernel: tile-per-workgroup
+//   rollout ......... policy_fwd_ws_kernel: one launch per control step, [Wx ; Wh] stationary in registers, tiles
+//                     software-pipelined over two barrier intervals, also fills the activation cache the update reads (policy_fwd_fused_kernel: tile-per-workgroup
 //                     variant; grouped GEMMs + lstm_fwd + head_fwd: training-shape re-forward / FC policy)
-//   update .......... head_bwd -> lstm_bwd (Wh^T stationary in registers, dc/dh in registers over the n_step
+//   update .......... head_bwd2 (persistent, loss gradient + dH + dWo | dbo) -> lstm_bwd (Wh^T stationary in registers, dc/dh in registers over the n_step
 //                     time steps) -> dwxh (dWx | dWh | dbl, whole tower output in accumulators) -> dx1w1 (dX1 in
-//                     registers, chained into dW1 | db1) -> grad_norm -> rmsprop; dWo and the FC-policy path on
-//                     the grouped split-K GEMM (tsc_gemm.h)
+//                     registers, chained into dW1 | db1) -> grad_norm -> rmsprop; the FC-policy path on the grouped
+//                     split-K GEMM (tsc_gemm.h)
 #include "tsc_common.h"
 #include "tsc_gemm.h"
 #include "../../include/tsc.h"
@@ -913,12 +913,24 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
 // 64-instance tile and runs 1.56 rounds of latency-chain workgroups.  Here ONE 8-wave workgroup per (tower, fifth of
 // the instances) loads the weights ONCE into registers -- wave w owns gate columns [32w, 32w + 32) of [Wx ; Wh]
 // (KS2 = (H + 64) / 2 MFMA steps = 144 registers per lane) and, for w < H / 32, column tile w of W1 -- and then
-// walks its 32-instance tiles:
-//   obs -> LDS (k-major) -> X1 tile per wave (MFMA, W1 in LDS) -> LDS (instance-major, so the gate GEMM reads its A
-//   operand as 16-byte quads) -> gate tile per wave (KS2 MFMAs, [Wx;Wh] stationary) -> LDS [256][33] -> cell update with thread = (instance, 4 units): float4 state / cache traffic ->
-//   h -> LDS -> head -> softmax -> action.
-// G x S workgroups (S = 256 / G) ~ one per CU, every instance tile of a tower is a loop iteration instead of a
-// workgroup, the next tile's obs / state are prefetched under the gate MFMAs.
+// walks its 32-instance tiles as a software pipeline of TWO barrier intervals per tile (round 1: six):
+//   interval 1  gate tile of this wave for tile t (KS2 dependent MFMAs, [Wx;Wh] stationary, A = [X1 | h_prev] rows
+//               of XH read as 16-byte quads).  Riding in its issue shadow, placed by hand between the MFMAs: the head
+//               dot products of tile t-1, tile t's X1 rows streamed to the activation cache, tile t+1's obs -> LDS,
+//               the global prefetches of tile t+1's state and tile t+2's obs; every 8 tiles the softmax + sampling of
+//               the buffered logits.  Ends with the gate tile -> LDS [256][33].
+//   interval 2  cell update of tile t (thread = (instance, 4 units): float4 state / cache traffic, h -> LDS) and the
+//               first layer of tile t+1 (X1 tile per wave, W1 in LDS, only the K rows of W1's block that feed the
+//               tile).  Waves w and w+4 share a SIMD and run the two in opposite order: one is an exp / rcp chain, the
+//               other a dependent MFMA chain.
+// G x S workgroups (S = 256 / G) ~ one per CU; every instance tile of a tower is a loop iteration instead of a
+// workgroup.  Rules the kernel is built around (each cost 5-15 % when violated, measured):
+//   * vmcnt retires in order and counts stores: a prefetched register is consumed (or touched by an empty asm) BEFORE
+//     the interval's streaming stores are issued; stores inside the MFMA stream are branch-free (clamped duplicates, a
+//     spare tile behind the buffer when the cache is off) -- a conditional store splits the block and spills;
+//   * no spills at all: a spilled VGPR is reloaded through vmcnt, i.e. behind every store in flight.  Per-thread LDS /
+//     cache offsets are re-derived from an opaque copy of the thread index inside each interval instead of being
+//     hoisted (144 of the 256 VGPRs hold the weights), global addresses are uniform base + 32-bit lane offset.
 // ------------------------------------------------------------------------------------------------
 // The activation cache is written once per control step and not read before the update: streaming (non-temporal) stores
 // keep its 160 MB per launch from evicting the simulator's vehicle state out of L2 / the infinity cache between two
@@ -964,7 +976,7 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
     const int t0 = (int)((long long)n_tiles * sp / S), t1 = (int)((long long)n_tiles * (sp + 1) / S);
     const int a = g >> 1, tower = g & 1, SMAX = lay.SMAX;
     const float *P = params + (long long)g * lay.stride;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31;
     const int col = 32 * wave + li;
     {   // W1 -> LDS: eight 16-byte loads in flight per thread and round (one round for SMAX <= 64)
         const int tot = SMAX * H / 4;

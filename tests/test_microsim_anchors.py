@@ -50,3 +50,38 @@ def test_monaco_greedy_band():
     assert -260.0 < r < -100.0 and 538 <= peak <= 734                 # peak vehicles inside the published 538-734
     assert tot['departed'] + tot['pending'] > 2300                    # ~2383 vehicles demanded (A.4)
     assert r / -41.8 > 2.5                                            # several times MORE congested than SUMO's greedy run
+
+
+# Aggregates of real_net_experimental_data/eva_data/real_net_greedy_{traffic,trip,control}.csv (10 evaluation episodes of
+# the authors' SUMO run): the statistical counterpart of the evaluation tables this repo writes.
+PUBLISHED_MONACO_GREEDY = dict(avg_queue=0.51, avg_speed_mps=6.06, avg_wait_sec=65.5, peak_cars=322, trips=1945,
+                               trip_duration_sec=238.0, reward=-41.8)
+
+
+def test_monaco_greedy_eval_tables_vs_published():
+    """The recorded evaluation tables (envs/env.py:409-437,498-542 schema) of one greedy Monaco episode under this spec,
+    next to the published ones: every aggregate says the same thing as the reward anchor -- the spec's Monaco jams."""
+    from oracle.env_oracle import OracleEnv
+    scn = build_real_net('greedy', norm_wave=1.0, clip_wave=-1.0)
+    L = scn.agent_lanes.shape[1]
+    env = OracleEnv(scn, seed=10000, train_mode=False, test_seeds=(10000,), is_record=True)
+    ob = env.reset(0)
+    while True:
+        w = np.zeros((scn.n_agent, L))
+        for a, o in enumerate(ob):
+            w[a, :len(o)] = o
+        ob, r, done, g = env.step(list(greedy_actions(scn, w)))
+        if done:
+            break
+    env.collect_tripinfo()
+    traffic, trips = env.traffic_data, env.trip_data
+    assert len(traffic) == 3600 and set(traffic[0]) >= {'avg_queue', 'avg_speed_mps', 'avg_wait_sec', 'number_total_car'}
+    ours = dict(avg_queue=np.mean([t['avg_queue'] for t in traffic]), avg_speed_mps=np.mean([t['avg_speed_mps'] for t in traffic]),
+                avg_wait_sec=np.mean([t['avg_wait_sec'] for t in traffic]), peak_cars=max(t['number_total_car'] for t in traffic),
+                trips=len(trips))
+    # today: queue 1.71 veh/lane, 1.96 m/s, 395 s mean wait, 644 concurrent vehicles, 355 completed trips
+    assert 1.0 < ours['avg_queue'] < 2.5 and 1.0 < ours['avg_speed_mps'] < 3.5 and 200 < ours['avg_wait_sec'] < 600
+    assert 500 < ours['peak_cars'] < 800 and 250 < ours['trips'] < 600
+    pub = PUBLISHED_MONACO_GREEDY
+    assert ours['avg_queue'] > 2 * pub['avg_queue'] and ours['avg_speed_mps'] < 0.6 * pub['avg_speed_mps']
+    assert ours['trips'] < 0.4 * pub['trips']                         # SUMO's run completes ~1945 trips per episode
