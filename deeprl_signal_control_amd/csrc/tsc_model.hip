@@ -190,6 +190,7 @@ __global__ void __launch_bounds__(256, PF ? 1 : 2) lstm_fwd_kernel(const float *
 // The step inputs are fetched four accumulator rows at a time (no next-step prefetch: the registers hold Wh^T).
 // ------------------------------------------------------------------------------------------------
 constexpr int kDzLd = 64 + 4;
+constexpr int QR = 8;            // accumulator rows per load batch of lstm_bwd (4: quarters, 8: halves)
 
 __global__ void __launch_bounds__(256, 2) lstm_bwd_kernel(const float *__restrict__ params, Layout lay, float *Z,
                                                          const float *Cc, const float *state_bw, const float *dH,
@@ -224,14 +225,14 @@ __global__ void __launch_bounds__(256, 2) lstm_bwd_kernel(const float *__restric
         const uint8_t *dt = done + nt;
         unsigned keepbits = 0;
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            float gi[4], gf[4], go[4], gu[4], cc[4], cpv[4], dhi[4], kp[4];
-            int er[4];
+        for (int qd = 0; qd < 16 / QR; ++qd) {
+            float gi[QR], gf[QR], go[QR], gu[QR], cc[QR], cpv[QR], dhi[QR], kp[QR];
+            int er[QR];
             int zq = 0;
             asm volatile("" : "+v"(zq));                // lane offsets are formed here every step, not hoisted out of the t loop and spilled
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = 4 * qd + q;
+            for (int q = 0; q < QR; ++q) {
+                const int r = QR * qd + q;
                 er[q] = r0 + (r & 3) + 8 * (r >> 2) + 4 * kh + zq;
                 const int e = e0 + er[q] < E ? e0 + er[q] : E - 1;
                 const unsigned oz = (unsigned)(e * kG4 + j) * 4u, oc = (unsigned)(e * kL + j) * 4u;
@@ -241,8 +242,8 @@ __global__ void __launch_bounds__(256, 2) lstm_bwd_kernel(const float *__restric
                 kp[q] = 1.0f - (float)dt[e];
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = 4 * qd + q;
+            for (int q = 0; q < QR; ++q) {
+                const int r = QR * qd + q;
                 const float ig = gi[q], fg = gf[q], og = go[q], ug = gu[q];
                 const float keep = kp[q];
                 const float cp = cpv[q] * keep;
