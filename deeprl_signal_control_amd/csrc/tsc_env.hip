@@ -136,6 +136,9 @@ __device__ __forceinline__ bool sig_open(int tl, int k, int a, int w, float x, f
     return false;
 }
 
+// dimensions of the reference's large_grid (SPEC 1 of step_kernel; checked against the scenario at create time)
+constexpr int kLG_NLP = 192, kLG_NLA = 128, kLG_NU = 81, kLG_NR = 12, kLG_A = 25, kLG_KMAX = 12;
+
 struct Smem {
     int *mv;                                   // [NU*NR]
     int *n; float *tx, *tv, *hx, *hv; uint32_t *hm;   // lane summaries [NLA]
@@ -272,11 +275,14 @@ __global__ void fingerprint_kernel(EnvDev P, const float *pi) {
 // grid fits the chip with no slack, and whenever another kernel ran in between (i.e. always, in the training
 // loop) XCD 0 admitted ~30 workgroups one full round late -> 178 us became 316 us per step
 // (tools/bench_env.py, tsc_env_debug_clock).  The cap costs ~120 B of scratch per lane and 8 % in isolation.
-template <int MAXT, bool HELP, bool REC = false, int KF = 4>      // REC: evaluation recording (plain walk only); KF: vehicles per thread and super-round of the flat phase
+// SPEC 1: the table dimensions of the reference's large_grid are compile-time constants (LDS offsets and index products
+// fold into immediates: the kernel holds > 100 scalar values otherwise and reloads the spilled ones with v_readlane)
+template <int MAXT, bool HELP, bool REC = false, int KF = 4, int SPEC = 0>      // REC: evaluation recording (plain walk only); KF: vehicles per thread and super-round of the flat phase
 __global__ void __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1)
 step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, double *__restrict__ reward,
             double *__restrict__ greward, uint8_t *__restrict__ done, int train_mode) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    if constexpr (SPEC == 1) { P.NLP = kLG_NLP; P.NLA = kLG_NLA; P.NU = kLG_NU; P.NR = kLG_NR; P.A = kLG_A; P.KMAX = kLG_KMAX; }
     Smem s = carve(smem_raw, P);
     const int e = blockIdx.x, l = threadIdx.x, NLP = P.NLP, NLA = P.NLA, NR = P.NR;
     const bool lane = l < P.NU;             // lanes >= NU are never entered by any route: always empty
@@ -578,71 +584,85 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             int round = 0;
             for (int base = 0; base < total; base += kF * (int)blockDim.x, ++round) {
                 const float carry_round = round > 0 ? s.wtail[((round - 1) & 1) * 16 + nwv - 1] : INFINITY;
+                // A wavefront whose first flat index is past the total has no vehicle in this (last) super-round: it only
+                // keeps the barrier.  The kernel is VALU-issue bound and the four workgroups of a CU share its SIMDs, so the
+                // ~600 instructions such a wave would run on clamped indices are real time for the others (on average half a
+                // super-round: 17-25 % of the phase at 2-3 super-rounds).
+                const bool wave_on = base + kF * (int)((unsigned)l & ~63u) < total;
                 int eq[kF], ei[kF];
                 float x[kF], v[kF], sf[kF], px[kF], pv[kF];
                 uint32_t m[kF];
                 bool act[kF];
-#pragma unroll
-                for (int u = 0; u < kF; ++u) {
-                    const int k = base + kF * l + u;
-                    act[u] = k < total;
-                    int w = 0, kk = act[u] ? k : total - 1;       // clamped: locate and load unconditionally
-                    for (; w < nseg - 1; ++w) {
-                        const int c = s.wtot[w];
-                        if (kk < c) break;
-                        kk -= c;
-                    }
-                    const int *pre = s.pre + (w << 6);
-                    int lo = 0;                                   // smallest j with pre[j] > kk
-#pragma unroll
-                    for (int st = 32; st; st >>= 1) if (pre[lo + st - 1] <= kk) lo += st;
-                    const int q = (w << 6) + lo;
-                    const int i = kk - (lo ? pre[lo - 1] : 0) + 1;
-                    eq[u] = q; ei[u] = i;
-                    const unsigned ob = (unsigned)(i * NLP + q) * 4u, pb = ob - (unsigned)NLP * 4u;
-                    x[u] = ldg(X, ob); v[u] = ldg(V, ob); sf[u] = ldg(SF, ob); m[u] = ldg(M, ob);
-                    px[u] = ldg(X, pb); pv[u] = ldg(V, pb);
-                }
-                if (round > 0 && l == 0 && ei[0] > 1) { px[0] = s.hz[0]; pv[0] = s.hz[1]; }   // overwritten by the previous super-round
                 float vn[kF], a[kF], key[kF], loc[kF];
                 bool run0[kF];
-                float run = INFINITY;
-                bool first_run = true;
+                float pvs = INFINITY;
+                int pfs = 1;
 #pragma unroll
                 for (int u = 0; u < kF; ++u) {
-                    const int q = eq[u];
-                    const float Lq = s.len[q];
-                    const int mvp = s.mv[q * NR + (int)(m[u] >> 16)];
-                    const float v0 = s.vmax[q] * sf[u];
-                    const bool open = sig_open(mv_tl(mvp), mv_k(mvp), s.node[q], (int)(m[u] & 0xFFFFu), x[u], v[u], Lq, link, P.KMAX, P.teleport);
-                    float vv = follow(v[u], v0, true, (px[u] - kLen) - x[u], pv[u], kS0);
-                    if (!open) {
-                        const float v2 = follow(v[u], v0, true, Lq - x[u], 0.0f, 0.0f);
-                        if (v2 < vv) vv = v2;
+                    eq[u] = 0; ei[u] = 0; x[u] = v[u] = sf[u] = px[u] = pv[u] = 0.0f; m[u] = 0u; act[u] = false;
+                    vn[u] = a[u] = 0.0f; key[u] = loc[u] = INFINITY; run0[u] = true;
+                }
+                if (wave_on) {
+    #pragma unroll
+                    for (int u = 0; u < kF; ++u) {
+                        const int k = base + kF * l + u;
+                        act[u] = k < total;
+                        int w = 0, kk = act[u] ? k : total - 1;       // clamped: locate and load unconditionally
+                        for (; w < nseg - 1; ++w) {
+                            const int c = s.wtot[w];
+                            if (kk < c) break;
+                            kk -= c;
+                        }
+                        const int *pre = s.pre + (w << 6);
+                        int lo = 0;                                   // smallest j with pre[j] > kk
+    #pragma unroll
+                        for (int st = 32; st; st >>= 1) if (pre[lo + st - 1] <= kk) lo += st;
+                        const int q = (w << 6) + lo;
+                        const int i = kk - (lo ? pre[lo - 1] : 0) + 1;
+                        eq[u] = q; ei[u] = i;
+                        const unsigned ob = (unsigned)(i * NLP + q) * 4u, pb = ob - (unsigned)NLP * 4u;
+                        x[u] = ldg(X, ob); v[u] = ldg(V, ob); sf[u] = ldg(SF, ob); m[u] = ldg(M, ob);
+                        px[u] = ldg(X, pb); pv[u] = ldg(V, pb);
                     }
-                    vn[u] = vv;
-                    float aa = x[u] + vv;
-                    if (aa > Lq) aa = Lq;
-                    a[u] = aa;
-                    const bool live = act[u] && ei[u] > s.nc[q];
-                    act[u] = live;
-                    key[u] = live ? aa + (float)(5 * ei[u]) : INFINITY;
-                    if (u > 0 && eq[u] != eq[u - 1]) { run = INFINITY; first_run = false; }
-                    loc[u] = run; run0[u] = first_run;
-                    run = fminf(run, key[u]);
+                    if (round > 0 && l == 0 && ei[0] > 1) { px[0] = s.hz[0]; pv[0] = s.hz[1]; }   // overwritten by the previous super-round
+                    float run = INFINITY;
+                    bool first_run = true;
+    #pragma unroll
+                    for (int u = 0; u < kF; ++u) {
+                        const int q = eq[u];
+                        const float Lq = s.len[q];
+                        const int mvp = s.mv[q * NR + (int)(m[u] >> 16)];
+                        const float v0 = s.vmax[q] * sf[u];
+                        const bool open = sig_open(mv_tl(mvp), mv_k(mvp), s.node[q], (int)(m[u] & 0xFFFFu), x[u], v[u], Lq, link, P.KMAX, P.teleport);
+                        float vv = follow(v[u], v0, true, (px[u] - kLen) - x[u], pv[u], kS0);
+                        if (!open) {
+                            const float v2 = follow(v[u], v0, true, Lq - x[u], 0.0f, 0.0f);
+                            if (v2 < vv) vv = v2;
+                        }
+                        vn[u] = vv;
+                        float aa = x[u] + vv;
+                        if (aa > Lq) aa = Lq;
+                        a[u] = aa;
+                        const bool live = act[u] && ei[u] > s.nc[q];
+                        act[u] = live;
+                        key[u] = live ? aa + (float)(5 * ei[u]) : INFINITY;
+                        if (u > 0 && eq[u] != eq[u - 1]) { run = INFINITY; first_run = false; }
+                        loc[u] = run; run0[u] = first_run;
+                        run = fminf(run, key[u]);
+                    }
+                    // segmented inclusive min-scan of the threads' last runs over the wavefront
+                    float sv = run;
+                    int sfl = (!first_run || ei[0] == 1) ? 1 : 0;
+    #pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const float ov = __shfl_up(sv, d, 64);
+                        const int of = __shfl_up(sfl, d, 64);
+                        if (wl >= d && !sfl) { sv = fminf(sv, ov); sfl |= of; }
+                    }
+                    pvs = __shfl_up(sv, 1, 64);
+                    pfs = __shfl_up(sfl, 1, 64);
+                    if (wl == 63) s.wtail[(round & 1) * 16 + wv] = sv;
                 }
-                // segmented inclusive min-scan of the threads' last runs over the wavefront
-                float sv = run;
-                int sfl = (!first_run || ei[0] == 1) ? 1 : 0;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const float ov = __shfl_up(sv, d, 64);
-                    const int of = __shfl_up(sfl, d, 64);
-                    if (wl >= d && !sfl) { sv = fminf(sv, ov); sfl |= of; }
-                }
-                const float pvs = __shfl_up(sv, 1, 64);
-                const int pfs = __shfl_up(sfl, 1, 64);
-                if (wl == 63) s.wtail[(round & 1) * 16 + wv] = sv;
                 if (l == (int)blockDim.x - 1) { s.hz[2] = x[kF - 1]; s.hz[3] = v[kF - 1]; }
                 __syncthreads();
                 if (l == 0) { s.hz[0] = s.hz[2]; s.hz[1] = s.hz[3]; }       // read by thread 0 after the next barrier only
@@ -898,6 +918,7 @@ struct tsc_env {
     size_t smem;
     int threads;                    // workgroup size of step_kernel
     int kf;                         // flat-phase vehicles per thread (measurement knob TSC_ENV_KF)
+    int spec;                       // 1: the scenario has the large_grid table dimensions -> specialised step_kernel (TSC_ENV_SPEC=0: off)
     uint32_t *d_seeds;
 };
 
@@ -1126,6 +1147,10 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     // barriers do not pay for the registers); TSC_ENV_KF = 2 / 4 keep the wider variants for A/B runs
     h->kf = 1;
     if (const char *ev = getenv("TSC_ENV_KF")) { const int kv = atoi(ev); h->kf = (kv == 2 || kv == 4) ? kv : 1; }
+    h->spec = (h->P.NLP == kLG_NLP && h->P.NLA == kLG_NLA && h->P.NU == kLG_NU && h->P.NR == kLG_NR && h->P.A == kLG_A &&
+               h->P.KMAX == kLG_KMAX) ? 1 : 0;
+    if (const char *ev = getenv("TSC_ENV_SPEC")) if (!atoi(ev)) h->spec = 0;
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     if (const char *ev = getenv("TSC_ENV_THREADS")) {       // measurement knob: extra helper wavefronts
@@ -1270,6 +1295,9 @@ int tsc_env_step(tsc_env *h, const int32_t *action_dev, float *obs_dev, double *
 #define TSC_STEP_KF(KF)                                                                                           \
     hipLaunchKernelGGL((step_kernel<256, true, false, KF>), dim3(h->P.E), dim3(h->threads), h->smem, h->stream, h->P, action_dev, \
                        obs_dev, reward_dev, global_reward_dev, done_dev, (int)train_mode)
+    else if (h->threads <= 256 && h->P.help && h->kf == 1 && h->spec == 1)
+        hipLaunchKernelGGL((step_kernel<256, true, false, 1, 1>), dim3(h->P.E), dim3(h->threads), h->smem, h->stream, h->P, action_dev,
+                           obs_dev, reward_dev, global_reward_dev, done_dev, (int)train_mode);
     else if (h->threads <= 256 && h->P.help && h->kf == 1) TSC_STEP_KF(1);
     else if (h->threads <= 256 && h->P.help && h->kf == 2) TSC_STEP_KF(2);
 #undef TSC_STEP_KF
