@@ -1143,14 +1143,18 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     h->smem = smem_bytes(P);
     if (h->smem > 160 * 1024) return tsc::fail("tsc_env_create: LDS need %zu B > 160 KiB", h->smem);
     h->threads = (P.help && P.NLA < 256) ? 256 : P.NLA;
-    // vehicles per thread and super-round of the flat phase: 1 measured best (296 M env-steps/s; 2: 294, 4: 284 -- fewer
-    // barriers do not pay for the registers); TSC_ENV_KF = 2 / 4 keep the wider variants for A/B runs
-    h->kf = 1;
-    if (const char *ev = getenv("TSC_ENV_KF")) { const int kv = atoi(ev); h->kf = (kv == 2 || kv == 4) ? kv : 1; }
+    // the reference's large_grid gets the instantiation with compile-time table dimensions (TSC_ENV_SPEC=0: off)
     h->spec = (h->P.NLP == kLG_NLP && h->P.NLA == kLG_NLA && h->P.NU == kLG_NU && h->P.NR == kLG_NR && h->P.A == kLG_A &&
                h->P.KMAX == kLG_KMAX) ? 1 : 0;
     if (const char *ev = getenv("TSC_ENV_SPEC")) if (!atoi(ev)) h->spec = 0;
+    // vehicles per thread and super-round of the flat phase (TSC_ENV_KF = 1 / 2 / 4 for A/B runs).  With runtime dimensions
+    // 1 is best (296 M env-steps/s; 2: 294, 4: 284 -- fewer barriers do not pay for the registers); the specialised kernel
+    // has the registers for 2 (env step 11.5 -> 10.7 ms per rollout; 4 spills: 11.4)
+    h->kf = h->spec ? 2 : 1;
+    if (const char *ev = getenv("TSC_ENV_KF")) { const int kv = atoi(ev); h->kf = (kv == 2 || kv == 4) ? kv : 1; }
+    if (h->spec && h->kf == 4) h->spec = 0;                  // (no specialised instantiation of the 4-wide variant)
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     if (const char *ev = getenv("TSC_ENV_THREADS")) {       // measurement knob: extra helper wavefronts
@@ -1298,6 +1302,10 @@ int tsc_env_step(tsc_env *h, const int32_t *action_dev, float *obs_dev, double *
     else if (h->threads <= 256 && h->P.help && h->kf == 1 && h->spec == 1)
         hipLaunchKernelGGL((step_kernel<256, true, false, 1, 1>), dim3(h->P.E), dim3(h->threads), h->smem, h->stream, h->P, action_dev,
                            obs_dev, reward_dev, global_reward_dev, done_dev, (int)train_mode);
+    else if (h->threads <= 256 && h->P.help && h->kf == 2 && h->spec == 1)
+        hipLaunchKernelGGL((step_kernel<256, true, false, 2, 1>), dim3(h->P.E), dim3(h->threads), h->smem, h->stream, h->P, action_dev,
+                           obs_dev, reward_dev, global_reward_dev, done_dev, (int)train_mode);
+
     else if (h->threads <= 256 && h->P.help && h->kf == 1) TSC_STEP_KF(1);
     else if (h->threads <= 256 && h->P.help && h->kf == 2) TSC_STEP_KF(2);
 #undef TSC_STEP_KF

@@ -149,15 +149,17 @@ def test_helper_threads_equal_plain_walk(monkeypatch):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize('kf', ['1', '2', '4'])
-def test_flat_phase_super_rounds_at_saturation(kf, monkeypatch):
+@pytest.mark.parametrize('kf,spec', [('1', '1'), ('2', '1'), ('4', '1'), ('1', '0'), ('2', '0')])
+def test_flat_phase_super_rounds_at_saturation(kf, spec, monkeypatch):
     """More queued vehicles than one super-round of the flat phase holds (kF x 256 per round): tripled demand and random
     phases fill most lanes to capacity.  The chain scan then crosses wavefronts and super-rounds (LDS carries, the saved
     old state of the previous round's last vehicle); obs, rewards and the full vehicle state stay bit-identical to the
-    oracle's sequential walk, for every kF variant of the kernel."""
+    oracle's sequential walk, for every kF variant of the kernel, with the table dimensions as compile-time constants
+    (the large_grid instantiation, spec 1) and as launch parameters (spec 0: what Monaco and small_grid run)."""
     from deeprl_signal_control_amd.env import VecTrafficEnv
     from oracle.env_oracle import OracleEnv
     monkeypatch.setenv('TSC_ENV_KF', kf)
+    monkeypatch.setenv('TSC_ENV_SPEC', spec)
     scn = build_large_grid('ma2c', peak_flow1=3300, peak_flow2=2800)
     E = 6
     env = VecTrafficEnv(scn, E, seed=9)
