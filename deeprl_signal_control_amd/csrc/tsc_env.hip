@@ -138,6 +138,7 @@ __device__ __forceinline__ bool sig_open(int tl, int k, int a, int w, float x, f
 
 // dimensions of the reference's large_grid (SPEC 1 of step_kernel; checked against the scenario at create time)
 constexpr int kLG_NLP = 192, kLG_NLA = 128, kLG_NU = 81, kLG_NR = 12, kLG_A = 25, kLG_KMAX = 12;
+constexpr int kLG_PMAX = 5, kLG_LMAX = 6, kLG_NBR = 4, kLG_CTRL = 5, kLG_YELLOW = 2, kLG_TELEPORT = 600;
 
 struct Smem {
     int *mv;                                   // [NU*NR]
@@ -282,7 +283,10 @@ __global__ void __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1)
 step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, double *__restrict__ reward,
             double *__restrict__ greward, uint8_t *__restrict__ done, int train_mode) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    if constexpr (SPEC == 1) { P.NLP = kLG_NLP; P.NLA = kLG_NLA; P.NU = kLG_NU; P.NR = kLG_NR; P.A = kLG_A; P.KMAX = kLG_KMAX; }
+    if constexpr (SPEC == 1) {
+        P.NLP = kLG_NLP; P.NLA = kLG_NLA; P.NU = kLG_NU; P.NR = kLG_NR; P.A = kLG_A; P.KMAX = kLG_KMAX;
+        P.PMAX = kLG_PMAX; P.LMAX = kLG_LMAX; P.NBR = kLG_NBR; P.ctrl = kLG_CTRL; P.yellow = kLG_YELLOW; P.teleport = kLG_TELEPORT;
+    }
     Smem s = carve(smem_raw, P);
     const int e = blockIdx.x, l = threadIdx.x, NLP = P.NLP, NLA = P.NLA, NR = P.NR;
     const bool lane = l < P.NU;             // lanes >= NU are never entered by any route: always empty
@@ -392,6 +396,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     TSC_STAMP();
 
     int d_wave = 0, d_halt = 0;                     // detector counts, taken during the last simulated second
+#pragma unroll 1
     for (int sub = 0; sub < P.ctrl; ++sub, ++t) {
         const uint8_t *link = sub < P.yellow ? s.link_y : s.link_g;
         const bool last = sub == P.ctrl - 1;
@@ -1145,7 +1150,8 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     h->threads = (P.help && P.NLA < 256) ? 256 : P.NLA;
     // the reference's large_grid gets the instantiation with compile-time table dimensions (TSC_ENV_SPEC=0: off)
     h->spec = (h->P.NLP == kLG_NLP && h->P.NLA == kLG_NLA && h->P.NU == kLG_NU && h->P.NR == kLG_NR && h->P.A == kLG_A &&
-               h->P.KMAX == kLG_KMAX) ? 1 : 0;
+               h->P.KMAX == kLG_KMAX && h->P.PMAX == kLG_PMAX && h->P.LMAX == kLG_LMAX && h->P.NBR == kLG_NBR &&
+               h->P.ctrl == kLG_CTRL && h->P.yellow == kLG_YELLOW && h->P.teleport == kLG_TELEPORT) ? 1 : 0;
     if (const char *ev = getenv("TSC_ENV_SPEC")) if (!atoi(ev)) h->spec = 0;
     // vehicles per thread and super-round of the flat phase (TSC_ENV_KF = 1 / 2 / 4 for A/B runs).  With runtime dimensions
     // 1 is best (296 M env-steps/s; 2: 294, 4: 284 -- fewer barriers do not pay for the registers); the specialised kernel
