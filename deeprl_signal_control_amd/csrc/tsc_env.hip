@@ -136,9 +136,12 @@ __device__ __forceinline__ bool sig_open(int tl, int k, int a, int w, float x, f
     return false;
 }
 
-// dimensions of the reference's large_grid (SPEC 1 of step_kernel; checked against the scenario at create time)
-constexpr int kLG_NLP = 192, kLG_NLA = 128, kLG_NU = 81, kLG_NR = 12, kLG_A = 25, kLG_KMAX = 12;
-constexpr int kLG_PMAX = 5, kLG_LMAX = 6, kLG_NBR = 4, kLG_CTRL = 5, kLG_YELLOW = 2, kLG_TELEPORT = 600;
+// Table dimensions of the reference's scenarios as compile-time constants (SPEC of step_kernel; matched against the
+// scenario at create time): 1 = large_grid (5x5), 2 = real_net (Monaco, lane chains contracted)
+struct SpecDims { int NLP, NLA, NU, NR, A, KMAX, PMAX, LMAX, NBR, ctrl, yellow, teleport; };
+constexpr SpecDims kSpec[3] = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+                               {192, 128, 81, 12, 25, 12, 5, 6, 4, 5, 2, 600},
+                               {192, 128, 113, 16, 28, 22, 6, 11, 5, 5, 2, 300}};
 
 struct Smem {
     int *mv;                                   // [NU*NR]
@@ -283,9 +286,10 @@ __global__ void __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1)
 step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, double *__restrict__ reward,
             double *__restrict__ greward, uint8_t *__restrict__ done, int train_mode) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    if constexpr (SPEC == 1) {
-        P.NLP = kLG_NLP; P.NLA = kLG_NLA; P.NU = kLG_NU; P.NR = kLG_NR; P.A = kLG_A; P.KMAX = kLG_KMAX;
-        P.PMAX = kLG_PMAX; P.LMAX = kLG_LMAX; P.NBR = kLG_NBR; P.ctrl = kLG_CTRL; P.yellow = kLG_YELLOW; P.teleport = kLG_TELEPORT;
+    if constexpr (SPEC > 0) {
+        constexpr SpecDims D = kSpec[SPEC];
+        P.NLP = D.NLP; P.NLA = D.NLA; P.NU = D.NU; P.NR = D.NR; P.A = D.A; P.KMAX = D.KMAX;
+        P.PMAX = D.PMAX; P.LMAX = D.LMAX; P.NBR = D.NBR; P.ctrl = D.ctrl; P.yellow = D.yellow; P.teleport = D.teleport;
     }
     Smem s = carve(smem_raw, P);
     const int e = blockIdx.x, l = threadIdx.x, NLP = P.NLP, NLA = P.NLA, NR = P.NR;
@@ -1148,19 +1152,24 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     h->smem = smem_bytes(P);
     if (h->smem > 160 * 1024) return tsc::fail("tsc_env_create: LDS need %zu B > 160 KiB", h->smem);
     h->threads = (P.help && P.NLA < 256) ? 256 : P.NLA;
-    // the reference's large_grid gets the instantiation with compile-time table dimensions (TSC_ENV_SPEC=0: off)
-    h->spec = (h->P.NLP == kLG_NLP && h->P.NLA == kLG_NLA && h->P.NU == kLG_NU && h->P.NR == kLG_NR && h->P.A == kLG_A &&
-               h->P.KMAX == kLG_KMAX && h->P.PMAX == kLG_PMAX && h->P.LMAX == kLG_LMAX && h->P.NBR == kLG_NBR &&
-               h->P.ctrl == kLG_CTRL && h->P.yellow == kLG_YELLOW && h->P.teleport == kLG_TELEPORT) ? 1 : 0;
+    // the reference's large_grid / Monaco get the instantiation with compile-time table dimensions (TSC_ENV_SPEC=0: off)
+    h->spec = 0;
+    for (int k = 1; k < 3; ++k) {
+        const SpecDims &D = kSpec[k];
+        if (P.NLP == D.NLP && P.NLA == D.NLA && P.NU == D.NU && P.NR == D.NR && P.A == D.A && P.KMAX == D.KMAX && P.PMAX == D.PMAX &&
+            P.LMAX == D.LMAX && P.NBR == D.NBR && P.ctrl == D.ctrl && P.yellow == D.yellow && P.teleport == D.teleport) h->spec = k;
+    }
     if (const char *ev = getenv("TSC_ENV_SPEC")) if (!atoi(ev)) h->spec = 0;
     // vehicles per thread and super-round of the flat phase (TSC_ENV_KF = 1 / 2 / 4 for A/B runs).  With runtime dimensions
     // 1 is best (296 M env-steps/s; 2: 294, 4: 284 -- fewer barriers do not pay for the registers); the specialised kernel
     // has the registers for 2 (env step 11.5 -> 10.7 ms per rollout; 4 spills: 11.4)
-    h->kf = h->spec ? 2 : 1;
+    h->kf = h->spec == 1 ? 2 : 1;                            // (Monaco, spec 2: 330 M env-steps/s with 1, 323 M with 2)
     if (const char *ev = getenv("TSC_ENV_KF")) { const int kv = atoi(ev); h->kf = (kv == 2 || kv == 4) ? kv : 1; }
     if (h->spec && h->kf == 4) h->spec = 0;                  // (no specialised instantiation of the 4-wide variant)
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     if (const char *ev = getenv("TSC_ENV_THREADS")) {       // measurement knob: extra helper wavefronts
@@ -1305,13 +1314,14 @@ int tsc_env_step(tsc_env *h, const int32_t *action_dev, float *obs_dev, double *
 #define TSC_STEP_KF(KF)                                                                                           \
     hipLaunchKernelGGL((step_kernel<256, true, false, KF>), dim3(h->P.E), dim3(h->threads), h->smem, h->stream, h->P, action_dev, \
                        obs_dev, reward_dev, global_reward_dev, done_dev, (int)train_mode)
-    else if (h->threads <= 256 && h->P.help && h->kf == 1 && h->spec == 1)
-        hipLaunchKernelGGL((step_kernel<256, true, false, 1, 1>), dim3(h->P.E), dim3(h->threads), h->smem, h->stream, h->P, action_dev,
-                           obs_dev, reward_dev, global_reward_dev, done_dev, (int)train_mode);
-    else if (h->threads <= 256 && h->P.help && h->kf == 2 && h->spec == 1)
-        hipLaunchKernelGGL((step_kernel<256, true, false, 2, 1>), dim3(h->P.E), dim3(h->threads), h->smem, h->stream, h->P, action_dev,
-                           obs_dev, reward_dev, global_reward_dev, done_dev, (int)train_mode);
-
+#define TSC_STEP_SPEC(KF, SP)                                                                                       \
+    hipLaunchKernelGGL((step_kernel<256, true, false, KF, SP>), dim3(h->P.E), dim3(h->threads), h->smem, h->stream, h->P, action_dev, \
+                       obs_dev, reward_dev, global_reward_dev, done_dev, (int)train_mode)
+    else if (h->threads <= 256 && h->P.help && h->kf == 1 && h->spec == 1) TSC_STEP_SPEC(1, 1);
+    else if (h->threads <= 256 && h->P.help && h->kf == 2 && h->spec == 1) TSC_STEP_SPEC(2, 1);
+    else if (h->threads <= 256 && h->P.help && h->kf == 1 && h->spec == 2) TSC_STEP_SPEC(1, 2);
+    else if (h->threads <= 256 && h->P.help && h->kf == 2 && h->spec == 2) TSC_STEP_SPEC(2, 2);
+#undef TSC_STEP_SPEC
     else if (h->threads <= 256 && h->P.help && h->kf == 1) TSC_STEP_KF(1);
     else if (h->threads <= 256 && h->P.help && h->kf == 2) TSC_STEP_KF(2);
 #undef TSC_STEP_KF
