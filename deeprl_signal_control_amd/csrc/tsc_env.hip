@@ -15,8 +15,10 @@
 // per-lane front-to-back walk issues fully coalesced loads.  Everything lanes need from *other* lanes
 // (tail/head summaries, signal states, the per-step hand-off outbox, the route tables) is staged in LDS; one
 // control step (2 yellow + 3 green simulated seconds, detectors, obs, reward) is a single launch.  Per
-// simulated second: phase A1 (all threads: car-following of every queued vehicle, load-balanced), phase A2
-// (lane threads: the sequential walk), phase B (gather + demand) -- three barriers (see step_kernel).
+// simulated second: phase H (lane threads: the platoon that crosses and the first vehicle that stays), phase F (all
+// threads: every other queued vehicle in a flat, load-balanced order -- car-following from the old state, the queue
+// constraint as a segmented prefix-min scan over the wavefront), phase B (gather + demand) (see step_kernel).  The
+// reference's large_grid and Monaco run instantiations whose table dimensions are compile-time constants (kSpec).
 //
 // Arithmetic is fp32 with one rounding per operation (-ffp-contract=off, IEEE div/sqrt) so the
 // vehicle state is bit-identical to the CPU oracle; obs/reward are computed in float64 exactly
@@ -266,9 +268,9 @@ __global__ void fingerprint_kernel(EnvDev P, const float *pi) {
 }
 
 // Work decomposition of one workgroup (= one env instance):
-//   * lane threads (l < NLA) own one lane each: the front-to-back walk (phase A2), the gather (phase B);
-//   * with HELP, phase A1 first evaluates the car-following law of every queued vehicle (slot >= 1) with ALL
-//     threads of the workgroup, one vehicle per thread in a flat, load-balanced order (prefix sum over the lane
+//   * lane threads (l < NLA) own one lane each: the head walk (phase H), the gather (phase B);
+//   * with HELP, phase F evaluates the car-following law of every queued vehicle behind the first one that stays with
+//     ALL threads of the workgroup, KF vehicles per thread in a flat, load-balanced order (prefix sum over the lane
 //     counts + a 6-step binary search).  A queued vehicle that is not the head of a platoon crossing in this very
 //     second cannot cross, so its new speed depends only on OLD state (itself, the vehicle ahead, the signal):
 //     min(follow(leader), follow(stop line) if the link is closed).  The walk then only applies the clamps and
