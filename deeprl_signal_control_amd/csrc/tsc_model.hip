@@ -953,7 +953,7 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
                      int E, int S, float *__restrict__ pi_out, float *__restrict__ v_out, int *action_out,
                      unsigned long long seed, unsigned long long step,
                      int tslot, long long Ntot, float *X1c, float *Zc, float *Hhc, float *Ccc, float *Hpc,
-                     long long *dbg, const float *__restrict__ Wr, const int *__restrict__ kr, int dbg_tid) {
+                     long long *dbg, const float *__restrict__ Wr, const int *__restrict__ kr, int dbg_tid, const int *__restrict__ wgmap) {
     constexpr int H = 2 * KS2 - 64, NCT = H / 32;
     static_assert((32 * (H / 4)) % 512 == 0 || (32 * (H / 4)) % 512 == 256, "X1 store: duplicates come from 256 lanes below");
     const bool stamp = dbg && blockIdx.x == 0 && (int)threadIdx.x == dbg_tid;
@@ -972,7 +972,14 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
     float *W1s = LGp + 2 * 32 * kOut;                    // [SMAX][H]: W1 is small enough to sit in LDS for the whole launch
     // (numbering the S workgroups of a tower onto one XCD so that four of the five weight reads hit its L2 halves the
     //  prologue but leaves two XCDs with 35 workgroups for 32 CUs: 126 -> 207 us)
-    const int g = blockIdx.x % lay.G, sp = blockIdx.x / lay.G;
+    // (tower, split) of this workgroup: by table when the host laid the S workgroups of a tower onto ONE XCD (workgroups go
+    // to the 8 XCDs round-robin by id), so that four of a tower's five weight reads hit that XCD's L2
+    int g = blockIdx.x % lay.G, sp = blockIdx.x / lay.G;
+    if (wgmap) {
+        const int gs = wgmap[blockIdx.x];
+        if (gs < 0) return;
+        g = gs >> 8; sp = gs & 255;
+    }
     const int n_tiles = (E + 31) / 32;
     const int t0 = (int)((long long)n_tiles * sp / S), t1 = (int)((long long)n_tiles * (sp + 1) / S);
     const int a = g >> 1, tower = g & 1, SMAX = lay.SMAX;
@@ -1727,6 +1734,7 @@ struct tsc_model {
     std::vector<void *> allocs;
     int *n_act;
     int16_t *rowrange;          // [A][SMAX][2]
+    int *wgmap; int wgmap_S, wgmap_n, xcd_map_on;   // ws forward: blockIdx -> (tower << 8 | split), XCD-affine (TSC_FWD_XCD=0: off)
     int dbg_tid;                // thread of workgroup 0 that writes the clock stamps (TSC_DBG_THREAD)
     int *krange;                // [A][8][2]: first-layer MFMA steps (2 obs rows each) that feed hidden column tile w (ws forward)
     float *params, *grads, *ms, *WxT;
@@ -1869,6 +1877,8 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     m->lds_fused = sizeof(float) * ((size_t)(L.H + 64) * kXLd + kL * kOut + kOut + 8);   // activations + head weights
     m->fused_fwd = !L.fc && (L.H % 32 == 0) && (L.SMAX <= 64) && (L.SMAX % 4 == 0) && ((L.H + 64) % 8 == 0) && m->lds_fused <= 160 * 1024;
     if (const char *ev = getenv("TSC_DBG_THREAD")) m->dbg_tid = atoi(ev);
+    m->xcd_map_on = 1;
+    if (const char *ev = getenv("TSC_FWD_XCD")) m->xcd_map_on = atoi(ev);
     if (const char *ev = getenv("TSC_UNFUSED_FWD")) if (atoi(ev)) m->fused_fwd = 0;
     m->fused_dw = !L.fc && (L.H == 224 || L.H == 160);
     if (const char *ev = getenv("TSC_UNFUSED_DW")) if (atoi(ev)) m->fused_dw = 0;
@@ -1899,6 +1909,7 @@ int tsc_model_destroy(tsc_model *m) {
     if (!m) return 0;
     (void)hipSetDevice(m->device);
     for (void *p : m->allocs) (void)hipFree(p);
+    if (m->wgmap) (void)hipFree(m->wgmap);
     delete m;
     return 0;
 }
@@ -1987,9 +1998,35 @@ static int model_forward(tsc_model *m, const float *obs, const uint8_t *done, fl
             int S = 256 / L.G;
             if (S < 1) S = 1;
             if (S > (E + 31) / 32) S = (E + 31) / 32;
-#define TSC_WS(KS2) hipLaunchKernelGGL(policy_fwd_ws_kernel<KS2>, dim3((unsigned)(L.G * S)), dim3(512), m->lds_ws, m->stream, m->params, \
+            // XCD-affine numbering: towers are placed whole on the XCD with the most free slots (cap = ceil(G S / 8) per XCD), the
+            // last ones are split over what is left; built once per (S), ids without work exit at once
+            const int *wgm = nullptr;
+            unsigned nwg = (unsigned)(L.G * S);
+            if (m->xcd_map_on && S > 1 && S < 256) {
+                if (m->wgmap_S != S) {
+                    const int cap = (L.G * S + 7) / 8;
+                    std::vector<int> tab((size_t)8 * cap, -1), used(8, 0);
+                    for (int gg = 0; gg < L.G; ++gg) {
+                        int left = S, spn = 0;
+                        while (left > 0) {
+                            int x = 0;
+                            for (int k = 1; k < 8; ++k) if (cap - used[k] > cap - used[x]) x = k;
+                            const int take = left < cap - used[x] ? left : cap - used[x];
+                            for (int q = 0; q < take; ++q) tab[(size_t)(used[x] + q) * 8 + x] = (gg << 8) | (spn + q);
+                            used[x] += take; spn += take; left -= take;
+                        }
+                    }
+                    if (m->wgmap) { (void)hipFree(m->wgmap); m->wgmap = nullptr; }
+                    TSC_HIP(hipMalloc((void **)&m->wgmap, tab.size() * sizeof(int)));
+                    TSC_HIP(hipMemcpyAsync(m->wgmap, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
+                    TSC_HIP(hipStreamSynchronize(m->stream));
+                    m->wgmap_S = S; m->wgmap_n = (int)tab.size();
+                }
+                wgm = m->wgmap; nwg = (unsigned)m->wgmap_n;
+            }
+#define TSC_WS(KS2) hipLaunchKernelGGL(policy_fwd_ws_kernel<KS2>, dim3(nwg), dim3(512), m->lds_ws, m->stream, m->params, \
                                        L, m->n_act, obs, done, m->state_fw, (int)advance, E, S, pi, v, action, (unsigned long long)seed,     \
-                                       (unsigned long long)step, (int)tslot, (long long)m->T * E, m->X1, m->Z, m->Hh, m->Cc, m->Hp, m->dbg, m->Wg, m->krange, m->dbg_tid)
+                                       (unsigned long long)step, (int)tslot, (long long)m->T * E, m->X1, m->Z, m->Hh, m->Cc, m->Hp, m->dbg, m->Wg, m->krange, m->dbg_tid, wgm)
             if (L.H == 224) TSC_WS(144); else TSC_WS(112);
 #undef TSC_WS
             ps.stop();
