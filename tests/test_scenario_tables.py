@@ -1,0 +1,39 @@
+"""The compile-time table dimensions of the specialised simulator kernel against the scenario compiler (CPU)."""
+import os
+import re
+
+import numpy as np
+
+from deeprl_signal_control_amd.scenario import build_large_grid, build_real_net
+
+
+def _reachable_prefix(scn):
+    """Lanes a route can ever put a vehicle on (tsc_env_create: route entry lane -> mv_next chain); 1 + the highest one."""
+    nu = 0
+    nxt = np.asarray(scn.mv_next).reshape(scn.n_lane, scn.n_route)
+    for r in range(scn.n_route):
+        l, hops = int(scn.route_entry_lane[r]), 0
+        while 0 <= l < scn.n_lane and hops <= scn.n_lane:
+            nu = max(nu, l + 1)
+            l = int(nxt[l, r]); hops += 1
+    return nu
+
+
+def test_specialised_kernel_dimensions_match_the_scenarios():
+    """step_kernel's compile-time table dimensions (kSpec in csrc/tsc_env.hip) are matched against the scenario at create time
+    and fall back to the launch-time kernel when they differ: pin them to what the scenario compiler produces, so that a
+    change of the compiler does not quietly un-specialise the benchmarked path."""
+    src = open(os.path.join(os.path.dirname(__file__), '..', 'deeprl_signal_control_amd', 'csrc', 'tsc_env.hip')).read()
+    rows = re.search(r'constexpr SpecDims kSpec\[3\] = \{(.*?)\};', src, re.S).group(1)
+    spec = [tuple(int(v) for v in r.split(',')) for r in re.findall(r'\{([^{}]*)\}', rows)]
+    assert len(spec) == 3 and spec[0] == (0,) * 12
+    for k, scn in ((1, build_large_grid('ma2c')), (2, build_real_net('ma2c'))):
+        NLP, NLA, NU, NR, A, KMAX, PMAX, LMAX, NBR, ctrl, yellow, teleport = spec[k]
+        assert NLP == (scn.n_lane + 63) // 64 * 64
+        assert NU == _reachable_prefix(scn) and NLA == (NU + 63) // 64 * 64
+        assert NR == scn.n_route and A == scn.n_agent
+        assert (PMAX, KMAX) == tuple(scn.green_tab.shape[1:]) and LMAX == scn.agent_lanes.shape[1]
+        assert NBR == max(1, max(len(n) for n in scn.neighbors))
+        assert (ctrl, yellow, teleport) == (scn.control_interval_sec, scn.yellow_interval_sec, scn.teleport_sec)
+    ia = build_large_grid('ia2c')                          # same tables, narrower observations: same instantiation
+    assert (ia.n_lane, ia.n_route, ia.n_agent) == (180, 12, 25)
