@@ -1675,13 +1675,18 @@ dx1w1_kernel(const float *__restrict__ dZ, const float *__restrict__ X1, const f
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             // A operand: row li of the chunk, k = 128 * kh + s2 -- four MFMA steps per 16-byte LDS read
             const float4 *As = reinterpret_cast<const float4 *>(Az + ((long long)buf * 32 + li) * kD1Ld + 128 * kh);
+            // the next quad is requested before this one's MFMAs (pinned by sched_barrier): after a barrier the two waves of a
+            // SIMD run in lock-step, so an LDS wait in front of every second quad is a wait of the whole MFMA pipe
+            float4 a4 = As[0];
 #pragma unroll
             for (int j4 = 0; j4 < 32; ++j4) {
-                const float4 a4 = As[j4];
+                const float4 an = As[j4 + 1 < 32 ? j4 + 1 : j4];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bw[4 * j4], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bw[4 * j4 + 1], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bw[4 * j4 + 2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bw[4 * j4 + 3], acc, 0, 0, 0);
+                a4 = an;
+                __builtin_amdgcn_sched_barrier(0);
             }
             const float *Os = Ob + (long long)buf * 32 * kObLd + li;
 #pragma unroll
