@@ -660,6 +660,15 @@ __device__ __forceinline__ int sample_action(const float *pi, int na, unsigned l
 // ahead.  Blocks are numbered so that all tiles of a tower run on the same XCD (block b -> XCD b%8)
 // and reuse its L2-resident weights.
 // ------------------------------------------------------------------------------------------------
+// The activation cache is written once per control step and not read before the update: streaming (non-temporal) stores
+// keep its 160 MB per launch from evicting the simulator's vehicle state out of L2 / the infinity cache between two
+// tsc_env_step launches (measured in bench.py: env_step 112 -> ... us in the training loop).
+__device__ __forceinline__ void st_stream(float *p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void st_stream4(float *p, const float4 &v) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f4 *>(p));
+}
 constexpr int kXLd = 68;
 
 __global__ void __launch_bounds__(256, 2)
@@ -777,8 +786,8 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
                 XH[col * kXLd + 32 + row] = v1;
                 if (tslot >= 0) {                                  // X1 of this step, in the training layout [g][n][H]
                     const long long nb = (long long)g * Ntot + (long long)tslot * E + eb1;
-                    if (eb1 + row < E) X1c[(nb + row) * H + col] = v0;
-                    if (eb1 + 32 + row < E) X1c[(nb + 32 + row) * H + col] = v1;
+                    if (eb1 + row < E) st_stream(X1c + ((nb + row) * H + col), v0);
+                    if (eb1 + 32 + row < E) st_stream(X1c + ((nb + 32 + row) * H + col), v1);
                 }
             }
         };
@@ -794,7 +803,7 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
     for (int r = 0; r < 16; ++r) {
         Hs[j * kXLd + erow[r]] = h0v[r];
         if (tslot >= 0 && eb15 + erow[r] < E)            // masked h_{t-1}: the operand of dWh in the update
-            Hpc[((long long)g * Ntot + (long long)tslot * E + eb15 + erow[r]) * kL + j] = h0v[r];
+            st_stream(Hpc + (((long long)g * Ntot + (long long)tslot * E + eb15 + erow[r]) * kL + j), h0v[r]);
     }
     __syncthreads();
     FSTAMP();
@@ -861,8 +870,8 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
         }
         if (tslot >= 0 && e < E) {                                 // what lstm_fwd_kernel<true> would store
             const long long n = (long long)g * Ntot + (long long)tslot * E + e;
-            Zc[n * kG4 + j] = ig; Zc[n * kG4 + 64 + j] = fg; Zc[n * kG4 + 128 + j] = og; Zc[n * kG4 + 192 + j] = ug;
-            Ccc[n * kL + j] = cn; Hhc[n * kL + j] = hn;
+            st_stream(Zc + (n * kG4 + j), ig); st_stream(Zc + (n * kG4 + 64 + j), fg); st_stream(Zc + (n * kG4 + 128 + j), og); st_stream(Zc + (n * kG4 + 192 + j), ug);
+            st_stream(Ccc + (n * kL + j), cn); st_stream(Hhc + (n * kL + j), hn);
         }
         XH[j * kXLd + erow[r]] = hn;
     }
@@ -933,15 +942,6 @@ policy_fwd_fused_kernel(const float *__restrict__ params, Layout lay, const int 
 //     cache offsets are re-derived from an opaque copy of the thread index inside each interval instead of being
 //     hoisted (144 of the 256 VGPRs hold the weights), global addresses are uniform base + 32-bit lane offset.
 // ------------------------------------------------------------------------------------------------
-// The activation cache is written once per control step and not read before the update: streaming (non-temporal) stores
-// keep its 160 MB per launch from evicting the simulator's vehicle state out of L2 / the infinity cache between two
-// tsc_env_step launches (measured in bench.py: env_step 112 -> ... us in the training loop).
-__device__ __forceinline__ void st_stream(float *p, float v) { __builtin_nontemporal_store(v, p); }
-__device__ __forceinline__ void st_stream4(float *p, const float4 &v) {
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    f4 t = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(t, reinterpret_cast<f4 *>(p));
-}
 constexpr int kWsLdx = 36;       // activations [k][32 instances + 4]
 constexpr int kWsLdg = 33;       // gate pre-activations [256 columns][32 instances + 1]
 constexpr int kWsBuf = 8;        // tiles whose logits are buffered before the softmax / sampling pass
