@@ -74,6 +74,17 @@ def test_greedy_state(golden_dir):
     _replay(env, g, test_ind=0)
 
 
+@pytest.mark.parametrize('tag,kw', [('queue', dict(objective='queue')), ('wait', dict(objective='wait')),
+                                    ('norms', dict(norm_wave=3.0, norm_wait=40.0, clip_wave=1.5, clip_wait=1.0, coop_gamma=0.5,
+                                                   coef_wait=0.5))])
+def test_reward_objectives_and_normalisation_constants(golden_dir, tag, kw):
+    """envs/env.py:356-367 'queue' / 'wait' objectives and non-default norm / clip / cooperation constants, recorded from
+    the reference LargeGridEnv with those [ENV_CONFIG] values."""
+    g = np.load(os.path.join(golden_dir, 'large_grid_ma2c_%s.npz' % tag))
+    _replay(OracleEnv(build_large_grid('ma2c', **kw), seed=12), g)
+    assert np.abs(g['reward']).max() > 0
+
+
 def test_numpy_sum_order():
     rng = np.random.RandomState(0)
     for n in (2, 6, 25, 28):

@@ -188,6 +188,20 @@ def env_fixtures():
         json.dump(static, f, indent=1)
 
 
+def objective_fixtures():
+    """The reward objectives other than the shipped 'hybrid' (envs/env.py:356-367: 'queue', 'wait') and non-default
+    normalisation / cooperation constants, 60 control steps each, from the reference LargeGridEnv."""
+    from deeprl_signal_control_amd.scenario import build_scenario
+    for tag, kw in (('queue', dict(objective='queue')), ('wait', dict(objective='wait')),
+                    ('norms', dict(norm_wave=3.0, norm_wait=40.0, clip_wave=1.5, clip_wait=1.0, coop_gamma=0.5, coef_wait=0.5))):
+        cfg = fake_traci.ref_config('large_grid', 'ma2c')
+        for k, v in kw.items():
+            cfg['ENV_CONFIG'][k] = str(v)
+        env = fake_traci.ref_env('large_grid', 'ma2c', scn=build_scenario('large_grid', 'ma2c', **kw), config=cfg)
+        g = rollout(env, 60, np.random.RandomState(11), 0.5, True)
+        np.savez_compressed(os.path.join(OUT, 'large_grid_ma2c_%s.npz' % tag), **g)
+
+
 def learner_fixtures():
     """Known answers from agents/utils.py (OnPolicyBuffer :182-228, Scheduler :268-281)."""
     fake_traci.install(__import__('deeprl_signal_control_amd.scenario', fromlist=['x']).build_large_grid())
@@ -322,7 +336,7 @@ if __name__ == '__main__':
     only = set(sys.argv[1:])                 # e.g. `python tools/make_golden.py real_net greedy`
     for name, fn in (('env', env_fixtures), ('real_net', real_net_fixtures), ('greedy', greedy_fixtures),
                      ('iql', iql_fixtures), ('learner', learner_fixtures), ('eval', eval_fixtures),
-                     ('small_grid', small_grid_fixtures)):
+                     ('small_grid', small_grid_fixtures), ('objective', objective_fixtures)):
         if not only or name in only:
             fn()
     for f in sorted(os.listdir(OUT)):
