@@ -85,6 +85,14 @@ def test_reward_objectives_and_normalisation_constants(golden_dir, tag, kw):
     assert np.abs(g['reward']).max() > 0
 
 
+def test_iql_agents_see_the_ia2c_env(golden_dir):
+    """config_iqll_large.ini (agent = iqll): undiscounted neighbour waves, no fingerprints, global reward -- recorded from
+    the reference LargeGridEnv; the scenario compiler builds the same tables for iqll / iqld as for ia2c."""
+    g = np.load(os.path.join(golden_dir, 'large_grid_iqll.npz'))
+    for agent in ('iqll', 'iqld'):
+        _replay(OracleEnv(build_large_grid(agent), seed=12), g)
+
+
 def test_numpy_sum_order():
     rng = np.random.RandomState(0)
     for n in (2, 6, 25, 28):

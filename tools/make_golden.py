@@ -200,6 +200,10 @@ def objective_fixtures():
         env = fake_traci.ref_env('large_grid', 'ma2c', scn=build_scenario('large_grid', 'ma2c', **kw), config=cfg)
         g = rollout(env, 60, np.random.RandomState(11), 0.5, True)
         np.savez_compressed(os.path.join(OUT, 'large_grid_ma2c_%s.npz' % tag), **g)
+    # the env as the IQL agents see it (config_iqll_large.ini: agent = iqll; envs/env.py treats it like ia2c)
+    env = fake_traci.ref_env('large_grid', 'iqll')
+    g = rollout(env, 60, np.random.RandomState(12), 0.5, False)
+    np.savez_compressed(os.path.join(OUT, 'large_grid_iqll.npz'), **g)
 
 
 def learner_fixtures():
