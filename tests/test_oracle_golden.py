@@ -85,6 +85,17 @@ def test_reward_objectives_and_normalisation_constants(golden_dir, tag, kw):
     assert np.abs(g['reward']).max() > 0
 
 
+def test_demand_tables_for_other_peak_flows(golden_dir):
+    """large_grid/data/build_file.py:268-337 with other [ENV_CONFIG] peak flows: every flow element incl. the `%d`
+    truncation of the scaled volumes, as the reference generator wrote them."""
+    ref = json.load(open(os.path.join(golden_dir, 'large_grid_flow_variants.json')))
+    assert len(ref) == 3
+    for key, flows in ref.items():
+        p1, p2 = (int(v) for v in key.split(','))
+        scn = build_large_grid('ma2c', peak_flow1=p1, peak_flow2=p2)
+        assert [[e1, e2, b, e, v] for (e1, e2, b, e, v) in scn.extra['demand']] == flows
+
+
 def test_iql_agents_see_the_ia2c_env(golden_dir):
     """config_iqll_large.ini (agent = iqll): undiscounted neighbour waves, no fingerprints, global reward -- recorded from
     the reference LargeGridEnv; the scenario compiler builds the same tables for iqll / iqld as for ia2c."""

@@ -200,6 +200,18 @@ def objective_fixtures():
         env = fake_traci.ref_env('large_grid', 'ma2c', scn=build_scenario('large_grid', 'ma2c', **kw), config=cfg)
         g = rollout(env, 60, np.random.RandomState(11), 0.5, True)
         np.savez_compressed(os.path.join(OUT, 'large_grid_ma2c_%s.npz' % tag), **g)
+    # demand tables of the reference generator (large_grid/data/build_file.py:268-337) for other peak flows
+    flows = {}
+    for p1, p2 in ((1500, 600), (777, 1234), (100, 50)):
+        cfg = fake_traci.ref_config('large_grid', 'ma2c')
+        cfg['ENV_CONFIG']['peak_flow1'], cfg['ENV_CONFIG']['peak_flow2'] = str(p1), str(p2)
+        env = fake_traci.ref_env('large_grid', 'ma2c', scn=build_scenario('large_grid', 'ma2c', peak_flow1=p1, peak_flow2=p2), config=cfg)
+        env.reset(); env.terminate()
+        rou = open(os.path.join(env.data_path, 'exp_0.rou.xml')).read()
+        flows['%d,%d' % (p1, p2)] = [[m.group(1), m.group(2), int(m.group(3)), int(m.group(4)), int(m.group(5))]
+                                     for m in re.finditer(r'from="(\S+)" to="(\S+)" begin="(\d+)" end="(\d+)" vehsPerHour="(\d+)"', rou)]
+    with open(os.path.join(OUT, 'large_grid_flow_variants.json'), 'w') as f:
+        json.dump(flows, f)
     # the env as the IQL agents see it (config_iqll_large.ini: agent = iqll; envs/env.py treats it like ia2c)
     env = fake_traci.ref_env('large_grid', 'iqll')
     g = rollout(env, 60, np.random.RandomState(12), 0.5, False)
