@@ -57,6 +57,42 @@ def ortho_init(shape, rng, scale=np.sqrt(2)):
     return (scale * q.reshape(shape)).astype(np.float32)
 
 
+def tower_param_shapes(n_wave, n_wait, n_fp, n_fc, n_lstm, policy='lstm'):
+    """TF-variable-style shapes of one tower (agents/policies.py:99-118,191-211,227-235), in the order the reference
+    creates the variables: fcw, [fcf], [fct], then lstm wx / wh / b (or fc); the head comes last."""
+    fw, fp, ft = n_fc
+    sh = {'fcw_w': (n_wave, fw), 'fcw_b': (fw,)}
+    if fp:
+        sh.update({'fcf_w': (n_fp, fp), 'fcf_b': (fp,)})
+    if ft:
+        sh.update({'fct_w': (n_wait, ft), 'fct_b': (ft,)})
+    H = fw + fp + ft
+    if policy == 'lstm':
+        sh.update({'lstm_wx': (H, 4 * n_lstm), 'lstm_wh': (n_lstm, 4 * n_lstm), 'lstm_b': (4 * n_lstm,)})
+    else:
+        sh.update({'fc_w': (H, n_lstm), 'fc_b': (n_lstm,)})
+    return sh
+
+
+def init_tower_params(n_wave_ls, n_w_ls, n_f_ls, n_a_ls, n_fc, n_lstm, policy, rng):
+    """Initial weights of all towers (agent-major, pi then v) drawn in the reference's variable-creation order:
+    `get_variable` calls ortho_init when the variable is created (agents/utils.py:66-74,96-102), policies are built
+    agent by agent, pi tower before v tower (agents/models.py:150-153, agents/policies.py:91-93).  With
+    rng = np.random.RandomState(s) this reproduces the reference's weights under np.random.seed(s)
+    (tests/test_refnet_oracle.py)."""
+    towers = []
+    for a in range(len(n_a_ls)):
+        for tower in ('pi', 'v'):
+            p = {}
+            for k, sh in tower_param_shapes(n_wave_ls[a], n_w_ls[a], n_f_ls[a], n_fc, n_lstm, policy).items():
+                p[k] = ortho_init(sh, rng) if len(sh) == 2 else np.zeros(sh, np.float32)
+            n_out = n_a_ls[a] if tower == 'pi' else 1
+            p['out_w'] = ortho_init((n_lstm, n_out), rng)
+            p['out_b'] = np.zeros(n_out, np.float32)
+            towers.append(p)
+    return towers
+
+
 class ParamLayout:
     """Flat parameter layout of csrc/tsc_model.hip (see include/tsc.h tsc_model_layout): group
     g = 2*agent + tower owns `stride` floats  W1[s_max][H] | b1[H] | Wx[H][4L] | Wh[L][4L] | bl[4L] |
@@ -293,31 +329,12 @@ class VecA2C:
 
     def agent_param_shapes(self, a):
         """TF-variable-style shapes of one tower of agent a (agents/policies.py:99-118,191-211)."""
-        fw, fp, ft = self.n_fc
-        sh = {'fcw_w': (self.n_wave_ls[a], fw), 'fcw_b': (fw,)}
-        if fp:
-            sh.update({'fcf_w': (self.n_f_ls[a], fp), 'fcf_b': (fp,)})
-        if ft:
-            sh.update({'fct_w': (self.n_w_ls[a], ft), 'fct_b': (ft,)})
-        if self.policy == 'lstm':
-            sh.update({'lstm_wx': (self.H, 4 * self.Lh), 'lstm_wh': (self.Lh, 4 * self.Lh), 'lstm_b': (4 * self.Lh,)})
-        else:
-            sh.update({'fc_w': (self.H, self.Lh), 'fc_b': (self.Lh,)})
-        return sh
+        return tower_param_shapes(self.n_wave_ls[a], self.n_w_ls[a], self.n_f_ls[a], self.n_fc, self.Lh, self.policy)
 
     def init_params(self, seed=None):
         rng = np.random.RandomState(seed) if seed is not None else np.random
-        towers = []
-        for a in range(self.n_agent):
-            for tower in ('pi', 'v'):
-                p = {}
-                for k, sh in self.agent_param_shapes(a).items():
-                    p[k] = ortho_init(sh, rng) if len(sh) == 2 else np.zeros(sh, np.float32)
-                n_out = self.n_a_ls[a] if tower == 'pi' else 1
-                p['out_w'] = ortho_init((self.Lh, n_out), rng)
-                p['out_b'] = np.zeros(n_out, np.float32)
-                towers.append(p)
-        self.set_tower_params(towers)
+        self.set_tower_params(init_tower_params(self.n_wave_ls, self.n_w_ls, self.n_f_ls, self.n_a_ls, self.n_fc, self.Lh,
+                                                self.policy, rng))
         _lib.check(self._L.tsc_model_reset_opt_state(self._h))      # TF1 RMSProp slot init: ms = 1
 
     def sync_replicas(self, src=0):

@@ -96,7 +96,12 @@ class OracleA2C:
     """IA2C / MA2C over E env instances in float64."""
 
     def __init__(self, tower_params, n_wave_ls, n_w_ls, n_f_ls, n_a_ls, n_env, n_lstm=64, gamma=0.99,
-                 reward_norm=2000.0, reward_clip=2.0, value_coef=0.5, max_grad_norm=40.0, alpha=0.99, eps=1e-5):
+                 reward_norm=2000.0, reward_clip=2.0, value_coef=0.5, max_grad_norm=40.0, alpha=0.99, eps=1e-5,
+                 state_f32=False):
+        # state_f32: round the carried LSTM state to float32 after every forward -- the reference fetches new_states from
+        # the session (float32) and feeds it back (agents/policies.py:130-135); only the Oracle-B replay
+        # (tests/test_refnet_oracle.py) needs that to agree with the recorded float64 values to 1e-12
+        self.state_f32 = state_f32
         self.p = to_torch(tower_params)
         self.ms = [{k: torch.ones_like(v) for k, v in p.items()} for p in self.p]
         self.nw, self.nt, self.nf, self.na = n_wave_ls, n_w_ls, n_f_ls, n_a_ls
@@ -124,6 +129,8 @@ class OracleA2C:
                 lo, s0 = tower(self.p[2 * a], ob, d, self.s_fw[2 * a], self.nw[a], self.nt[a], self.nf[a])
                 vo, s1 = tower(self.p[2 * a + 1], ob, d, self.s_fw[2 * a + 1], self.nw[a], self.nt[a], self.nf[a])
                 if 'p' in out_type:                            # policies.py:127-135
+                    if self.state_f32:
+                        s0, s1 = s0.float().double(), s1.float().double()
                     self.s_fw[2 * a], self.s_fw[2 * a + 1] = s0, s1
                 pis.append(torch.softmax(lo[0], -1).numpy())
                 vs.append(vo[0, :, 0].numpy())
@@ -227,6 +234,9 @@ class OracleA2C:
 
     def tower_params(self):
         return [{k: v.numpy().astype(np.float32) for k, v in p.items()} for p in self.p]
+
+    def tower_params_f64(self):
+        return [{k: v.numpy().copy() for k, v in p.items()} for p in self.p]
 
 
 def choice_from_uniform(pi, u):

@@ -347,12 +347,30 @@ def iql_fixtures():
                         content=content)
 
 
+def refnet_fixtures():
+    """Oracle-B: the reference's OWN learner code executed (agents/models.py, agents/policies.py, agents/utils.py and
+    Trainer.run of utils.py, unmodified, over oracle/fake_tf.py) on the reference's env classes (over oracle/fake_traci.py),
+    one shortened training episode per configuration -- see oracle/refnet.py for what is recorded.
+      refnet_ma2c_large ..... config_ma2c_large.ini, 2 x 120 steps (FPLstmACPolicy, 25 agents; bootstrap 'v' call, terminal R = 0)
+      refnet_ia2c_large ..... config_ia2c_large.ini, 120 steps, max_grad_norm 1.8 so that clip_by_global_norm bites
+      refnet_fc_large ....... the same with the reference's FcACPolicy swapped in (BASELINE configs[1])
+      refnet_ma2c_real ...... config_ma2c_real.ini, 3 x 40 steps (28 agents, 2..6 actions, no wait inputs)"""
+    from oracle import refnet
+    for name, kw in (('refnet_ma2c_large', dict(scenario='large_grid', agent='ma2c', seed_w=101, episode_sec=1200, full_agents=(3,))),
+                     ('refnet_ia2c_large', dict(scenario='large_grid', agent='ia2c', seed_w=102, episode_sec=600,
+                                                model_over=dict(max_grad_norm=1.8))),
+                     ('refnet_fc_large', dict(scenario='large_grid', agent='ia2c', seed_w=103, episode_sec=600, policy='fc')),
+                     ('refnet_ma2c_real', dict(scenario='real_net', agent='ma2c', seed_w=104, episode_sec=600))):
+        fx = refnet.run_reference_a2c(**kw)
+        np.savez_compressed(os.path.join(OUT, name + '.npz'), **fx)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])                 # e.g. `python tools/make_golden.py real_net greedy`
     for name, fn in (('env', env_fixtures), ('real_net', real_net_fixtures), ('greedy', greedy_fixtures),
                      ('iql', iql_fixtures), ('learner', learner_fixtures), ('eval', eval_fixtures),
-                     ('small_grid', small_grid_fixtures), ('objective', objective_fixtures)):
+                     ('small_grid', small_grid_fixtures), ('objective', objective_fixtures), ('refnet', refnet_fixtures)):
         if not only or name in only:
             fn()
     for f in sorted(os.listdir(OUT)):
