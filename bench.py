@@ -13,6 +13,9 @@ reference generator emits it, random-init (ortho) weights.
 
     value = agents x env instances (all ranks) x simulated seconds / wall time     [env-steps/s]
 
+The timed region carries no profiling; a second pass of the same loop, HIP events around every launch on the launch
+stream, gives the per-kernel table.  `--config c2 | c3 | c5` select BASELINE.json configs[1], [2] (default), [4].
+
 Adds `roofline` (dominant kernel, timed live with HIP events on the launch stream) and
 `cpu_baseline` (the CPU oracle -- C microsim + NumPy env wrapper + torch-CPU nets -- on a bounded
 sample of the same workload, rank 0, N = 1 only).
@@ -34,10 +37,12 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, default_workload=True):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (profiles/r02_pmc.json: separate
     FETCH_SIZE / WRITE_SIZE passes, KB units; the gfx950 x2 FETCH correction only applies to 16 B/lane streams and
     is NOT applied to these dword-per-lane kernels) or None."""
+    if not default_workload:            # the committed counters were collected on the default workload (configs[2]) only
+        return None
     try:
         d = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc.json')))
         k = d['kernels'][kernel]
@@ -53,6 +58,10 @@ def algorithmic_flops(model, rows):
     fc = sum(2 * (nw * fw + nf * fp + nt * ft) for nw, nf, nt in zip(model.n_wave_ls, model.n_f_ls, model.n_w_ls)) * 2
     H, L, G = model.H, model.Lh, model.G
     out = sum(2 * L * (na + 1) for na in model.n_a_ls)
+    if model.policy == 'fc':            # FcACPolicy: the second layer is fc(H -> L), no recurrence (agents/policies.py:227-235)
+        z = G * 2 * H * L
+        return {'policy_fwd_fused': (fc + z + out) * rows, 'fc_gemm': fc * rows, 'zx_gemm': z * rows, 'lstm_fwd': 0.0, 'lstm_bwd': 0.0,
+                'dwx_gemm': z * rows, 'dwh_gemm': 0.0, 'dx1_gemm': z * rows, 'dw1_gemm': fc * rows, 'dwo_gemm': 0.0}
     fused = fc + G * 2 * H * 4 * L + G * 2 * L * 4 * L + out           # one rollout forward of every tower
     # profile ids keep the names of the grouped GEMMs they started as: with the fused update kernels (default)
     # 'dwx_gemm' times dwxh_kernel (dWx + dWh + dbl in one pass) and 'dx1_gemm' times dx1w1_kernel (dX1 + dW1 + db1);
@@ -196,18 +205,34 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the sim-only / sim+forward lines (SURVEY 8d)')
     ap.add_argument('--no-profile', action='store_true')
-    ap.add_argument('--profile-stride', type=int, default=8,
-                    help='HIP-event timing of every n-th launch of the per-control-step kernels (1 = all; the pairs serialise dependent kernels)')
+    ap.add_argument('--profile-stride', type=int, default=1,
+                    help='profiled pass: HIP-event timing of every n-th launch of the per-control-step kernels (1 = all)')
+    ap.add_argument('--profile-steps', type=int, default=0, help='iterations of the profiled pass (0 = same as --steps)')
+    ap.add_argument('--config', default=None, choices=['c2', 'c3', 'c5'],
+                    help='BASELINE.json configs[i] presets: c2 = large_grid IA2C FC, 256 envs; c3 = large_grid MA2C LSTM, 1024 envs '
+                         '(the default); c5 = real_net Monaco MA2C LSTM, 512 envs per GPU')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='process-group backend for N > 1 (nccl = RCCL; gloo only for the two-ranks-on-one-GPU test)')
+    ap.add_argument('--device', type=int, default=None, help='force this device index on every rank (test only)')
     args = ap.parse_args()
+    if args.config == 'c2':
+        args.scenario, args.agent, args.policy, args.envs = 'large_grid', 'ia2c', 'fc', 256
+    elif args.config == 'c3':
+        args.scenario, args.agent, args.policy, args.envs = 'large_grid', 'ma2c', 'lstm', 1024
+    elif args.config == 'c5':
+        args.scenario, args.agent, args.policy, args.envs = 'real_net', 'ma2c', 'lstm', 512
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    local = int(os.environ.get('LOCAL_RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0)) if args.device is None else args.device
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local)
-        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if args.backend == 'nccl':
+            torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            torch.distributed.init_process_group('gloo')
     assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world)
     torch.cuda.set_device(local)
 
@@ -248,18 +273,27 @@ def main():
     for e_ in envs:
         e_.live_vehicle_mean(1)                       # reset the window accumulators
     live = []
-    if not args.no_profile:
-        _lib.profile(enable=max(1, args.profile_stride), reset=True)
+    # ---- the timed region: profile-free (no event pairs between dependent launches) --------------------------------
     t0 = time.perf_counter()
     for _ in range(args.steps):
         tr.run_iteration()
     sync()
     dt = time.perf_counter() - t0
-    prof = {} if args.no_profile else _lib.profile()
-    _lib.profile(enable=False)
     # window mean over the timed region of the vehicles in the network per env instance (SURVEY 8d's V)
     live.append(float(np.mean([e_.live_vehicle_mean(args.steps * model.n_step) for e_ in envs])))
     msr = tr.mean_step_reward()
+    # ---- a second, profiled pass of the same loop: HIP events on the launch stream around every kernel -------------
+    prof, psteps, live_prof, dt_prof = {}, args.profile_steps or args.steps, None, None
+    if not args.no_profile:
+        _lib.profile(enable=max(1, args.profile_stride), reset=True)
+        t1 = time.perf_counter()
+        for _ in range(psteps):
+            tr.run_iteration()
+        sync()
+        dt_prof = time.perf_counter() - t1
+        prof = _lib.profile()
+        _lib.profile(enable=False)
+        live_prof = float(np.mean([e_.live_vehicle_mean(psteps * model.n_step) for e_ in envs]))
     extra = {}
     if rank == 0 and world == 1 and B == 1 and not args.no_extra:
         extra = extra_lines(env, model, scn)
@@ -285,6 +319,7 @@ def main():
                           'parallelism': 'env-sharded x%d%s' % (world, ', %d half-batches on separate streams' % B if B > 1 else ''),
                           'mean_live_vehicles_per_env': live[-1], 'live_vehicles': 'window mean over the timed region',
                           'mean_step_reward': msr}}
+        is_default = (args.scenario, args.agent, args.policy, E) == ('large_grid', 'ma2c', 'lstm', 1024)
         if prof:
             total = sum(ms for ms, _ in prof.values())
             dom = max(prof, key=lambda k: prof[k][0])
@@ -296,17 +331,17 @@ def main():
             for k, d in kern.items():
                 avg = d['ms_total'] / d['launches'] * 1e-3
                 if k == 'env_step':
-                    d['frac_hbm'] = round((32.0 * live[-1] + 16.0 * scn.n_lane + scn.n_agent * 52.0 / 5.0) * ctrl * E / avg / 1e9 / PEAK_HBM_GBS, 4)
+                    d['frac_hbm'] = round((32.0 * live_prof + 16.0 * scn.n_lane + scn.n_agent * 52.0 / 5.0) * ctrl * E / avg / 1e9 / PEAK_HBM_GBS, 4)
                 elif k == 'policy_fwd_fused':
                     d['frac_mfma'] = round(algorithmic_flops(model, E)[k] / avg / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
-                elif fl_all.get(k, 0.0) > 0 and d['launches'] == args.steps:
+                elif fl_all.get(k, 0.0) > 0 and d['launches'] == psteps:
                     d['frac_mfma'] = round(fl_all[k] / avg / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
             if dom == 'env_step':
-                V, Ln, A = live[-1], scn.n_lane, scn.n_agent           # 32 V + 16 L + A*52/5 B per env-sim-step (V = window mean)
+                V, Ln, A = live_prof, scn.n_lane, scn.n_agent           # 32 V + 16 L + A*52/5 B per env-sim-step (V = window mean)
                 bytes_launch = (32.0 * V + 16.0 * Ln + A * 52.0 / 5.0) * ctrl * E
                 ach = bytes_launch / avg_s / 1e9
                 roof = {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                        'frac': ach / PEAK_HBM_GBS, 'traffic': pmc_traffic(dom)}
+                        'frac': ach / PEAK_HBM_GBS, 'traffic': pmc_traffic(dom, is_default)}
             else:
                 rows = E * n_step if dom not in ('fc_gemm', 'zx_gemm', 'lstm_fwd') else None
                 fl = algorithmic_flops(model, E * n_step)
@@ -314,14 +349,17 @@ def main():
                     ach = algorithmic_flops(model, E)[dom] / avg_s / 1e12
                 elif dom in ('fc_gemm', 'zx_gemm', 'lstm_fwd'):
                     # launched both per control step (rows = E) and once per update (rows = E * n_step)
-                    calls_small = args.steps * (n_step + 1) if dom != 'lstm_fwd' else args.steps * (n_step + 1)
-                    tot_fl = fl[dom] * args.steps + algorithmic_flops(model, E)[dom] * (cnt - args.steps)
+                    tot_fl = fl[dom] * psteps + algorithmic_flops(model, E)[dom] * (cnt - psteps)
                     ach = tot_fl / (ms * 1e-3) / 1e12
                 else:
                     ach = fl.get(dom, 0.0) / avg_s / 1e12
                 roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
-                        'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(dom)}
-            roof['timed'] = 'HIP events on the launch stream, every %s launch of the per-control-step kernels, every launch of the others' % ('%dth' % args.profile_stride if args.profile_stride > 1 else '')
+                        'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(dom, is_default)}
+            roof['timed'] = ('HIP events on the launch stream around every %slaunch, in a second pass of %d iterations of the same loop '
+                             'right after the timed region (the timed region itself carries no events); that pass took %.2f ms '
+                             'per iteration' % ('%d-th per-control-step ' % args.profile_stride if args.profile_stride > 1 else '',
+                                                psteps, 1e3 * dt_prof / psteps))
+            roof['mean_live_vehicles_per_env'] = live_prof
             roof['avg_launch_ms'] = ms / cnt
             roof['share_of_kernel_time'] = ms / total
             roof['kernel_time_ms_total'] = total

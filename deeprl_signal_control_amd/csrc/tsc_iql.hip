@@ -440,7 +440,18 @@ int tsc_iql_replay_size(tsc_iql *h, int64_t *size, int64_t *cum) {
     return 0;
 }
 
+static int iql_compute_grads(tsc_iql *h, uint64_t seed, uint64_t update_index, const int32_t *idx_dev);
+
 int tsc_iql_compute_grads(tsc_iql *h, uint64_t seed, uint64_t update_index) {
+    return iql_compute_grads(h, seed, update_index, nullptr);
+}
+
+int tsc_iql_compute_grads_at(tsc_iql *h, const int32_t *idx_dev) {
+    if (!idx_dev) return tsc::fail("tsc_iql_compute_grads_at: null index buffer");
+    return iql_compute_grads(h, 0, 0, idx_dev);
+}
+
+static int iql_compute_grads(tsc_iql *h, uint64_t seed, uint64_t update_index, const int32_t *idx_dev) {
     if (!h) return tsc::fail("null handle");
     const QLayout &L = h->lay;
     const long long size = h->cum < h->cap ? h->cum : h->cap;
@@ -448,8 +459,12 @@ int tsc_iql_compute_grads(tsc_iql *h, uint64_t seed, uint64_t update_index) {
     hipStream_t st = h->stream;
     const long long E = h->E, A = L.A, R = E * h->B;
     TSC_HIP(hipMemsetAsync(h->stats, 0, sizeof(double) * A * 2, st));
-    hipLaunchKernelGGL(iql_sample_kernel, dim3((unsigned)((E * A + 127) / 128)), dim3(128), 0, st, (int)E, (int)A, h->B, size,
-                       (unsigned long long)seed, (unsigned long long)update_index, h->idx);
+    if (idx_dev) {      // the caller's draw (e.g. the reference's random.sample): indices are clamped by the gather's caller contract
+        TSC_HIP(hipMemcpyAsync(h->idx, idx_dev, sizeof(int) * E * A * h->B, hipMemcpyDeviceToDevice, st));
+    } else {
+        hipLaunchKernelGGL(iql_sample_kernel, dim3((unsigned)((E * A + 127) / 128)), dim3(128), 0, st, (int)E, (int)A, h->B, size,
+                           (unsigned long long)seed, (unsigned long long)update_index, h->idx);
+    }
     const long long tot = A * R * (L.SMAX / 4);
     hipLaunchKernelGGL(iql_gather_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (int)E, (int)A, L.SMAX, h->B, h->cap,
                        h->idx, h->r_obs, h->r_next, h->r_act, h->r_rew, h->r_done, h->S, h->S1, h->act, h->rew, h->done);

@@ -50,6 +50,7 @@ def _setup_lib(L):
     L.tsc_iql_add_transition.argtypes = [vp, vp, vp, vp, vp, vp]
     L.tsc_iql_replay_size.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.tsc_iql_compute_grads.argtypes = [vp, C.c_uint64, C.c_uint64]
+    L.tsc_iql_compute_grads_at.argtypes = [vp, vp]
     L.tsc_iql_grad_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
     L.tsc_iql_apply_grads.argtypes = [vp, C.c_double, C.c_double, vp]
     L.tsc_iql_debug_batch.argtypes = [vp, vp]
@@ -132,6 +133,14 @@ class QParamLayout:
         return out
 
 
+def init_agent_params(layout, rng):
+    """Initial Q-net weights of all agents in the reference's variable-creation order (q_fcw, q_fct, q_fc_0, q per agent,
+    agents/policies.py:299-303,355-362; ortho_init is called when the variable is created): with
+    rng = np.random.RandomState(s) the reference's weights under np.random.seed(s) (tests/test_refnet_oracle.py)."""
+    return [{k: ortho_init(sh, rng) if len(sh) == 2 else np.zeros(sh, np.float32) for k, sh in layout.shapes(a).items()}
+            for a in range(layout.A)]
+
+
 class VecIQL:
     """IQL-LR / IQL-DNN for A agents x E env instances on one GPU."""
 
@@ -206,11 +215,7 @@ class VecIQL:
     # ---- parameters -------------------------------------------------------------------------------------------
     def init_params(self, seed=None):
         rng = np.random.RandomState(seed) if seed is not None else np.random
-        agents = []
-        for a in range(self.n_agent):
-            agents.append({k: ortho_init(sh, rng) if len(sh) == 2 else np.zeros(sh, np.float32)
-                           for k, sh in self.layout.shapes(a).items()})
-        self.set_agent_params(agents)
+        self.set_agent_params(init_agent_params(self.layout, rng))
         z = np.zeros(self.n_param, np.float32)
         _lib.check(self._L.tsc_iql_set_opt_state(self._h, z.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p), 0))
 
@@ -258,6 +263,7 @@ class VecIQL:
         m, eps = 0, 0.0
         if mode == 'explore':
             m, eps = 1, float(self.eps_scheduler.get(1))
+            self.last_eps = eps
         elif stochastic:
             m = 2
         _lib.check(self._L.tsc_iql_forward(self._h, C.c_void_p(obs.data_ptr()), C.c_void_p(self.q.data_ptr()),
@@ -290,6 +296,16 @@ class VecIQL:
         stats = np.zeros((self.n_agent, 2), np.float64) if want_stats else None
         _lib.check(self._L.tsc_iql_apply_grads(self._h, float(lr), float(scale),
                                                stats.ctypes.data_as(C.c_void_p) if want_stats else None))
+        return stats
+
+    def minibatch_step_at(self, idx, lr, want_stats=False):
+        """minibatch_step with the caller's draw: idx int32 [E, A, batch_size] (device), ring slots of every (instance,
+        agent) -- ReplayBuffer.sample_transition's pick (include/tsc.h tsc_iql_compute_grads_at)."""
+        assert idx.dtype == torch.int32 and idx.is_contiguous() and tuple(idx.shape) == (self.E, self.n_agent, self.n_step)
+        _lib.check(self._L.tsc_iql_compute_grads_at(self._h, C.c_void_p(idx.data_ptr())))
+        self.update_step += 1
+        stats = np.zeros((self.n_agent, 2), np.float64) if want_stats else None
+        _lib.check(self._L.tsc_iql_apply_grads(self._h, float(lr), 1.0, stats.ctypes.data_as(C.c_void_p) if want_stats else None))
         return stats
 
     def backward(self, summary_writer=None, global_step=None, want_stats=False):

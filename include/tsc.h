@@ -293,6 +293,10 @@ int tsc_iql_replay_size(tsc_iql *h, int64_t *size, int64_t *cum_size);       /* 
  * and leave the gradient of mean((Q(s)[a] - stop_grad(done ? r : r + gamma max Q(s')))^2) over the E * batch_size rows
  * of every agent in the contiguous buffer tsc_iql_grad_buffer() returns (parameter layout). */
 int tsc_iql_compute_grads(tsc_iql *h, uint64_t seed, uint64_t update_index);
+/* The same with the caller's draw instead of the built-in one: idx dev i32 [E, A, batch_size], every entry a ring slot
+ * in [0, replay size) -- what ReplayBuffer.sample_transition's random.sample picked (agents/utils.py:252-258).  Lets a
+ * host that owns the sampling (or a recorded reference run, tests/test_refnet_iql_gpu.py) drive the update. */
+int tsc_iql_compute_grads_at(tsc_iql *h, const int32_t *idx_dev);
 int tsc_iql_grad_buffer(tsc_iql *h, float **grad_dev, int64_t *count);
 /* ... second half: per-agent clip_by_global_norm(max_grad_norm) on grad * grad_scale, TF1 AdamOptimizer step
  * (beta1 .9, beta2 .999, epsilon 1e-8).  stats_host (nullable): per agent {loss, grad_norm} float64 [A,2]. */

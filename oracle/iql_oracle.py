@@ -159,8 +159,9 @@ class OracleIQL:
                 self.rings[e][a].add_transition(np.array(obs[e, a, :n], np.float64), int(actions[e, a]), float(np.float32(r[e, a])),
                                                 np.array(next_obs[e, a, :n], np.float64), bool(done[e]))
 
-    def minibatch_step(self, lr):
-        """-> (per-agent loss, per-agent grad norm, grads list[A] of dict) ; also applies the Adam step."""
+    def minibatch_step(self, lr, idx_given=None):
+        """-> (per-agent loss, per-agent grad norm, grads list[A] of dict) ; also applies the Adam step.
+        idx_given [E, A, B]: the caller's draw (a recorded reference run) instead of the documented Floyd sampling."""
         from oracle.nets_oracle import sample_uniform
         size = self.rings[0][0].size
         idx = np.zeros((self.E, self.A, self.B), np.int32)
@@ -169,7 +170,8 @@ class OracleIQL:
             obs, acts, nobs, rs, dones = [], [], [], [], []
             for e in range(self.E):
                 p = e * self.A + a
-                ids = floyd_sample(size, self.B, lambda i: sample_uniform(self.replay_seed, self.update_step, p * self.B + i))
+                ids = (floyd_sample(size, self.B, lambda i: sample_uniform(self.replay_seed, self.update_step, p * self.B + i))
+                       if idx_given is None else [int(x) for x in idx_given[e, a]])
                 idx[e, a] = ids
                 for s in ids:
                     ob, ac, r, nob, d = self.rings[e][a].buffer[s]

@@ -42,6 +42,7 @@ def ref_var_key(name):
 
 
 N_SAMPLE = 24
+N_SUMS = 4
 
 
 def digest_index(size):
@@ -52,18 +53,18 @@ def digest_index(size):
 
 
 def digest(arr):
-    """[sum, sum |x|, sqrt(sum x^2), sampled entries...] in float64."""
+    """[sum, sum |x|, sqrt(sum x^2), max |x|, sampled entries...] in float64."""
     a = np.asarray(arr, np.float64).ravel()
-    return np.concatenate([[a.sum(), np.abs(a).sum(), np.sqrt((a * a).sum())], a[digest_index(a.size)]])
+    return np.concatenate([[a.sum(), np.abs(a).sum(), np.sqrt((a * a).sum()), np.abs(a).max()], a[digest_index(a.size)]])
 
 
 def tower_digest(towers, sums_only=False):
     """{'<g>/<key>': digest} for a list of per-tower dicts (order agent0 pi, agent0 v, agent1 pi, ...)."""
-    return {'%d/%s' % (g, k): digest(v)[:3 if sums_only else None] for g, p in enumerate(towers) for k, v in p.items()}
+    return {'%d/%s' % (g, k): digest(v)[:N_SUMS if sums_only else None] for g, p in enumerate(towers) for k, v in p.items()}
 
 
 def pack_digests(d):
-    """{name: digest} -> (names [n] str, rows [n, 3 + N_SAMPLE] float64, NaN-padded): one array instead of thousands."""
+    """{name: digest} -> (names [n] str, rows [n, N_SUMS + N_SAMPLE] float64, NaN-padded): one array instead of thousands."""
     names = sorted(d)
     width = max(len(d[k]) for k in names)
     rows = np.full((len(names), width), np.nan)
@@ -74,6 +75,63 @@ def pack_digests(d):
 
 def unpack_digests(names, rows):
     return {str(k): r[~np.isnan(r)] for k, r in zip(names, rows)}
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+A2C_FIXTURES = ['refnet_ma2c_large', 'refnet_ia2c_large', 'refnet_fc_large', 'refnet_ma2c_real']
+
+
+def load_fixture(name):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    return {k: z[k] for k in z.files}
+
+
+def fixture_model_cfg(fx):
+    """[MODEL_CONFIG] of the reference INI a fixture was recorded with (config/config_{ma2c,ia2c}_{large,real}.ini) plus
+    the overrides of tools/make_golden.py refnet_fixtures."""
+    from deeprl_signal_control_amd.agents import A2C_DEFAULTS
+    cfg = dict(A2C_DEFAULTS)
+    cfg['batch_size'] = int(fx['n_step'])
+    if str(fx['scenario']) == 'real_net':
+        cfg['reward_norm'] = 1.0
+    elif str(fx['agent']) == 'ia2c':
+        cfg['reward_norm'] = 3000.0
+    if str(fx['agent']) == 'ia2c' and str(fx['policy']) == 'lstm':
+        cfg['max_grad_norm'] = 1.8
+    return cfg
+
+
+def fixture_dims(fx):
+    """-> n_wave_ls, n_w_ls, n_f_ls, n_a_ls, (num_fw, num_fp, num_ft)."""
+    n_s, n_w, n_f, n_a = (fx[k].tolist() for k in ('n_s_ls', 'n_w_ls', 'n_f_ls', 'n_a_ls'))
+    n_wave = [s - w - f for s, w, f in zip(n_s, n_w, n_f)]
+    n_fc = (128, 64 if str(fx['agent']) == 'ma2c' else 0, 32 if max(n_w) > 0 else 0)
+    return n_wave, n_w, n_f, n_a, n_fc
+
+
+def initial_towers(fx):
+    """The reference's initial weights, regenerated from the recorded np.random seed (pinned by the fixture's digests)."""
+    from deeprl_signal_control_amd.agents import init_tower_params
+    n_wave, n_w, n_f, n_a, n_fc = fixture_dims(fx)
+    return init_tower_params(n_wave, n_w, n_f, n_a, n_fc, 64, str(fx['policy']), np.random.RandomState(int(fx['seed_w'])))
+
+
+def check_digests(got_towers, names, rows, tol, what, sums_only=False, sum_tol=None):
+    """Sampled entries within tol * max|tensor|, the sums within sum_tol (default tol) relative."""
+    want = unpack_digests(names, rows)
+    got = tower_digest(got_towers, sums_only=sums_only)
+    assert set(got) == set(want), what
+    sum_tol = tol if sum_tol is None else sum_tol
+    worst = 0.0
+    for k in want:
+        np.testing.assert_allclose(got[k][:N_SUMS], want[k][:N_SUMS], rtol=sum_tol, atol=sum_tol * max(want[k][1], 1e-30),
+                                   err_msg='%s %s sums' % (what, k))
+        if len(want[k]) > N_SUMS:
+            scale = max(want[k][3], 1e-30)
+            err = np.abs(got[k][N_SUMS:] - want[k][N_SUMS:]).max() / scale
+            worst = max(worst, err)
+            assert err <= tol, '%s %s: %.3g > %.3g' % (what, k, err, tol)
+    return worst
 
 
 # ---- everything below needs /root/reference ---------------------------------------------------------------------
@@ -271,4 +329,121 @@ def run_reference_a2c(scenario, agent, seed_w, episode_sec, policy='lstm', model
         fx[p + 'w/names'], fx[p + 'w/rows'] = pack_digests(tower_digest(b['w']))
         fx[p + 'ms/names'], fx[p + 'ms/rows'] = pack_digests(tower_digest(b['ms'], sums_only=True))
     fx['n_backward'] = len(rec['bw'])
+    return fx
+
+
+def run_reference_iql(agent, seed_w, episode_sec, scenario='large_grid'):
+    """main.train for agent = iqll / iqld (main.py:117-122): the reference env, the reference IQL (LRQPolicy / DeepQPolicy,
+    ReplayBuffer, AdamOptimizer) and Trainer.run, instrumented.  `random.sample` draws transitions, not indices
+    (agents/utils.py:252-258); the indices are recovered by replaying the same draw on range(len(buffer)) from the saved
+    generator state (checked to leave the generator where the reference left it)."""
+    import random
+    fake_tf, fake_traci = _install()
+    from deeprl_signal_control_amd.scenario import build_scenario
+    cfg = fake_traci.ref_config(scenario, agent, 'config_%s_large.ini' % agent)
+    cfg['ENV_CONFIG']['episode_length_sec'] = str(episode_sec)
+    scn = build_scenario(scenario, agent, episode_length_sec=episode_sec)
+    env = fake_traci.ref_env(scenario, agent, scn=scn, config=cfg)
+    import agents.models as ref_models
+    from utils import Counter, Trainer
+    n_step = cfg['MODEL_CONFIG'].getint('batch_size')
+    T = episode_sec // cfg['ENV_CONFIG'].getint('control_interval_sec')
+    np.random.seed(seed_w)
+    random.seed(seed_w)
+    model = ref_models.IQL(env.n_s_ls, env.n_a_ls, env.n_w_ls, T, cfg['MODEL_CONFIG'], seed=0,
+                           model_type='dqn' if agent == 'iqld' else 'lr')
+    A = model.n_agent
+    amax, smax = max(env.n_a_ls), max(env.n_s_ls)
+    w0 = graph_agents(fake_tf, A)
+    sess = model.sess
+    rec = dict(fw_obs=[], fw_q=[], fw_eps=[], actions=[], reward=[], next_obs=[], done=[], global_reward=[], bw=[])
+
+    def pad(obs):
+        o = np.zeros((A, smax), np.float32)
+        for a, ob in enumerate(obs):
+            o[a, :len(ob)] = np.asarray(ob, np.float32)
+        return o
+
+    def fw_before(obs, mode='act', stochastic=False):
+        sess.trace = []
+
+    def fw_after(out, obs, mode='act', stochastic=False):
+        q = np.zeros((A, amax))
+        for a, vals in enumerate(sess.trace):
+            q[a, :env.n_a_ls[a]] = vals[0].reshape(-1)
+        rec['fw_obs'].append(pad(obs)); rec['fw_q'].append(q)
+        sess.trace = None
+    _Tap(model, 'forward', fw_before, fw_after)
+    _Tap(model.eps_scheduler, 'get', None, lambda out, n: rec['fw_eps'].append(float(out)))      # agents/models.py:334
+
+    def step_after(out, action):
+        ob, r, done, g = out
+        rec['actions'].append([int(x) for x in action]); rec['reward'].append(np.asarray(r, np.float64).copy())
+        rec['next_obs'].append(pad(ob)); rec['done'].append(bool(done)); rec['global_reward'].append(float(g))
+    _Tap(env, 'step', None, step_after)
+
+    cur = {}
+    for a, buf in enumerate(model.trans_buffer_ls):
+        def st_before(a=a, buf=buf):
+            cur['state'] = random.getstate()
+
+        def st_after(out, a=a, buf=buf):
+            after = random.getstate()
+            random.setstate(cur['state'])
+            idx = random.sample(range(len(buf.buffer)), buf.batch_size)
+            assert random.getstate() == after
+            obs = out[0]
+            for j, i in enumerate(idx):                   # the recovered indices name the sampled transitions
+                assert np.array_equal(obs[j], buf.buffer[i][0])
+            cur.setdefault('idx', {}).setdefault(a, []).append(idx)
+        _Tap(buf, 'sample_transition', st_before, st_after)
+    bundles = {tuple(id(x) for x in b.xs): b for b in fake_tf.get_default_graph().grad_bundles}
+    for a, pol in enumerate(model.policy_ls):
+        def bw_after(out, sess_, obs, acts, next_obs, dones, rs, cur_lr, summary_writer=None, global_step=None, a=a, pol=pol):
+            memo = sess.last_memo
+            wts = fake_tf.trainable_variables(scope=pol.name)
+            raw = memo[id(bundles[tuple(id(x) for x in wts)].node)]
+            k = len(cur.setdefault('loss', {}).setdefault(a, []))
+            cur['loss'][a].append(float(memo[id(pol.loss)].detach()))
+            cur.setdefault('norm', {}).setdefault(a, []).append(float(memo[id(pol.grad_norm)].detach()))
+            if k in (0, 9):
+                for var, gr in zip(wts, raw):
+                    _, _, key = ref_var_key(var.var_name)
+                    cur.setdefault('g%d' % k, {})['%d/%s' % (a, key)] = gr.numpy().copy()
+            cur['lr'] = float(cur_lr)
+        _Tap(pol, 'backward', None, bw_after)
+
+    def model_bw_before(*a, **k):
+        cur.clear()
+
+    def model_bw_after(out, *a, **k):
+        if 'idx' not in cur:
+            return
+        opts = [p.optimizer for p in model.policy_ls]
+        rec['bw'].append(dict(idx=np.array([cur['idx'][a_] for a_ in range(A)]).transpose(1, 0, 2),      # [10, A, B]
+                              loss=np.array([cur['loss'][a_] for a_ in range(A)]).T, norm=np.array([cur['norm'][a_] for a_ in range(A)]).T,
+                              lr=cur['lr'], g0=dict(cur['g0']), g9=dict(cur['g9']), w=graph_agents(fake_tf, A),
+                              m=graph_agents(fake_tf, A, 'm', opts), v=graph_agents(fake_tf, A, 'v', opts)))
+    _Tap(model, 'backward', model_bw_before, model_bw_after)
+
+    out_dir = tempfile.mkdtemp(prefix='tsc_refnet_') + '/'
+    Trainer(env, model, Counter(T, 10 ** 9, 10 ** 9), fake_tf.summary.FileWriter(out_dir), False, output_path=out_dir).run()
+
+    def agent_digest(agents, sums_only=False):
+        return {'%d/%s' % (a, k): digest(v)[:N_SUMS if sums_only else None] for a, p in enumerate(agents) for k, v in p.items()}
+    fx = dict(scenario=scenario, agent=agent, seed_w=seed_w, episode_sec=episode_sec, n_step=n_step,
+              n_s_ls=np.array(env.n_s_ls), n_a_ls=np.array(env.n_a_ls), n_w_ls=np.array(env.n_w_ls),
+              fw_obs=np.array(rec['fw_obs']), fw_q=np.array(rec['fw_q']), fw_eps=np.array(rec['fw_eps']),
+              actions=np.array(rec['actions'], np.int32), reward=np.array(rec['reward']), next_obs=np.array(rec['next_obs']),
+              done=np.array(rec['done']), global_reward=np.array(rec['global_reward']), n_backward=len(rec['bw']))
+    fx['w0/names'], fx['w0/rows'] = pack_digests(agent_digest(w0))
+    for i, b in enumerate(rec['bw']):
+        p = 'bw%d/' % i
+        for k in ('idx', 'loss', 'norm', 'lr'):
+            fx[p + k] = np.asarray(b[k])
+        for k in ('g0', 'g9'):
+            fx[p + k + '/names'], fx[p + k + '/rows'] = pack_digests({kk: digest(v) for kk, v in b[k].items()})
+        fx[p + 'w/names'], fx[p + 'w/rows'] = pack_digests(agent_digest(b['w']))
+        fx[p + 'm/names'], fx[p + 'm/rows'] = pack_digests(agent_digest(b['m'], True))
+        fx[p + 'v/names'], fx[p + 'v/rows'] = pack_digests(agent_digest(b['v'], True))
     return fx

@@ -473,6 +473,70 @@ def test_update_bench_shape_T120():
     m.close()
 
 
+@pytest.mark.parametrize('agent', ['ma2c', 'ia2c'])
+def test_update_benchmarked_batch_E1024_T120(agent):
+    """The update AT the benchmarked batch -- E = 1024 distinct instances, T = 120: 122 880 rows per agent-tower, the five
+    row splits of dwxh / dx1w1 cover 24 576 rows each, lstm_bwd runs its full grid -- through the rollout path the
+    benchmark uses (fused forward, activation cache), for MA2C (H = 224) and IA2C (H = 160: the dwxh<7> / dx1w1<5>
+    instantiations).  The float64 oracle evaluates the first, a four-neighbour and the last agent (six towers: all the
+    CPU can do in seconds); their gradient slices, returns, losses, norms and updated parameters are compared."""
+    from deeprl_signal_control_amd import _lib
+    from oracle.nets_oracle import OracleA2C
+    E, T = 1024, 120
+    scn, m, _ = _make(agent, E, T, seed=5)
+    A = scn.n_agent
+    sel = [0, 3, A - 1]
+    tw = m.get_tower_params()
+    o = OracleA2C([tw[2 * a + k] for a in sel for k in (0, 1)], [m.n_wave_ls[a] for a in sel], [m.n_w_ls[a] for a in sel],
+                  [m.n_f_ls[a] for a in sel], [m.n_a_ls[a] for a in sel], E, gamma=m.cfg['gamma'],
+                  reward_norm=m.cfg['reward_norm'], reward_clip=m.cfg['reward_clip'], value_coef=m.cfg['value_coef'],
+                  max_grad_norm=m.cfg['max_grad_norm'])
+    rng = np.random.RandomState(17)
+    m.reset(); o.reset()
+    obs, done = _rand_obs(scn, E, rng), np.ones(E, np.uint8)
+    for t in range(T):
+        d_obs, d_done = torch.from_numpy(obs).cuda(), torch.from_numpy(done).cuda()
+        pi, v, _ = m.forward_sample(d_obs, d_done)
+        v = v.cpu().numpy()
+        _, ov = o.forward(obs[:, sel], done, 'pv')
+        np.testing.assert_allclose(v[:, sel], ov, atol=3e-5)
+        act = np.stack([rng.randint(0, n, E) for n in scn.n_a_ls], 1).astype(np.int32)
+        rew = -rng.rand(E, A) * 3.0 * m.cfg['reward_norm']
+        dpost = (rng.rand(E) < 0.05).astype(np.uint8)
+        m.add_transition(d_obs, d_done, torch.from_numpy(act).cuda(), torch.from_numpy(rew).cuda(), torch.from_numpy(v).cuda(),
+                         torch.from_numpy(dpost).cuda())
+        o.add_transition(obs[:, sel], done, act[:, sel], rew[:, sel], v[:, sel], dpost)
+        obs, done = _rand_obs(scn, E, rng), dpost
+    Rb = m.forward(torch.from_numpy(obs).cuda(), False, 'v').clone()
+    _lib.check(m._L.tsc_model_compute_grads(m._h, C.c_void_p(Rb.data_ptr()), 0.01))
+    ograds, ostats = o.compute_grads(Rb.cpu().numpy()[:, sel], 0.01)
+    Rs = np.zeros((T, E, A), np.float32); Advs = np.zeros_like(Rs)
+    _lib.check(m._L.tsc_model_get_returns(m._h, Rs.ctypes.data_as(C.c_void_p), Advs.ctypes.data_as(C.c_void_p)))
+    np.testing.assert_array_equal(Rs[:, :, sel], o.Rs)
+    np.testing.assert_array_equal(Advs[:, :, sel], o.Advs)
+    g = m.unpack(m.grad_tensor().cpu().numpy())
+    worst = {}
+    for i, a in enumerate(sel):
+        for k2 in (0, 1):
+            for k, og in ograds[2 * i + k2].items():
+                err = _grad_err(o, 2 * i + k2, k, g[2 * a + k2][k], og.numpy())
+                worst[k] = max(worst.get(k, 0.0), err)
+                assert err <= 1e-4, 'agent %d tower %d %s: |dg| / max|g| = %.2e' % (a, k2, k, err)
+    stats = np.zeros((A, 4))
+    _lib.check(m._L.tsc_model_apply_grads(m._h, 5e-4, 1.0, stats.ctypes.data_as(C.c_void_p)))
+    m.cur_t = 0
+    onorm = o.apply_grads(ograds, 5e-4)
+    np.testing.assert_allclose(stats[sel, :3], ostats, rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(stats[sel, 3], onorm, rtol=2e-3)
+    p, op = m.get_tower_params(), o.tower_params()
+    for i, a in enumerate(sel):
+        for k2 in (0, 1):
+            for k in op[2 * i + k2]:
+                np.testing.assert_allclose(p[2 * a + k2][k], op[2 * i + k2][k], atol=3e-5, err_msg='param agent=%d %s' % (a, k))
+    print('E=1024 T=120 %s worst |dg| / max|g|:' % agent, {k: '%.1e' % v for k, v in worst.items()})
+    m.close()
+
+
 @pytest.mark.parametrize('agent,E,T,use_cache', [('ma2c', 70, 40, True), ('ia2c', 40, 40, True), ('ma2c', 33, 10, False)])
 def test_monaco_learner_vs_oracle(agent, E, T, use_cache):
     """Monaco (real_net) learner shapes -- H = 192 (MA2C: fw 128 + fp 64, no wait FC) / 128 (IA2C), heterogeneous

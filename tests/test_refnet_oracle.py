@@ -7,59 +7,15 @@ Pinned here: the reference's weights under np.random.seed (ortho_init in variabl
 every forward (pi, v; 'pv' advancing the LSTM state, 'v' not), the float32 returns / advantages, the raw tf.gradients
 of every variable, the per-agent global norm, the loss, and the variables + RMSProp `rms` slots after each update.
 Tolerances: float64 against float64 -- 1e-9 relative (summation order only)."""
-import os
-
 import numpy as np
 import pytest
 
-from deeprl_signal_control_amd.agents import A2C_DEFAULTS, init_tower_params
 from oracle import refnet
 from oracle.nets_oracle import OracleA2C
 
-GOLD = os.path.join(os.path.dirname(__file__), 'golden')
-FIXTURES = ['refnet_ma2c_large', 'refnet_ia2c_large', 'refnet_fc_large', 'refnet_ma2c_real']
-
-
-def load(name):
-    z = np.load(os.path.join(GOLD, name + '.npz'))
-    return {k: z[k] for k in z.files}
-
-
-def model_cfg(fx):
-    """[MODEL_CONFIG] of the reference INI the fixture was recorded with (config/config_{ma2c,ia2c}_{large,real}.ini)."""
-    cfg = dict(A2C_DEFAULTS)
-    cfg['batch_size'] = int(fx['n_step'])
-    if str(fx['scenario']) == 'real_net':
-        cfg['reward_norm'] = 1.0
-    elif str(fx['agent']) == 'ia2c':
-        cfg['reward_norm'] = 3000.0
-    if str(fx['agent']) == 'ia2c' and str(fx['policy']) == 'lstm':
-        cfg['max_grad_norm'] = 1.8                              # tools/make_golden.py refnet_ia2c_large
-    return cfg
-
-
-def dims(fx):
-    n_s, n_w, n_f, n_a = (fx[k].tolist() for k in ('n_s_ls', 'n_w_ls', 'n_f_ls', 'n_a_ls'))
-    n_wave = [s - w - f for s, w, f in zip(n_s, n_w, n_f)]
-    ma2c = str(fx['agent']) == 'ma2c'
-    n_fc = (128, 64 if ma2c else 0, 32 if max(n_w) > 0 else 0)
-    return n_wave, n_w, n_f, n_a, n_fc
-
-
-def initial_towers(fx):
-    n_wave, n_w, n_f, n_a, n_fc = dims(fx)
-    return init_tower_params(n_wave, n_w, n_f, n_a, n_fc, 64, str(fx['policy']), np.random.RandomState(int(fx['seed_w'])))
-
-
-def check_digests(got_towers, names, rows, rtol, what, sums_only=False):
-    want = refnet.unpack_digests(names, rows)
-    got = refnet.tower_digest(got_towers, sums_only=sums_only)
-    assert set(got) == set(want), what
-    for k in want:
-        scale = max(np.abs(want[k][3:]).max() if len(want[k]) > 3 else abs(want[k][2]), 1e-30)
-        np.testing.assert_allclose(got[k][:3], want[k][:3], rtol=rtol, atol=rtol * max(want[k][1], 1e-30), err_msg='%s %s sums' % (what, k))
-        if len(want[k]) > 3:
-            np.testing.assert_allclose(got[k][3:], want[k][3:], rtol=0, atol=rtol * scale, err_msg='%s %s' % (what, k))
+FIXTURES = refnet.A2C_FIXTURES
+load, model_cfg, dims, initial_towers, check_digests = (refnet.load_fixture, refnet.fixture_model_cfg, refnet.fixture_dims,
+                                                        refnet.initial_towers, refnet.check_digests)
 
 
 @pytest.mark.parametrize('name', FIXTURES)
@@ -137,3 +93,76 @@ def test_clip_bites_in_the_ia2c_fixture():
     """The IA2C fixture was recorded with max_grad_norm = 1.8 so that tf.clip_by_global_norm is not the identity."""
     fx = load('refnet_ia2c_large')
     assert (fx['bw0/norm'] > 1.8).sum() >= 3 and (fx['bw0/norm'] < 1.8).sum() >= 3
+
+
+# ---- IQL-LR / IQL-DNN (agents/models.py:264-376, agents/policies.py:285-389, agents/utils.py:231-263) ---------------------
+IQL_FIXTURES = ['refnet_iqll_large', 'refnet_iqld_large']
+
+
+def iql_layout(fx):
+    from deeprl_signal_control_amd.iql import QParamLayout
+    n_s, n_w, n_a = (fx[k].tolist() for k in ('n_s_ls', 'n_w_ls', 'n_a_ls'))
+    kind = 'dqn' if str(fx['agent']) == 'iqld' else 'lr'
+    n_wave = [s - w for s, w in zip(n_s, n_w)]
+    return QParamLayout(n_wave, n_w, n_a, (max(n_s) + 3) // 4 * 4, kind, 128, 64), n_wave, n_w, n_a
+
+
+def iql_initial(fx):
+    from deeprl_signal_control_amd.iql import init_agent_params
+    return init_agent_params(iql_layout(fx)[0], np.random.RandomState(int(fx['seed_w'])))
+
+
+def agent_digest(agents, sums_only=False):
+    return {'%d/%s' % (a, k): refnet.digest(v)[:refnet.N_SUMS if sums_only else None] for a, p in enumerate(agents) for k, v in p.items()}
+
+
+def check_agent_digests(got, names, rows, tol, what):
+    want = refnet.unpack_digests(names, rows)
+    assert set(got) == set(want), what
+    for k in want:
+        n = refnet.N_SUMS
+        np.testing.assert_allclose(got[k][:n], want[k][:n], rtol=tol, atol=tol * max(want[k][1], 1e-30), err_msg='%s %s sums' % (what, k))
+        if len(want[k]) > n:
+            assert np.abs(got[k][n:] - want[k][n:]).max() <= tol * max(want[k][3], 1e-30), (what, k)
+
+
+@pytest.mark.parametrize('name', IQL_FIXTURES)
+def test_oracle_replays_reference_iql(name):
+    """The float64 restatement (oracle/iql_oracle.py) against the reference IQL executed over oracle/fake_tf.py: initial
+    weights under the seed, Q values of every forward, the epsilon schedule, and for each of the 3 x 10 minibatch steps per
+    agent (the reference's own random.sample draws) loss and global norm; raw gradients of step 0 and 9; weights and both
+    Adam moments after every backward."""
+    from oracle.iql_oracle import OracleIQL
+    fx = load(name)
+    lay, n_wave, n_w, n_a = iql_layout(fx)
+    A = len(n_a)
+    w0 = iql_initial(fx)
+    check_agent_digests(agent_digest(w0), fx['w0/names'], fx['w0/rows'], 0.0, 'w0')
+    o = OracleIQL(w0, n_wave, n_w, n_a, 1, batch_size=int(fx['n_step']), buffer_size=1000, reward_norm=3000.0, reward_clip=2.0,
+                  max_grad_norm=40.0)
+    from deeprl_signal_control_amd.agents import Scheduler
+    T = len(fx['actions'])
+    eps = Scheduler(1.0, 0.01, T * 0.5, decay='linear')                          # config_iql*_large.ini, total_step = T
+    bw = 0
+    S = lay.s_max
+    for t in range(T):
+        obs = np.zeros((1, A, S)); obs[0, :, :fx['fw_obs'].shape[2]] = fx['fw_obs'][t]
+        nxt = np.zeros((1, A, S)); nxt[0, :, :fx['next_obs'].shape[2]] = fx['next_obs'][t]
+        qs = o.forward(obs)
+        for a in range(A):
+            np.testing.assert_allclose(qs[a][0], fx['fw_q'][t, a, :n_a[a]], rtol=0, atol=1e-12)
+        assert abs(eps.get(1) - fx['fw_eps'][t]) < 1e-12
+        o.add_transition(obs, fx['actions'][t][None], fx['reward'][t][None], nxt, np.array([fx['done'][t]]))
+        if (t + 1) % int(fx['n_step']) == 0:
+            p = 'bw%d/' % bw
+            for k in range(10):
+                loss, norm, grads = o.minibatch_step(float(np.float32(fx[p + 'lr'])), idx_given=fx[p + 'idx'][k][None])
+                np.testing.assert_allclose(loss, fx[p + 'loss'][k], rtol=1e-9, atol=1e-18)
+                np.testing.assert_allclose(norm, fx[p + 'norm'][k], rtol=1e-9, atol=1e-18)
+                if k in (0, 9):
+                    check_agent_digests(agent_digest(grads), fx[p + 'g%d/names' % k], fx[p + 'g%d/rows' % k], 1e-9, p + 'g%d' % k)
+            check_agent_digests(agent_digest([{k_: v.numpy() for k_, v in q.p.items()} for q in o.qs]), fx[p + 'w/names'], fx[p + 'w/rows'], 1e-10, p + 'w')
+            check_agent_digests(agent_digest([{k_: v.numpy() for k_, v in q.m.items()} for q in o.qs], True), fx[p + 'm/names'], fx[p + 'm/rows'], 1e-9, p + 'm')
+            check_agent_digests(agent_digest([{k_: v.numpy() for k_, v in q.v.items()} for q in o.qs], True), fx[p + 'v/names'], fx[p + 'v/rows'], 1e-9, p + 'v')
+            bw += 1
+    assert bw == int(fx['n_backward']) == 3

@@ -363,6 +363,11 @@ def refnet_fixtures():
                      ('refnet_ma2c_real', dict(scenario='real_net', agent='ma2c', seed_w=104, episode_sec=600))):
         fx = refnet.run_reference_a2c(**kw)
         np.savez_compressed(os.path.join(OUT, name + '.npz'), **fx)
+    # IQL-LR / IQL-DNN: config_iql{l,d}_large.ini, 60 control steps = 3 rollouts of 20, 3 x 10 Adam minibatch steps per agent
+    for name, kw in (('refnet_iqll_large', dict(agent='iqll', seed_w=105, episode_sec=300)),
+                     ('refnet_iqld_large', dict(agent='iqld', seed_w=106, episode_sec=300))):
+        fx = refnet.run_reference_iql(**kw)
+        np.savez_compressed(os.path.join(OUT, name + '.npz'), **fx)
 
 
 if __name__ == '__main__':
