@@ -200,7 +200,7 @@ def test_hip_replays_reference_iql(name, E):
                     import ctypes as C
                     _lib.check(m._L.tsc_iql_compute_grads_at(m._h, C.c_void_p(idx.data_ptr())))
                     g = m.layout.unpack(m.grad_tensor().cpu().numpy())
-                    worst['g'] = max(worst['g'], check(agent_digest(g), fx[p + 'g%d/names' % k], fx[p + 'g%d/rows' % k], 2e-5, p + 'g%d' % k))
+                    worst['g'] = max(worst['g'], check(agent_digest(g), fx[p + 'g%d/names' % k], fx[p + 'g%d/rows' % k], 1e-4, p + 'g%d' % k))
                 stats = m.minibatch_step_at(idx, lr, want_stats=True)
                 np.testing.assert_allclose(stats[:, 0], fx[p + 'loss'][k], rtol=2e-4, atol=1e-12)
                 np.testing.assert_allclose(stats[:, 1], fx[p + 'norm'][k], rtol=2e-4, atol=1e-9)

@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""Learning curve of the HIP path: large_grid MA2C (config/config_ma2c_large.ini of the reference), E env instances on one
+MI355X, `--episodes` training episodes of 720 control steps = 6 A2C updates each (Trainer.run, utils.py:255-308).
+
+Writes the rows of the reference's train_reward.csv (one per episode: mean / std over the episode's control steps of the
+global reward, averaged over the env instances -- the quantity of figs/large_grid_train.png) plus the episode's wall time:
+
+    python tools/learning_curve.py --episodes 50 --envs 1024 --out profiles/r03_learning_curve.json
+
+Every instance sees its own demand seed per episode (seed0 + e, stride E per episode), every instance explores with its
+own action stream, all share one set of weights.  The simulator underneath is this repo's microsim spec:
+absolute reward levels are not SUMO's, the trend is what this shows."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
+
+
+def run(episodes, n_env, scenario='large_grid', agent='ma2c', seed=0, lr=None, log=None):
+    from deeprl_signal_control_amd.agents import VecA2C
+    from deeprl_signal_control_amd.env import VecTrafficEnv
+    from deeprl_signal_control_amd.scenario import build_scenario
+    from deeprl_signal_control_amd.trainer import VecTrainer
+    scn = build_scenario(scenario, agent)
+    if scenario == 'large_grid':
+        mcfg, seed0 = dict(reward_norm=2000.0 if agent == 'ma2c' else 3000.0, batch_size=120), 12
+    else:
+        mcfg, seed0 = dict(reward_norm=1.0, batch_size=40), 42
+    if lr is not None:
+        mcfg['lr_init'] = lr
+    env = VecTrafficEnv(scn, n_env, device=0, seed=seed0)
+    model = VecA2C(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, scn.n_f_ls, n_env, scn.s_max, int(scn.green_tab.shape[1]), mcfg,
+                   device=0, seed=seed, name=agent)
+    tr = VecTrainer(env, model, log_rewards=True)
+    rows = []
+    T = int(env.T)
+    for ep in range(episodes):
+        t0 = time.perf_counter()
+        tr.start_episode()
+        tr._ep_rewards = []
+        while True:
+            finished, R = tr.explore()
+            model.backward(R)
+            if finished:
+                env.terminate()
+                break
+        r = torch.stack(tr._ep_rewards)                                  # [T, E] global reward per control step
+        torch.cuda.synchronize()
+        row = dict(episode=ep, step=(ep + 1) * T, avg_reward=float(r.mean(0).mean().item()),
+                   std_reward=float(r.std(0, unbiased=False).mean().item()),
+                   spread_over_instances=float(r.mean(0).std().item()), wall_s=time.perf_counter() - t0)
+        rows.append(row)
+        if log:
+            log('episode %3d  avg step reward %9.2f  (std over steps %.1f, over instances %.1f)  %.2f s'
+                % (ep, row['avg_reward'], row['std_reward'], row['spread_over_instances'], row['wall_s']))
+    env.close(); model.close()
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--episodes', type=int, default=50)
+    ap.add_argument('--envs', type=int, default=1024)
+    ap.add_argument('--scenario', default='large_grid')
+    ap.add_argument('--agent', default='ma2c')
+    ap.add_argument('--lr', type=float, default=None)
+    ap.add_argument('--out', default=None)
+    args = ap.parse_args()
+    rows = run(args.episodes, args.envs, args.scenario, args.agent, lr=args.lr, log=print)
+    first, last = np.mean([r['avg_reward'] for r in rows[:5]]), np.mean([r['avg_reward'] for r in rows[-5:]])
+    out = dict(scenario=args.scenario, agent=args.agent, envs=args.envs, episodes=args.episodes,
+               control_steps_per_episode=rows[0]['step'], first5_mean=first, last5_mean=last, rows=rows,
+               note='mean over env instances of the per-episode mean global step reward (train_reward.csv avg_reward); '
+                    'this repo\'s microsim spec underneath, not SUMO')
+    print('first 5 episodes %.2f -> last 5 episodes %.2f' % (first, last))
+    if args.out:
+        with open(args.out, 'w') as f:
+            json.dump(out, f, indent=1)
+
+
+if __name__ == '__main__':
+    main()
