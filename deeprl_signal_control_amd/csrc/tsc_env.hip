@@ -32,8 +32,8 @@
 
 namespace {
 
-constexpr float kLen = 5.0f, kS0 = 2.5f, kAcc = 5.0f, kDec = 10.0f, kTHead = 1.5f;
-constexpr float kCab = 14.142136f, kHalt = 0.1f, kYieldT = 3.0f, kYieldD = 10.0f;
+constexpr float kLen = 5.0f, kS0 = 2.5f, kAcc = 5.0f, kDec = 10.0f, kTHead = 1.0f;   // headway = SUMO's default tau
+constexpr float kICab = 0.070710678f /* 1 / (2 sqrt(acc dec)): a multiply instead of an IEEE division */, kHalt = 0.1f, kYieldT = 3.0f, kYieldD = 10.0f;
 constexpr int kCap = TSC_LANE_CAP, kMaxCross = TSC_MAX_CROSS, kMaxUp = TSC_MAX_UP;
 
 constexpr int kMaxEntry = 8;           // routes that may share one entry lane (small_grid: 6 paths leave np1_nt1)
@@ -105,7 +105,7 @@ __device__ __forceinline__ float follow(float v, float v0, bool has_lead, float 
     float acc = kAcc * (1.0f - r2 * r2);
     float vsafe = INFINITY;
     if (has_lead) {
-        float sstar = (kS0 + v * kTHead) + (v * (v - vl)) / kCab;
+        float sstar = (kS0 + v * kTHead) + (v * (v - vl)) * kICab;
         if (sstar < kS0) sstar = kS0;
         float s = g < 0.5f ? 0.5f : g;
         float q = sstar / s;
@@ -156,6 +156,7 @@ struct Smem {
     float *len, *vmax; int *node;               // lane length / speed limit / downstream agent [NLA]
     int *pend, *ser; uint8_t *emit;             // per-route insertion state [NR], emissions [NR*8]
     uint8_t *zip;                               // [NU*NR]
+    uint32_t *up4;                              // [NLA] the lane's feeders, a byte each (0xFF = none): merge arbitration
     int *pre, *wtot;                            // wave-local inclusive scan of queued vehicles [NLA], wave totals [16]
     int *nc; float *seed;                       // per lane: vehicles ahead of the first one that stays; its chain key [NLA]
     float *wtail, *hz;                          // wave tails of the chain scan [2][16]; old (x, v) across super-rounds [2]
@@ -179,6 +180,7 @@ __host__ __device__ __forceinline__ void smem_layout(Smem &s, const EnvDev &P, T
     s.len = (float *)take(4 * P.NLA); s.vmax = (float *)take(4 * P.NLA); s.node = (int *)take(4 * P.NLA);
     s.pend = (int *)take(4 * P.NR); s.ser = (int *)take(4 * P.NR); s.emit = (uint8_t *)take(8 * P.NR);
     s.zip = (uint8_t *)take((P.NU * P.NR + 3) / 4 * 4);
+    s.up4 = (uint32_t *)take(4 * P.NLA);
     s.pre = (int *)take(4 * P.NLA); s.wtot = (int *)take(4 * 16);
     s.nc = (int *)take(4 * P.NLA); s.seed = (float *)take(4 * P.NLA); s.wtail = (float *)take(4 * 32); s.hz = (float *)take(4 * 4);
     if (P.rec) {
@@ -396,7 +398,11 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         }
     };
     publish();
-    if (lthr) s.nout[l] = 0;
+    if (lthr) {
+        auto b8 = [&](int u) { return (uint32_t)((u >= 0 && u < 255 && u < P.NU) ? u : 0xFF); };
+        s.up4[l] = b8(up0) | b8(up1) << 8 | b8(up2) << 16 | b8(up3) << 24;
+        s.nout[l] = 0;
+    }
     unsigned arrived = 0;
     __syncthreads();
     TSC_STAMP();
@@ -480,12 +486,50 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                             }
                         }
                     }
-                    // zipper merge: feeder `rank` of `count` may send in second t iff (t + rank) % count == 0
-                    if (can_cross && (z >> 4) > 1 && ((t + (z & 0xF)) % (z >> 4)) != 0) can_cross = false;
+                    // zipper merge by readiness: of the feeders of tl whose HEAD wants tl, sees an open signal and can reach
+                    // its stop line within this second, the one with the smallest rotating rank (t + rank) % count sends
+                    if (can_cross && (z >> 4) > 1) {
+                        const uint32_t ups = s.up4[tl];
+                        int best = -1, bestp = 1 << 30;
+#pragma unroll
+                        for (int u = 0; u < kMaxUp; ++u) {
+                            const int f = (int)((ups >> (8 * u)) & 0xFFu);
+                            if (f == 0xFF || s.n[f] == 0) continue;
+                            const uint32_t om = s.hm[f];
+                            const int ro = (int)(om >> 16), mo = s.mv[f * NR + ro];
+                            if (mv_tl(mo) != tl) continue;
+                            const int zo = s.zip[f * NR + ro], cnt = zo >> 4;
+                            if (cnt <= 1) continue;
+                            const float xo = s.hx[f], vo = s.hv[f], Lo = s.len[f];
+                            if (!sig_open(tl, mv_k(mo), s.node[f], (int)(om & 0xFFFFu), xo, vo, Lo, link, P.KMAX, P.teleport)) continue;
+                            if (!((Lo - xo) < vo + kAcc)) continue;
+                            const int pr = (t + (zo & 0xF)) % cnt;
+                            if (pr < bestp) { bestp = pr; best = f; }
+                        }
+                        if (best != l) can_cross = false;
+                    }
                     if (can_cross && tl >= 0 && s.n[tl] + kMaxCross > kCap) can_cross = false;
                     if (can_cross && tl >= 0 && s.n[tl] > 0 && s.tx[tl] < kLen) can_cross = false;   // no room behind the tail
                     if (can_cross && ncross >= kMaxCross) can_cross = false;
                     if (tl < -1) can_cross = false;
+                }
+                // teleport (SUMO --time-to-teleport): the head, standing for >= teleport seconds, whose way is still blocked
+                // (merge slot, capacity, no room behind the target's tail) leaves the network where it stands
+                if (i == 0 && !can_cross && tl >= 0 && w >= P.teleport) {
+                    ++arrived;
+                    if constexpr (REC) {
+                        ++rq_arr;
+                        const int k = atomicAdd(&P.n_trips[e], 1);
+                        if (k < P.trip_cap) {
+                            int *tr = P.trips + ((size_t)e * P.trip_cap + k) * 6;
+                            tr[0] = r; tr[1] = (int)(cur.r0 >> 16); tr[2] = (int)(cur.r0 & 0xFFFFu); tr[3] = t + 1;
+                            tr[4] = (int)(cur.r1 & 0xFFFFu); tr[5] = (int)(cur.r1 >> 16);
+                        }
+                    }
+                    ++ncross;
+                    pox = x; pov = v;
+                    cur = nxt;
+                    continue;
                 }
                 const bool line_block = all_crossed ? !can_cross : !open;
                 const bool tgt_lead = can_cross && !sink && s.n[tl] > 0;

@@ -127,7 +127,7 @@ class MicroSim:
         out = (C.c_int64 * 8)()
         self.L.ms_totals(self.h, out)
         return dict(live=out[0], departed=out[1], arrived=out[2], sum_trip=out[3], pending=out[4],
-                    step_departed=out[5], step_arrived=out[6])
+                    step_departed=out[5], step_arrived=out[6], teleported=out[7])
 
     def check(self):
         return self.L.ms_check(self.h)
