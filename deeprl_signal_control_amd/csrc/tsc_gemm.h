@@ -20,6 +20,7 @@
 namespace tsc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum GemmEpi : int {
     EPI_NONE = 0,

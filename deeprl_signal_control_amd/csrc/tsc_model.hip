@@ -33,6 +33,7 @@
 namespace {
 
 using tsc::f32x16;
+using tsc::f32x4;
 using tsc::GemmArgs;
 
 constexpr int kOut = 8;          // padded head width (n_a <= 8; v uses column 0)
@@ -1711,6 +1712,207 @@ dx1w1_kernel(const float *__restrict__ dZ, const float *__restrict__ X1, const f
     if (kh == 0) w[(long long)64 * H + col] = bsum;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same pass re-tiled for an even MFMA load (round 3).  dx1w1_kernel gives a 32-column strip to each of 7 waves and
+// keeps the eighth as a loader: three SIMDs carry two strips, one carries one -- 7/8 of the MFMA rate at best, and every
+// wave waits at the chunk barrier for the slowest SIMD.  Here the unit of work is a 16 x 16 tile of the chunk's dX1
+// (v_mfma_f32_16x16x4_f32): 2 row tiles x H/16 column units per 32-row chunk, dealt out so that the two waves of every
+// SIMD (w, w + 4) own the same number of tiles (H = 224: 4 + 3 of 28), a column unit possibly split between two waves
+// by row tile.  All eight waves compute; the next chunk is fetched into registers at the top of a chunk and written to
+// the other LDS buffer at its end (five 16-byte loads per thread).  A wave keeps the Wx^T slices of its (at most two)
+// column units stationary (64 registers each); per tile 64 MFMAs give dX1, masked by X1 > 0, and the accumulator
+// registers go straight back in as the B operand of 16 MFMAs against the obs tile (contraction order = accumulator row
+// order, the trick of dx1w1_kernel).  Partial dW1 | db1 per (workgroup, row-tile slot), folded by dx1w1_reduce2_kernel.
+// ------------------------------------------------------------------------------------------------
+template <int NCU>   // H / 16
+__global__ void __launch_bounds__(512, 1)
+dx1w1_kernel2(const float *__restrict__ dZ, const float *__restrict__ X1, const float *__restrict__ WxT,
+              const float *__restrict__ obs, long long N, int G, int S, long long rows_per_split, int A, int SMAX,
+              float *__restrict__ ws) {
+    constexpr int H = 16 * NCU, NHU = 2 * NCU;                  // half units (column unit x row tile) per chunk
+    constexpr int CHI = (NHU + 7) / 8, CLO = NHU / 8;           // tiles of waves 0..3 / 4..7
+    static_assert(NHU % 8 == 0 || NHU % 8 == 4, "H must be a multiple of 32");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *Az = (float *)smem_raw;                              // [2][32][kD1Ld]
+    float *Ob = Az + 2 * 32 * kD1Ld;                            // [2][32][kObLd]
+    const int g = blockIdx.x % G, sp = blockIdx.x / G, a = g >> 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, kq = lane >> 4;
+    const long long n0 = (long long)sp * rows_per_split;
+    long long n1 = n0 + rows_per_split;
+    if (n1 > N) n1 = N;
+    const float *dz = dZ + (long long)g * N * kG4, *x1 = X1 + (long long)g * N * H;
+    const long long AS = (long long)A * SMAX;
+    const int sq = SMAX >> 2;
+    float *w = ws + ((long long)sp * G + g) * ((long long)2 * 65 * H);
+    // this wave's half units [st, st + cnt): unit = h >> 1, row tile = h & 1
+    const int st = wave < 4 ? wave * CHI : 4 * CHI + (wave - 4) * CLO, cnt = wave < 4 ? CHI : CLO;
+    const int U0 = st >> 1;
+    const bool a00 = 2 * U0 >= st, a01 = 2 * U0 + 1 < st + cnt, a10 = 2 * U0 + 2 < st + cnt, a11 = 2 * U0 + 3 < st + cnt;
+    const int U1 = U0 + 1 < NCU ? U0 + 1 : NCU - 1;             // clamped when the second slot is unused
+    const int col0 = 16 * U0 + n, col1 = 16 * U1 + n;
+    // stationary B operands: bwX[4 j + c] = Wx^T[k = 16 j + 4 kq + c][col]
+    float bw0[64], bw1[64];
+    {
+        const float *src = WxT + (long long)g * kG4 * H + (long long)(4 * kq) * H;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bw0[4 * j + c] = src[(long long)(16 * j + c) * H + col0];
+                bw1[4 * j + c] = src[(long long)(16 * j + c) * H + col1];
+            }
+    }
+    f32x4 accW[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) accW[u][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum0 = 0.f, bsum1 = 0.f;
+    // staging: thread -> four dZ float4s (rows tid >> 6 + 8 q, 16-byte column tid & 63) and one obs float4
+    const int zr = tid >> 6, zc = tid & 63, orow = tid >> 4, oc = tid & 15;
+    float4 s0, s1, s2, s3, so;
+    auto fetch = [&](long long row0) {
+        auto rowc = [&](long long r) { return r < n1 ? r : n1 - 1; };
+        s0 = *reinterpret_cast<const float4 *>(dz + rowc(row0 + zr) * kG4 + 4 * zc);
+        s1 = *reinterpret_cast<const float4 *>(dz + rowc(row0 + zr + 8) * kG4 + 4 * zc);
+        s2 = *reinterpret_cast<const float4 *>(dz + rowc(row0 + zr + 16) * kG4 + 4 * zc);
+        s3 = *reinterpret_cast<const float4 *>(dz + rowc(row0 + zr + 24) * kG4 + 4 * zc);
+        const float4 o = *reinterpret_cast<const float4 *>(obs + rowc(row0 + orow) * AS + (long long)a * SMAX + 4 * (oc < sq ? oc : 0));
+        so = oc < sq ? o : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto put = [&](int buf) {
+        float *zb = Az + (long long)buf * 32 * kD1Ld + 4 * zc;
+        *reinterpret_cast<float4 *>(zb + (zr) * kD1Ld) = s0;
+        *reinterpret_cast<float4 *>(zb + (zr + 8) * kD1Ld) = s1;
+        *reinterpret_cast<float4 *>(zb + (zr + 16) * kD1Ld) = s2;
+        *reinterpret_cast<float4 *>(zb + (zr + 24) * kD1Ld) = s3;
+        *reinterpret_cast<float4 *>(Ob + ((long long)buf * 32 + orow) * kObLd + 4 * oc) = so;
+    };
+    // one column unit of the chunk in LDS buffer `buf`: both / one of its row tiles
+    auto unit = [&](int buf, long long row, const float (&bw)[64], int col, bool r0, bool r1, f32x4 (&aw)[4], float &bs) {
+        // relu mask rows 16 r + 4 kq + i of column col: requested first, consumed after the 64 / 128 MFMAs
+        float xm0[4], xm1[4];
+        int zq = 0;
+        asm volatile("" : "+v"(zq));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            long long ra = row + 4 * kq + i + zq, rb = ra + 16;
+            if (ra >= n1) ra = n1 - 1;
+            if (rb >= n1) rb = n1 - 1;
+            xm0[i] = x1[ra * H + col];
+            xm1[i] = x1[rb * H + col];
+        }
+        f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float4 *A0 = reinterpret_cast<const float4 *>(Az + ((long long)buf * 32 + n) * kD1Ld + 4 * kq);
+        const float4 *A1 = reinterpret_cast<const float4 *>(Az + ((long long)buf * 32 + 16 + n) * kD1Ld + 4 * kq);
+        if (r0 && r1) {
+            float4 p = A0[0], q = A1[0];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float4 pn = A0[4 * (j + 1 < 16 ? j + 1 : j)], qn = A1[4 * (j + 1 < 16 ? j + 1 : j)];
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p.x, bw[4 * j], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.x, bw[4 * j], c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p.y, bw[4 * j + 1], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.y, bw[4 * j + 1], c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p.z, bw[4 * j + 2], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.z, bw[4 * j + 2], c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p.w, bw[4 * j + 3], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.w, bw[4 * j + 3], c1, 0, 0, 0);
+                p = pn; q = qn;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            const float4 *As = r0 ? A0 : A1;
+            float4 p = As[0];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float4 pn = As[4 * (j + 1 < 16 ? j + 1 : j)];
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p.x, bw[4 * j], c0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p.y, bw[4 * j + 1], c0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p.z, bw[4 * j + 2], c0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p.w, bw[4 * j + 3], c0, 0, 0, 0);
+                p = pn;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!r0) { c1 = c0; }
+        }
+        // dW1 += obs^T dX1 : contraction step i takes rows 16 r + 4 kq + i = the accumulator's own rows
+        auto tail = [&](int r, const f32x4 &c, const float (&xm)[4]) {
+            const float *Os = Ob + ((long long)buf * 32 + 16 * r + 4 * kq) * kObLd + n;
+            float d[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d[i] = (xm[i] > 0.f && row + 16 * r + 4 * kq + i < n1) ? c[i] : 0.f;
+                bs += d[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft)
+                    aw[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(Os[i * kObLd + 16 * ft], d[i], aw[ft], 0, 0, 0);
+        };
+        if (r0) tail(0, c0, xm0);
+        if (r1) tail(1, c1, xm1);
+    };
+    if (n0 < n1) {
+        fetch(n0);
+        put(0);
+        __syncthreads();
+        int buf = 0;
+        for (long long row = n0; row < n1; row += 32, buf ^= 1) {
+            fetch(row + 32);                                    // lands while this chunk computes
+            if (a00 || a01) unit(buf, row, bw0, col0, a00, a01, accW[0], bsum0);
+            if (a10 || a11) unit(buf, row, bw1, col1, a10, a11, accW[1], bsum1);
+            put(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // partial results: slot 0 = row tile 0 (or both tiles of a unit owned by one wave), slot 1 = row tile 1 alone
+    auto flush = [&](const f32x4 (&aw)[4], float bs, int col, bool r0, bool r1) {
+        float *w0 = w + (long long)((r0 ? 0 : 1) * 65) * H;
+        float *wz = w + (long long)65 * H;                      // slot 1, zeroed by the owner of both tiles
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = 16 * ft + 4 * kq + i;
+                w0[(long long)f * H + col] = aw[ft][i];
+                if (r0 && r1) wz[(long long)f * H + col] = 0.f;
+            }
+        bs += __shfl_xor(bs, 16, 64);
+        bs += __shfl_xor(bs, 32, 64);
+        if (kq == 0) {
+            w0[(long long)64 * H + col] = bs;
+            if (r0 && r1) wz[(long long)64 * H + col] = 0.f;
+        }
+    };
+    if (a00 || a01) flush(accW[0], bsum0, col0, a00, a01);
+    if (a10 || a11) flush(accW[1], bsum1, col1, a10, a11);
+}
+
+// grads[g][oW1 .. +SMAX*H) and [ob1 .. +H) = sum over (split, row-tile slot) in that order; structural zeros of W1 applied
+__global__ void dx1w1_reduce2_kernel(const float *__restrict__ ws, int G, int S, int H, int SMAX, const int16_t *__restrict__ rr,
+                                     float *__restrict__ grads, long long stride, long long oW1, long long ob1) {
+    const long long per = (long long)65 * H, out = (long long)(SMAX + 1) * H;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= out * G) return;
+    const long long g = i / out, j = i % out;
+    const int f = (int)(j / H), n = (int)(j % H);
+    const long long src = f < SMAX ? j : (long long)64 * H + n;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) {
+        acc += ws[(((long long)s * G + g) * 2 + 0) * per + src];
+        acc += ws[(((long long)s * G + g) * 2 + 1) * per + src];
+    }
+    if (f < SMAX) {
+        const int16_t *q = rr + ((g >> 1) * SMAX + f) * 2;
+        if (n < q[0] || n >= q[1]) acc = 0.f;
+        grads[g * stride + oW1 + j] = acc;
+    } else {
+        grads[g * stride + ob1 + n] = acc;
+    }
+}
+
 // grads[g][oW1 .. +SMAX*H) and [ob1 .. +H) = sum over splits, in split order; structural zeros of W1 applied
 __global__ void dx1w1_reduce_kernel(const float *__restrict__ ws, int G, int S, int H, int SMAX, const int16_t *__restrict__ rr,
                                     float *__restrict__ grads, long long stride, long long oW1, long long ob1) {
@@ -1758,6 +1960,7 @@ struct tsc_model {
     int fused_fwd;
     int fused_dw;               // dWx | dWh | dbl in one pass (dwxh_kernel)
     int fused_dx;               // dX1 in registers, dW1 | db1 in the same pass (dx1w1_kernel)
+    int dx_v2;                  // ... as 16 x 16 tiles dealt evenly over the SIMDs (dx1w1_kernel2; TSC_DX_V2=0: the strip kernel)
     int cached_next;            // next rollout slot whose activations the fused forward will cache; T = all cached
     long long *dbg;
     long long nparam;
@@ -1887,10 +2090,16 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     if (const char *ev = getenv("TSC_UNFUSED_FWD")) if (atoi(ev)) m->fused_fwd = 0;
     m->fused_dw = !L.fc && (L.H == 224 || L.H == 160);
     if (const char *ev = getenv("TSC_UNFUSED_DW")) if (atoi(ev)) m->fused_dw = 0;
-    m->fused_dx = !L.fc && (L.H == 224 || L.H == 160) && L.SMAX <= 64 && L.SMAX % 4 == 0;
+    m->dx_v2 = 1;
+    if (const char *ev = getenv("TSC_DX_V2")) m->dx_v2 = atoi(ev);
+    m->fused_dx = !L.fc && (L.H == 224 || L.H == 160 || (m->dx_v2 && (L.H == 192 || L.H == 128))) && L.SMAX <= 64 && L.SMAX % 4 == 0;
     if (const char *ev = getenv("TSC_UNFUSED_DX")) if (atoi(ev)) m->fused_dx = 0;
     if (m->fused_dx) {
         const int lds = (int)(sizeof(float) * (2 * 32 * kD1Ld + 2 * 32 * kObLd));
+        TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel2<14>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel2<10>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel2<12>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel2<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
@@ -2219,11 +2428,23 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
     if (gemm(m, tsc::KID_DWX_GEMM, true, tsc::EPI_NONE, (int)G, L.H, kG4, (int)N, m->X1, N * L.H, L.H, 1, m->Z, N * kG4, kG4, g + L.oWx, L.stride,
              kG4, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, 0)) return tsc::fail("gemm failed");
     }
-    if (m->fused_dx && L.ob1 == L.oW1 + (long long)L.SMAX * L.H && (size_t)((long long)S * G * 65 * L.H) <= m->ws_floats) {
+    if (m->fused_dx && L.ob1 == L.oW1 + (long long)L.SMAX * L.H && (size_t)((long long)S * G * 2 * 65 * L.H) <= m->ws_floats) {
         // dX1 stays in registers: dW1 | db1 come out of the same pass (dx1w1_kernel)
         long long rps = (N + S - 1) / S;
         rps = (rps + 31) / 32 * 32;                  // whole 32-row chunks
         const size_t lds = sizeof(float) * (2 * 32 * kD1Ld + 2 * 32 * kObLd);
+        if (m->dx_v2) {
+            {
+                tsc::ProfScope ps(tsc::KID_DX1_GEMM, m->stream);
+#define TSC_DX2(NCU) hipLaunchKernelGGL(dx1w1_kernel2<NCU>, dim3((unsigned)(S * G)), dim3(512), lds, st, m->Z, m->X1, m->WxT, m->r_obs, N, (int)G, S, rps, (int)A, L.SMAX, m->ws)
+                if (L.H == 224) TSC_DX2(14); else if (L.H == 160) TSC_DX2(10); else if (L.H == 192) TSC_DX2(12); else TSC_DX2(8);
+#undef TSC_DX2
+            }
+            tsc::ProfScope ps(tsc::KID_DW1_GEMM, m->stream);
+            const long long tot = (long long)(L.SMAX + 1) * L.H * G;
+            hipLaunchKernelGGL(dx1w1_reduce2_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m->ws, (int)G, S, L.H, L.SMAX,
+                               m->rowrange, g, L.stride, L.oW1, L.ob1);
+        } else {
         {
             tsc::ProfScope ps(tsc::KID_DX1_GEMM, m->stream);
             if (L.H == 224) hipLaunchKernelGGL(dx1w1_kernel<7>, dim3((unsigned)(S * G)), dim3(512), lds, st, m->Z, m->X1, m->WxT, m->r_obs, N, (int)G, S, rps, (int)A, L.SMAX, m->ws);
@@ -2234,6 +2455,7 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
             const long long tot = (long long)(L.SMAX + 1) * L.H * G;
             hipLaunchKernelGGL(dx1w1_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m->ws, (int)G, S, L.H, L.SMAX,
                                m->rowrange, g, L.stride, L.oW1, L.ob1);
+        }
         }
         TSC_HIP(hipGetLastError());
         m->cached_next = 0;
