@@ -309,7 +309,8 @@ class VecA2C:
         dist = torch.distributed
         self.rank = dist.get_rank(process_group) if dist.is_available() and dist.is_initialized() else 0
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
-        self.sample_seed = replica_sample_seed(0 if seed is None else seed, self.rank, replica)
+        self.base_seed, self.replica = (0 if seed is None else int(seed)), int(replica)
+        self.sample_seed = replica_sample_seed(self.base_seed, self.rank, replica)
         self.init_params(seed)
         self.sync_replicas()
 
@@ -501,7 +502,7 @@ class VecA2C:
         np.savez(os.path.join(model_dir, 'checkpoint-%d.npz' % int(global_step)), params=self.get_flat('params'),
                  ms=self.get_flat('ms'), layout=np.array(self.layout.as_tuple() + (self.s_max,), np.int64),
                  dims=np.array([self.n_wave_ls, self.n_w_ls, self.n_f_ls, self.n_a_ls], np.int64),
-                 counters=np.array([self.sample_step, self.sample_seed, self.lr_scheduler.n, self.beta_scheduler.n], np.int64))
+                 counters=np.array([self.sample_step, self.base_seed, self.lr_scheduler.n, self.beta_scheduler.n], np.int64))
 
     def load(self, model_dir, checkpoint=None):
         save_file, save_step = None, 0
@@ -529,8 +530,10 @@ class VecA2C:
                              % (save_file, tuple(int(x) for x in z['layout']), want, p.size, self.n_param))
         _lib.check(self._L.tsc_model_set_params(self._h, p.ctypes.data_as(C.c_void_p)))
         _lib.check(self._L.tsc_model_set_opt_state(self._h, ms.ctypes.data_as(C.c_void_p)))
-        if 'counters' in z.files:            # action-RNG stream and lr / beta schedules resume where they stopped
-            self.sample_step, self.sample_seed = int(z['counters'][0]), int(z['counters'][1])
+        if 'counters' in z.files:            # action-RNG stream and lr / beta schedules resume where they stopped; the checkpoint holds
+            # the BASE seed, every rank / replica re-derives its own stream from it (independent exploration survives a resume)
+            self.sample_step, self.base_seed = int(z['counters'][0]), int(z['counters'][1])
+            self.sample_seed = replica_sample_seed(self.base_seed, self.rank, self.replica)
             self.lr_scheduler.n, self.beta_scheduler.n = int(z['counters'][2]), int(z['counters'][3])
         return True
 

@@ -1961,6 +1961,7 @@ struct tsc_model {
     int fused_dw;               // dWx | dWh | dbl in one pass (dwxh_kernel)
     int fused_dx;               // dX1 in registers, dW1 | db1 in the same pass (dx1w1_kernel)
     int dx_v2;                  // ... as 16 x 16 tiles dealt evenly over the SIMDs (dx1w1_kernel2; TSC_DX_V2=0: the strip kernel)
+    int inplace;                // the running rollout is written straight into the buffer's slots (tsc_model_rollout_slot): slot T -> 0 carry
     int cached_next;            // next rollout slot whose activations the fused forward will cache; T = all cached
     long long *dbg;
     long long nparam;
@@ -2082,6 +2083,7 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bwd));
     m->dbg = nullptr;
     m->cached_next = 0;
+    m->inplace = 0;
     m->lds_fused = sizeof(float) * ((size_t)(L.H + 64) * kXLd + kL * kOut + kOut + 8);   // activations + head weights
     m->fused_fwd = !L.fc && (L.H % 32 == 0) && (L.SMAX <= 64) && (L.SMAX % 4 == 0) && ((L.H + 64) % 8 == 0) && m->lds_fused <= 160 * 1024;
     if (const char *ev = getenv("TSC_DBG_THREAD")) m->dbg_tid = atoi(ev);
@@ -2284,6 +2286,8 @@ int tsc_model_forward(tsc_model *m, const float *obs, const uint8_t *done, float
 int tsc_model_forward_sample(tsc_model *m, const float *obs, const uint8_t *done, float *pi, float *v, int32_t *action,
                              uint64_t seed, uint64_t step, int32_t t_slot) {
     if (!action) return tsc::fail("tsc_model_forward_sample: bad arguments");
+    if (m && t_slot >= 0 && t_slot < m->T)      // a forward that reads its observation from slot t_slot is a zero-copy rollout
+        m->inplace = obs == m->r_obs + (size_t)t_slot * m->E * m->lay.A * m->lay.SMAX;
     return model_forward(m, obs, done, pi, v, 1, action, seed, step, t_slot);
 }
 
@@ -2303,6 +2307,7 @@ int tsc_model_add_transition(tsc_model *m, int32_t t, const float *obs, const ui
     if (!m || t < 0 || t >= m->T) return tsc::fail("tsc_model_add_transition: slot %d outside [0,%d)", t, m->T);
     const Layout &L = m->lay;
     const long long E = m->E, A = L.A, no = E * A * L.SMAX;
+    if (obs != m->r_obs + (size_t)t * no) m->inplace = 0;     // a copied transition: slot T is not part of this rollout
     tsc::ProfScope ps5(tsc::KID_ADD_TRANS, m->stream);
     hipLaunchKernelGGL(add_transition_kernel, dim3((unsigned)((no + 255) / 256)), dim3(256), 0, m->stream, (int)E, (int)A,
                        L.SMAX, obs, done_pre, action, reward, value, done_post, m->r_obs + t * no,
@@ -2498,9 +2503,11 @@ int tsc_model_apply_grads(tsc_model *m, double lr, double grad_scale, double *st
     // states_bw <- states_fw (policies.py:153); buffer.reset(dones[-1]) (utils.py:227)
     TSC_HIP(hipMemcpyAsync(m->state_bw, m->state_fw, sizeof(float) * (size_t)L.G * m->E * 2 * kL, hipMemcpyDeviceToDevice, st));
     TSC_HIP(hipMemcpyAsync(m->r_done, m->r_done + (size_t)m->T * m->E, m->E, hipMemcpyDeviceToDevice, st));
-    // zero-copy rollouts: the observation the env wrote into slot T is the first observation of the next rollout
-    TSC_HIP(hipMemcpyAsync(m->r_obs, m->r_obs + (size_t)m->T * m->E * L.A * L.SMAX, sizeof(float) * (size_t)m->E * L.A * L.SMAX,
-                           hipMemcpyDeviceToDevice, st));
+    // zero-copy rollouts only: the observation the env wrote into slot T is the first observation of the next rollout
+    // (on the add_transition path slot T is never written and slot 0 belongs to the caller's next add_transition(t = 0))
+    if (m->inplace)
+        TSC_HIP(hipMemcpyAsync(m->r_obs, m->r_obs + (size_t)m->T * m->E * L.A * L.SMAX, sizeof(float) * (size_t)m->E * L.A * L.SMAX,
+                               hipMemcpyDeviceToDevice, st));
     if (stats_host) {
         std::vector<double> s(L.A * 4), n2(L.A);
         TSC_HIP(hipStreamSynchronize(st));

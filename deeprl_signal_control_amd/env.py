@@ -88,6 +88,7 @@ class VecTrafficEnv:
         statistics of _measure_traffic_step (:409-437), per control step the control log (:581-588) and a log of finished
         trips (:498-515), per env instance.  Uses the recording instantiation of the step kernel (plain lane walk)."""
         self.is_record = bool(on)
+        self.trip_cap = int(trip_cap)
         if self.is_record or getattr(self, '_rec_alloc', False):
             _lib.check(self._L.tsc_env_record(self._h, int(self.is_record), int(trip_cap)))
             self._rec_alloc = True
@@ -127,11 +128,14 @@ class VecTrafficEnv:
         buf = np.zeros((8192, 6), np.int32)
         for e in range(self.E):
             cnt = C.c_int32()
-            while True:
-                _lib.check(self._L.tsc_env_read_trips(self._h, e, buf.ctypes.data_as(C.c_void_p), len(buf), C.byref(cnt)))
-                if cnt.value <= len(buf):
-                    break
+            _lib.check(self._L.tsc_env_read_trips(self._h, e, buf.ctypes.data_as(C.c_void_p), len(buf), C.byref(cnt)))
+            cap = getattr(self, 'trip_cap', len(buf))
+            if cnt.value > cap:              # the kernel keeps the first trip_cap trips of an instance and counts the rest
+                raise RuntimeError('instance %d finished %d trips, the trip log holds %d: call set_record(True, trip_cap=...) '
+                                   'with a larger capacity' % (e, cnt.value, cap))
+            if cnt.value > len(buf):
                 buf = np.zeros((cnt.value, 6), np.int32)
+                _lib.check(self._L.tsc_env_read_trips(self._h, e, buf.ctypes.data_as(C.c_void_p), len(buf), C.byref(cnt)))
             tr = buf[:cnt.value]
             tr = tr[np.lexsort((tr[:, 1], tr[:, 0], tr[:, 3]))]
             for r, ser, dep, arr, wsec, wcnt in tr:

@@ -189,7 +189,8 @@ class VecIQL:
         dist = torch.distributed
         self.rank = dist.get_rank(process_group) if dist.is_available() and dist.is_initialized() else 0
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
-        self.sample_seed = replica_sample_seed(0 if seed is None else seed, self.rank, replica)
+        self.base_seed, self.replica = (0 if seed is None else int(seed)), int(replica)
+        self.sample_seed = replica_sample_seed(self.base_seed, self.rank, replica)
         self.replay_seed = self.sample_seed ^ 0x5DEECE66D
         self.act_step = 0           # forward(mode='explore' / stochastic) calls so far: the action-RNG counter
         self.update_step = 0        # minibatch steps so far: the replay-sampling counter
@@ -324,7 +325,7 @@ class VecIQL:
         m, v, t = self.get_opt_state()
         np.savez(os.path.join(model_dir, 'checkpoint-%d.npz' % int(global_step)), params=self.get_flat(), adam_m=m, adam_v=v,
                  layout=np.array(self.layout.as_tuple() + (self.s_max,), np.int64),
-                 counters=np.array([t, self.act_step, self.update_step, self.sample_seed, self.lr_scheduler.n, self.eps_scheduler.n], np.int64))
+                 counters=np.array([t, self.act_step, self.update_step, self.base_seed, self.lr_scheduler.n, self.eps_scheduler.n], np.int64))
 
     def load(self, model_dir, checkpoint=None):
         save_file, save_step = None, 0
@@ -347,7 +348,8 @@ class VecIQL:
         m, v = np.ascontiguousarray(z['adam_m'], np.float32), np.ascontiguousarray(z['adam_v'], np.float32)
         c = [int(x) for x in z['counters']]
         _lib.check(self._L.tsc_iql_set_opt_state(self._h, m.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), c[0]))
-        self.act_step, self.update_step, self.sample_seed = c[1], c[2], c[3]
+        self.act_step, self.update_step, self.base_seed = c[1], c[2], c[3]     # the BASE seed: every rank / replica re-derives its stream
+        self.sample_seed = replica_sample_seed(self.base_seed, self.rank, self.replica)
         self.replay_seed = self.sample_seed ^ 0x5DEECE66D
         self.lr_scheduler.n, self.eps_scheduler.n = c[4], c[5]
         return True

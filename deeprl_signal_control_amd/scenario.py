@@ -662,6 +662,11 @@ def contract_chains(scn: Scenario) -> Scenario:
         if scn.lane_node[a] >= 0 or ends[a] or len(nxt[a]) != 1:
             continue
         b = next(iter(nxt[a]))
+        # a movement of A that yields or has priority at the junction A -> B is a right-of-way relation the merged lane
+        # would silently drop: such a junction stays (none on the reference's Monaco routes, asserted by
+        # tests/test_scenario_tables.py)
+        if (scn.mv_yield[a] >= 0).any() or (scn.mv_prio[a] != 0).any():
+            continue
         if ups[b] == [a] and b != a:
             cand[a] = b
     # a merged lane must still fit its vehicles into LANE_CAP slots: grow chains from their downstream end while the

@@ -186,8 +186,7 @@ class VecTrainer:
             r = torch.stack(self._ep_rewards)                       # [T, E]
             mean, std = float(r.mean(0).mean().item()), float(r.std(0, unbiased=False).mean().item())
             data.append({'agent': self.agent, 'step': self.global_counter.cur_step, 'test_id': -1, 'avg_reward': mean, 'std_reward': std})
-            if self.global_counter.should_log() or True:
-                logging.info('Training: global step %d, episode %d, avg R: %.2f' % (self.global_counter.cur_step, self.env.cur_episode, mean))
+            logging.info('Training: global step %d, episode %d, avg R: %.2f' % (self.global_counter.cur_step, self.env.cur_episode, mean))
             self.ob = None
         self.log_rewards = was
         return data

@@ -163,3 +163,33 @@ def test_live_lanes_are_a_prefix_after_load_sorting(name):
                     c = int(scn.mv_next[c][r])
                 if l in chain:
                     assert t in reach
+
+
+def test_chain_clamp_closed_form_equals_the_recurrence():
+    """DESIGN.md section 3 rule 4 / ADVICE r02: the queue clamp behind the first vehicle that stays is evaluated as an
+    exclusive prefix-min over keys (x'_i = max(x_i, min(a_i, K_{i-1} - 5 i)), K_i = min(K_{i-1}, a_i + 5 i)) so that the HIP
+    kernel can scan it.  On random queues it equals the sequential recurrence x'_i = max(x_i, min(a_i, x'_{i-1} - 5)): with the
+    spec's invariant (old spacing >= 5 m, nobody moves backward) the no-backward clamp never binds -- x'_{i-1} - 5 >= x_{i-1} - 5
+    >= x_i -- which is the only place where the two forms could part; the test checks that too."""
+    rng = np.random.RandomState(4)
+    worst = 0.0
+    for _ in range(2000):
+        n = rng.randint(2, 27)
+        gaps = 5.0 + rng.exponential(1.5, n) * (rng.rand(n) < 0.7)
+        x = np.float32(180.0) - np.cumsum(gaps).astype(np.float32)          # front first, spacing >= 5 m
+        a = np.minimum(x + (rng.rand(n) * 6).astype(np.float32), np.float32(200.0))
+        first = np.float32(min(a[0], 200.0))
+        seq = [first]                                                        # the sequential recurrence
+        for i in range(1, n):
+            inner = min(a[i], np.float32(seq[-1] - np.float32(5.0)))
+            assert inner >= x[i] - 1e-3                                      # the no-backward clamp cannot bind
+            seq.append(max(x[i], inner))
+        K = np.float32(first + np.float32(0.0))                              # the closed form (oracle/microsim.c, csrc/tsc_env.hip)
+        cf = [first]
+        for i in range(1, n):
+            cf.append(max(x[i], min(a[i], np.float32(K - np.float32(5 * i)))))
+            K = min(K, np.float32(a[i] + np.float32(5 * i)))
+        seq, cf = np.array(seq, np.float64), np.array(cf, np.float64)
+        assert np.all(cf[:-1] - cf[1:] >= 5.0 - 1e-3)                        # spacing kept
+        worst = max(worst, np.abs(cf - seq).max())
+    assert worst < 1e-3                                                      # float32 rounding of the keys only

@@ -37,3 +37,13 @@ def test_specialised_kernel_dimensions_match_the_scenarios():
         assert (ctrl, yellow, teleport) == (scn.control_interval_sec, scn.yellow_interval_sec, scn.teleport_sec)
     ia = build_large_grid('ia2c')                          # same tables, narrower observations: same instantiation
     assert (ia.n_lane, ia.n_route, ia.n_agent) == (180, 12, 25)
+
+
+def test_contracted_chains_drop_no_right_of_way_relation():
+    """contract_chains refuses to merge a lane whose movements yield or have priority; on the reference's Monaco
+    routes no such movement exists (every unsignalised merge is a zipper), so the contraction (160 -> 113 live lanes) loses
+    nothing."""
+    from deeprl_signal_control_amd.scenario import build_real_net
+    scn = build_real_net('ma2c')
+    assert int((scn.mv_yield >= 0).sum()) == 0 and int((scn.mv_prio != 0).sum()) == 0
+    assert scn.n_lane == 158
