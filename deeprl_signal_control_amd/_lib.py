@@ -31,6 +31,9 @@ class TscScenario(C.Structure):
         ('coop_gamma', C.c_double), ('norm_wave', C.c_double), ('norm_wait', C.c_double),
         ('clip_wave', C.c_double), ('clip_wait', C.c_double), ('coef_wait', C.c_double),
         ('lane_origin', _fp),
+        ('n_stream', C.c_int32), ('k_choice', C.c_int32),
+        ('stream_entry', _ip), ('stream_origin', _fp), ('stream_limit', _fp), ('stream_mode', _ip), ('stream_choice', _ip),
+        ('n_interval', C.c_int32), ('choice_interval_sec', C.c_int32),
     ]
 
 
@@ -39,7 +42,7 @@ _LIB = None
 # every symbol include/tsc.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = ['tsc_last_error', 'tsc_version', 'tsc_profile_enable', 'tsc_profile_reset', 'tsc_profile_read',
            'tsc_profile_name', 'tsc_env_create', 'tsc_env_destroy', 'tsc_env_set_stream',
-           'tsc_env_reset', 'tsc_env_set_fingerprint', 'tsc_env_bind_fingerprint', 'tsc_env_reward_sum', 'tsc_env_step', 'tsc_env_get_state',
+           'tsc_env_reset', 'tsc_env_set_stream_routes', 'tsc_env_set_fingerprint', 'tsc_env_bind_fingerprint', 'tsc_env_reward_sum', 'tsc_env_step', 'tsc_env_get_state',
            'tsc_env_live_vehicles', 'tsc_env_debug_clock', 'tsc_env_live_sum', 'tsc_env_record', 'tsc_env_read_record', 'tsc_env_read_trips',
            'tsc_model_create', 'tsc_model_destroy', 'tsc_model_set_stream', 'tsc_model_layout',
            'tsc_model_set_params', 'tsc_model_reset_opt_state', 'tsc_model_debug_read', 'tsc_model_get_params', 'tsc_model_get_opt_state', 'tsc_model_set_opt_state',
@@ -72,6 +75,7 @@ def lib():
     L.tsc_env_destroy.argtypes = [vp]
     L.tsc_env_set_stream.argtypes = [vp, vp]
     L.tsc_env_reset.argtypes = [vp, C.POINTER(C.c_uint32), vp]
+    L.tsc_env_set_stream_routes.argtypes = [vp, _ip]
     L.tsc_env_set_fingerprint.argtypes = [vp, vp]
     L.tsc_env_bind_fingerprint.argtypes = [vp, vp]
     L.tsc_env_reward_sum.argtypes = [vp, C.POINTER(C.c_double), C.c_int32]
@@ -130,6 +134,15 @@ def scenario_struct(scn):
         coop_gamma=scn.coop_gamma, norm_wave=scn.norm_wave, norm_wait=scn.norm_wait,
         clip_wave=scn.clip_wave, clip_wait=scn.clip_wait, coef_wait=scn.coef_wait,
         lane_origin=arr(scn.lane_origin, np.float32, _fp))
+    scn.streams_ready()
+    if scn.stream_entry_lane is not None:
+        s.n_stream, s.k_choice = int(scn.n_stream), int(scn.stream_choice.shape[2])
+        s.n_interval, s.choice_interval_sec = int(scn.stream_choice.shape[1]), int(min(scn.choice_interval_sec, 1 << 30))
+        s.stream_limit = arr(scn.stream_limit, np.float32, _fp)
+        s.stream_entry = arr(scn.stream_entry_lane, np.int32, _ip)
+        s.stream_origin = arr(scn.stream_origin, np.float32, _fp)
+        s.stream_mode = arr(scn.stream_mode, np.int32, _ip)
+        s.stream_choice = arr(scn.stream_choice, np.int32, _ip)
     return s, keep
 
 

@@ -46,17 +46,24 @@ __host__ __device__ __forceinline__ bool mv_prio(int w) { return (w >> 30) & 1; 
 
 struct EnvDev {
     int NL, NLP, NR, A, NF, KMAX, PMAX, LMAX, SMAX, NBR, E;
+    int NS, KC;                    // insertion streams (= NR when every route is its own stream), route choices per stream
     int NU, NLA;                   // lanes that can ever hold a vehicle (prefix after load sorting), rounded up to wavefronts
     int help;                      // phase A1 enabled (step_kernel)
     const float *lane_len, *lane_vmax, *lane_det;
     const int *lane_node, *lane_up;
     const int *mv;                 // [NL*NR] packed movement word, see mv_* helpers
     const uint8_t *zip;            // [NL*NR] zipper-merge slot: rank | count << 4 (0 = none)
-    const int *route_entry;        // [NR]
-    const int *flow_ptr;           // [NR+1] CSR over flows sorted by route
+    const int *route_entry;        // [NS] entry lane of every stream
+    const int *flow_ptr;           // [NS+1] CSR over flows sorted by stream
+    const int *sroute;             // [NS] route of a stream's vehicles (-1: drawn); null = the stream index itself
+    const int *smode;              // [NS] 0 fixed, 1 per-vehicle draw from schoice, 2 per-instance route (iroute)
+    const int *schoice;            // [NS][KC][2] (route, cumulative weight of 65536)
+    const float *sorigin;          // [NS][2] the stretch of the entry lane vehicles are inserted on, or null (whole lane)
+    int NI, ilen;                  // choice intervals per stream and their length in seconds
+    int *iroute;                   // [E][NS] routes of the mode-2 streams of the running episode
     const int *flows;              // [NF*4] begin,end,vph,route (sorted by route, stable)
     const uint32_t *lane_routes;   // [NL][2] the (<= kMaxEntry) routes whose entry lane this is, one byte each, 0xFF = none
-    const uint8_t *emit_tab;       // [NR][emit_len] vehicles each route's flows emit at second t
+    const uint8_t *emit_tab;       // [NS][emit_len] vehicles each stream's flows emit at second t
     int emit_len;
     const int *agent_lanes, *agent_nlane, *agent_nlink, *agent_nphase;
     const uint8_t *green_tab, *yellow_tab;
@@ -67,7 +74,7 @@ struct EnvDev {
     float *X, *V, *SF;
     uint32_t *M;                   // w | route << 16
     int *N;                        // [E][NLP]
-    int *pending, *serial;         // [E][NR]
+    int *pending, *serial;         // [E][NS]
     int *tsec;
     uint32_t *seed;
     int *prev_action;              // [E][A]
@@ -154,7 +161,7 @@ struct Smem {
     double *r;                                  // local rewards [A] (+1 for global)
     uint8_t *link_y, *link_g;                   // [A*KMAX]
     float *len, *vmax; int *node;               // lane length / speed limit / downstream agent [NLA]
-    int *pend, *ser; uint8_t *emit;             // per-route insertion state [NR], emissions [NR*8]
+    int *pend, *ser; uint8_t *emit;             // per-stream insertion state [NS], emissions [NS*8]
     uint8_t *zip;                               // [NU*NR]
     uint32_t *up4;                              // [NLA] the lane's feeders, a byte each (0xFF = none): merge arbitration
     int *pre, *wtot;                            // wave-local inclusive scan of queued vehicles [NLA], wave totals [16]
@@ -178,7 +185,7 @@ __host__ __device__ __forceinline__ void smem_layout(Smem &s, const EnvDev &P, T
     s.wave = (int *)take(4 * P.NLP); s.halt = (int *)take(4 * P.NLP); s.hwait = (int *)take(4 * P.NLP);
     s.link_y = (uint8_t *)take(P.A * P.KMAX); s.link_g = (uint8_t *)take(P.A * P.KMAX);
     s.len = (float *)take(4 * P.NLA); s.vmax = (float *)take(4 * P.NLA); s.node = (int *)take(4 * P.NLA);
-    s.pend = (int *)take(4 * P.NR); s.ser = (int *)take(4 * P.NR); s.emit = (uint8_t *)take(8 * P.NR);
+    s.pend = (int *)take(4 * P.NS); s.ser = (int *)take(4 * P.NS); s.emit = (uint8_t *)take(8 * P.NS);
     s.zip = (uint8_t *)take((P.NU * P.NR + 3) / 4 * 4);
     s.up4 = (uint32_t *)take(4 * P.NLA);
     s.pre = (int *)take(4 * P.NLA); s.wtot = (int *)take(4 * 16);
@@ -248,9 +255,9 @@ __global__ void reset_kernel(EnvDev P, const uint32_t *seeds, float *obs) {
     Smem s = carve(smem_raw, P);
     const int e = blockIdx.x, l = threadIdx.x;
     if (l < P.NLP) { P.N[(size_t)e * P.NLP + l] = 0; s.wave[l] = 0; s.hwait[l] = 0; }
-    for (int r = l; r < P.NR; r += blockDim.x) {
-        P.pending[(size_t)e * P.NR + r] = 0;
-        P.serial[(size_t)e * P.NR + r] = 0;
+    for (int r = l; r < P.NS; r += blockDim.x) {
+        P.pending[(size_t)e * P.NS + r] = 0;
+        P.serial[(size_t)e * P.NS + r] = 0;
     }
     for (int a = l; a < P.A; a += blockDim.x) {
         P.prev_action[(size_t)e * P.A + a] = 0;                    // envs/env.py:448
@@ -294,9 +301,10 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         constexpr SpecDims D = kSpec[SPEC];
         P.NLP = D.NLP; P.NLA = D.NLA; P.NU = D.NU; P.NR = D.NR; P.A = D.A; P.KMAX = D.KMAX;
         P.PMAX = D.PMAX; P.LMAX = D.LMAX; P.NBR = D.NBR; P.ctrl = D.ctrl; P.yellow = D.yellow; P.teleport = D.teleport;
+        P.NS = D.NR;                            // the reference's configurations: every route is its own stream
     }
     Smem s = carve(smem_raw, P);
-    const int e = blockIdx.x, l = threadIdx.x, NLP = P.NLP, NLA = P.NLA, NR = P.NR;
+    const int e = blockIdx.x, l = threadIdx.x, NLP = P.NLP, NLA = P.NLA, NR = P.NR, NS = P.NS;
     const bool lane = l < P.NU;             // lanes >= NU are never entered by any route: always empty
     const bool lthr = l < NLA;              // threads >= NLA only help in phase A1 and in the strided loops
     const bool stamp = P.dbg && blockIdx.x == 0 && threadIdx.x == 0;
@@ -327,8 +335,8 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     uint32_t myr_lo = P.lane_routes[lc * 2], myr_hi = P.lane_routes[lc * 2 + 1];     // entry routes, a byte each
     int t = P.tsec[e];
     const uint32_t seed = P.seed[e];
-    const int rc = l < NR ? l : NR - 1;
-    const int pend0 = P.pending[(size_t)e * NR + rc], ser0 = P.serial[(size_t)e * NR + rc];
+    const int rc = l < NS ? l : NS - 1;
+    const int pend0 = P.pending[(size_t)e * NS + rc], ser0 = P.serial[(size_t)e * NS + rc];
     if (!lane) {
         n = 0; L = 1.0f; vmax = 1.0f; det = 0.0f; my_node = -1; up0 = up1 = up2 = up3 = -1;
         myr_lo = myr_hi = 0xFFFFFFFFu;
@@ -361,12 +369,12 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         for (int k = 0; k < P.KMAX; ++k) { s.link_y[l * P.KMAX + k] = y[k]; s.link_g[l * P.KMAX + k] = g[k]; }
     }
     // per-route insertion state and this step's emissions live in LDS for the duration of the launch
-    if (l < NR) {
+    if (l < NS) {
         s.pend[l] = pend0; s.ser[l] = ser0;
         for (int q = 0; q < 8; ++q) s.emit[l * 8 + q] = q < P.ctrl ? P.emit_tab[(size_t)l * P.emit_len + t + q] : 0;
     }
-    for (int r = blockDim.x + l; r < NR; r += blockDim.x) {              // more routes than threads (not on the reference scenarios)
-        s.pend[r] = P.pending[(size_t)e * NR + r]; s.ser[r] = P.serial[(size_t)e * NR + r];
+    for (int r = blockDim.x + l; r < NS; r += blockDim.x) {              // more streams than threads (not on the reference scenarios)
+        s.pend[r] = P.pending[(size_t)e * NS + r]; s.ser[r] = P.serial[(size_t)e * NS + r];
         for (int q = 0; q < 8; ++q) s.emit[r * 8 + q] = q < P.ctrl ? P.emit_tab[(size_t)r * P.emit_len + t + q] : 0;
     }
     for (int a2 = blockDim.x + l; a2 < P.A; a2 += blockDim.x) {          // more agents than threads (ditto)
@@ -795,14 +803,37 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 int ser = s.ser[r];
                 if (pend > 0 && n < kCap) {
                     const float xt = n > 0 ? tx : (L + kLen) + kS0;
-                    const float xmax = (xt - kLen) - kS0;
-                    if (!(xmax < kLen)) {
+                    float xmax = (xt - kLen) - kS0;
+                    float xlo = kLen;
+                    if (P.sorigin) {                                 // the SUMO entry lane is one piece of this (contracted) lane
+                        xlo = P.sorigin[2 * r] + kLen;
+                        const float hi = P.sorigin[2 * r + 1];
+                        if (xmax > hi) xmax = hi;
+                    }
+                    if (!(xmax < xlo)) {
                         const float u0 = u01(hash32(seed, (uint32_t)r, (uint32_t)ser, 0));
                         const float u1 = u01(hash32(seed, (uint32_t)r, (uint32_t)ser, 1));
                         const float u2 = u01(hash32(seed, (uint32_t)r, (uint32_t)ser, 2));
-                        const float ax = kLen + u0 * (xmax - kLen);
+                        const float ax = xlo + u0 * (xmax - xlo);
                         const float asf = 1.0f + 0.2f * ((u1 + u2) - 1.0f);
-                        const uint32_t am = (uint32_t)r << 16;
+                        int rt = r;                                  // the vehicle's route: the stream itself, ...
+                        if (P.sroute) {
+                            const int md = P.smode[r];
+                            rt = P.sroute[r];                        // ... the stream's fixed route, ...
+                            if (md == 2) rt = P.iroute[(size_t)e * NS + r];      // ... this episode's draw of the host, ...
+                            if (md == 1) {                           // ... or this vehicle's draw from the turn ratios
+                                const int u16 = (int)(hash32(seed, (uint32_t)r, (uint32_t)ser, 3) >> 16);
+                                const int iv = t / P.ilen < P.NI ? t / P.ilen : P.NI - 1;
+                                const int *ch = P.schoice + ((size_t)r * P.NI + iv) * P.KC * 2;
+                                rt = ch[0];
+                                for (int c = 0; c < P.KC; ++c) {
+                                    if (ch[2 * c] < 0) break;
+                                    rt = ch[2 * c];
+                                    if (u16 < ch[2 * c + 1]) break;
+                                }
+                            }
+                        }
+                        const uint32_t am = (uint32_t)rt << 16;
                         const int d = n * NLP + l;
                         X[d] = ax; V[d] = 0.0f; SF[d] = asf; M[d] = am;
                         if constexpr (REC) { R0[d] = (uint32_t)t | ((uint32_t)ser << 16); R1[d] = 0u; tally(ax, 0.0f, am); ++rq_dep; }
@@ -860,7 +891,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         const int hw = (n > 0 && hx >= det && hx > 0.0f) ? (int)(hm & 0xFFFFu) : 0;
         s.wave[l] += d_wave; s.halt[l] += d_halt; s.hwait[l] = hw;       // the flat phase added its vehicles with LDS atomics
     }
-    for (int r = l; r < NR; r += blockDim.x) { P.pending[(size_t)e * NR + r] = s.pend[r]; P.serial[(size_t)e * NR + r] = s.ser[r]; }
+    for (int r = l; r < NS; r += blockDim.x) { P.pending[(size_t)e * NS + r] = s.pend[r]; P.serial[(size_t)e * NS + r] = s.ser[r]; }
     if (arrived) atomicAdd(&P.arrived[e], (unsigned long long)arrived);
     if (l == 0) { P.tsec[e] = t; done[e] = t >= P.episode ? 1 : 0; }
     TSC_STAMP();
@@ -975,6 +1006,7 @@ struct tsc_env {
     int kf;                         // flat-phase vehicles per thread (measurement knob TSC_ENV_KF)
     int spec;                       // 1: the scenario has the large_grid table dimensions -> specialised step_kernel (TSC_ENV_SPEC=0: off)
     uint32_t *d_seeds;
+    std::vector<int> h_mode, h_sroute;      // host copies of the stream tables (tsc_env_set_stream_routes)
 };
 
 namespace tsc {
@@ -1061,20 +1093,34 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     P.clip_wave = sc->clip_wave; P.clip_wait = sc->clip_wait; P.coef_wait = sc->coef_wait;
 
     const int NL = P.NL, NR = P.NR, A = P.A;
+    // insertion streams: none declared -> every route is its own stream
+    const bool streams = sc->n_stream > 0;
+    const int NS = streams ? sc->n_stream : NR, KC = streams ? sc->k_choice : 1;
+    P.NS = NS; P.KC = KC;
+    if (NS > 254) return tsc::fail("tsc_env_create: n_stream %d > 254 unsupported", NS);
+    if (streams && (!sc->stream_entry || !sc->stream_mode || !sc->stream_choice || KC < 1 || sc->n_interval < 1 || sc->choice_interval_sec < 1))
+        return tsc::fail("tsc_env_create: incomplete stream tables");
+    const int NI = streams ? sc->n_interval : 1;
+    P.NI = NI; P.ilen = streams ? sc->choice_interval_sec : 1 << 30;
+    auto stream_entry = [&](int s_) { return streams ? sc->stream_entry[s_] : sc->route_entry[s_]; };
     // Lanes that can ever hold a vehicle: the chains route entry lane -> mv_next[lane][route] -> ...  (the movement
     // table also has rows for the sibling lanes of every edge a route passes, which no vehicle of that route is
     // ever put on).  After load sorting they are a prefix; only they get a thread and LDS rows.
     std::vector<char> reach((size_t)NL, 0);
     {
         int nu = 0;
-        for (int r = 0; r < NR; ++r) {
-            int l = sc->route_entry[r];
-            for (int hops = 0; l >= 0 && l < NL && hops <= NL; ++hops) {
-                reach[l] = 1;
-                if (l + 1 > nu) nu = l + 1;
-                l = sc->mv_next[(size_t)l * NR + r];
+        for (int s_ = 0; s_ < NS; ++s_)
+            for (int c = 0; c < KC * NI; ++c) {
+                const int r = streams ? sc->stream_choice[((size_t)s_ * KC * NI + c) * 2] : s_;
+                if (r < 0) continue;
+                if (r >= NR) return tsc::fail("tsc_env_create: stream %d names route %d of %d", s_, r, NR);
+                int l = stream_entry(s_);
+                for (int hops = 0; l >= 0 && l < NL && hops <= NL; ++hops) {
+                    reach[l] = 1;
+                    if (l + 1 > nu) nu = l + 1;
+                    l = sc->mv_next[(size_t)l * NR + r];
+                }
             }
-        }
         P.NU = nu < 1 ? 1 : nu;
         P.NLA = (P.NU + 63) / 64 * 64;
     }
@@ -1109,22 +1155,58 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
         }
         UP(zip, uint8_t, zp.data(), zp.size());
     }
-    UP(route_entry, int, sc->route_entry, NR);
-    // flows sorted by route (stable) + CSR
-    std::vector<int> fl; std::vector<int> ptr(NR + 1, 0);
-    for (int r = 0; r < NR; ++r) {
+    {
+        std::vector<int> se(NS);
+        for (int s_ = 0; s_ < NS; ++s_) se[s_] = stream_entry(s_);
+        UP(route_entry, int, se.data(), NS);
+    }
+    P.sroute = nullptr; P.smode = nullptr; P.schoice = nullptr; P.sorigin = nullptr; P.iroute = nullptr;
+    if (streams) {
+        std::vector<int> sr(NS);
+        bool any_origin = false, identity = NS == NR;
+        for (int s_ = 0; s_ < NS; ++s_) {
+            const int md = sc->stream_mode[s_];
+            if (md < 0 || md > 2) return tsc::fail("tsc_env_create: stream %d has mode %d", s_, md);
+            sr[s_] = sc->stream_choice[(size_t)s_ * NI * KC * 2];
+            if (sr[s_] < 0) return tsc::fail("tsc_env_create: stream %d has no route", s_);
+            if (md != 0 || sr[s_] != s_) identity = false;
+            if (sc->stream_origin && sc->stream_origin[s_] != 0.0f) any_origin = true;
+            if (sc->stream_limit && sc->stream_limit[s_] < sc->lane_len[stream_entry(s_)]) any_origin = true;
+        }
+        h->h_mode.assign(sc->stream_mode, sc->stream_mode + NS); h->h_sroute = sr;
+        if (!identity) {                              // fixed one-to-one streams keep the round-2 fast path (sroute == null)
+            UP(sroute, int, sr.data(), NS);
+            UP(smode, int, sc->stream_mode, NS);
+            UP(schoice, int, sc->stream_choice, (size_t)NS * NI * KC * 2);
+            ALLOC(iroute, int, (size_t)n_env * NS);
+            std::vector<int> ir((size_t)n_env * NS);
+            for (size_t i = 0; i < ir.size(); ++i) ir[i] = sr[i % NS];
+            TSC_HIP(hipMemcpy(P.iroute, ir.data(), sizeof(int) * ir.size(), hipMemcpyHostToDevice));
+        }
+        if (any_origin) {
+            std::vector<float> so((size_t)NS * 2);
+            for (int s_ = 0; s_ < NS; ++s_) {
+                so[2 * s_] = sc->stream_origin ? sc->stream_origin[s_] : 0.0f;
+                so[2 * s_ + 1] = sc->stream_limit ? sc->stream_limit[s_] : INFINITY;
+            }
+            UP(sorigin, float, so.data(), so.size());
+        }
+    }
+    // flows sorted by stream (stable) + CSR
+    std::vector<int> fl; std::vector<int> ptr(NS + 1, 0);
+    for (int r = 0; r < NS; ++r) {
         ptr[r] = (int)fl.size() / 4;
         for (int f = 0; f < sc->n_flow; ++f)
             if (sc->flows[f * 4 + 3] == r) fl.insert(fl.end(), sc->flows + f * 4, sc->flows + f * 4 + 4);
     }
-    ptr[NR] = (int)fl.size() / 4;
+    ptr[NS] = (int)fl.size() / 4;
     UP(flows, int, fl.data(), fl.size());
-    UP(flow_ptr, int, ptr.data(), NR + 1);
+    UP(flow_ptr, int, ptr.data(), NS + 1);
     {   // per-lane entry routes (<= 2) and per-route emission table (DESIGN.md microsim spec, rule 6)
         std::vector<int> lr((size_t)NL * kMaxEntry, -1);
-        for (int r = 0; r < NR; ++r) {
-            const int l = sc->route_entry[r];
-            if (l < 0 || l >= NL) return tsc::fail("tsc_env_create: route %d has no entry lane", r);
+        for (int r = 0; r < NS; ++r) {
+            const int l = stream_entry(r);
+            if (l < 0 || l >= NL) return tsc::fail("tsc_env_create: stream %d has no entry lane", r);
             int q = 0;
             while (q < kMaxEntry && lr[l * kMaxEntry + q] >= 0) ++q;
             if (q == kMaxEntry) return tsc::fail("tsc_env_create: more than %d routes enter lane %d", kMaxEntry, l);
@@ -1137,10 +1219,11 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
                     lrp[l * 2 + q / 4] = (lrp[l * 2 + q / 4] & ~(0xFFu << (8 * (q % 4)))) | ((uint32_t)lr[l * kMaxEntry + q] << (8 * (q % 4)));
         UP(lane_routes, uint32_t, lrp.data(), lrp.size());
         P.emit_len = sc->episode_length_sec + 64;
-        std::vector<uint8_t> em((size_t)NR * P.emit_len, 0);
+        std::vector<uint8_t> em((size_t)NS * P.emit_len, 0);
         for (int f = 0; f < sc->n_flow; ++f) {
             const long long b = sc->flows[f * 4], en = sc->flows[f * 4 + 1], vph = sc->flows[f * 4 + 2];
             const int r = sc->flows[f * 4 + 3];
+            if (r < 0 || r >= NS) return tsc::fail("tsc_env_create: flow %d names stream %d of %d", f, r, NS);
             for (long long t = b; t < en && t < P.emit_len; ++t) {
                 const long long tau = t - b;
                 const long long c = (((tau + 1) * vph + 3599) / 3600) - ((tau * vph + 3599) / 3600);
@@ -1171,7 +1254,7 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     const size_t slots = (size_t)n_env * kCap * P.NLP;
     ALLOC(X, float, slots); ALLOC(V, float, slots); ALLOC(SF, float, slots); ALLOC(M, uint32_t, slots);
     ALLOC(N, int, (size_t)n_env * P.NLP);
-    ALLOC(pending, int, (size_t)n_env * NR); ALLOC(serial, int, (size_t)n_env * NR);
+    ALLOC(pending, int, (size_t)n_env * NS); ALLOC(serial, int, (size_t)n_env * NS);
     ALLOC(tsec, int, n_env); ALLOC(seed, uint32_t, n_env);
     ALLOC(prev_action, int, (size_t)n_env * A);
     ALLOC(fp, float, (size_t)n_env * A * P.PMAX);
@@ -1202,7 +1285,7 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     h->spec = 0;
     for (int k = 1; k < 3; ++k) {
         const SpecDims &D = kSpec[k];
-        if (P.NLP == D.NLP && P.NLA == D.NLA && P.NU == D.NU && P.NR == D.NR && P.A == D.A && P.KMAX == D.KMAX && P.PMAX == D.PMAX &&
+        if (P.NS == P.NR && P.NLP == D.NLP && P.NLA == D.NLA && P.NU == D.NU && P.NR == D.NR && P.A == D.A && P.KMAX == D.KMAX && P.PMAX == D.PMAX &&
             P.LMAX == D.LMAX && P.NBR == D.NBR && P.ctrl == D.ctrl && P.yellow == D.yellow && P.teleport == D.teleport) h->spec = k;
     }
     if (const char *ev = getenv("TSC_ENV_SPEC")) if (!atoi(ev)) h->spec = 0;
@@ -1317,6 +1400,25 @@ int tsc_env_reset(tsc_env *h, const uint32_t *seeds_host, float *obs_dev) {
     return 0;
 }
 
+int tsc_env_set_stream_routes(tsc_env *h, const int32_t *routes_host) {
+    if (!h || !routes_host) return tsc::fail("tsc_env_set_stream_routes: bad arguments");
+    const EnvDev &P = h->P;
+    if (!P.iroute) return tsc::fail("tsc_env_set_stream_routes: the scenario has no per-episode stream routes");
+    std::vector<int> ir((size_t)P.E * P.NS);
+    for (int e = 0; e < P.E; ++e)
+        for (int s_ = 0; s_ < P.NS; ++s_) {
+            int r = h->h_sroute[s_];
+            if (h->h_mode[s_] == 2) {
+                r = routes_host[(size_t)e * P.NS + s_];
+                if (r < 0 || r >= P.NR) return tsc::fail("tsc_env_set_stream_routes: instance %d stream %d: route %d of %d", e, s_, r, P.NR);
+            }
+            ir[(size_t)e * P.NS + s_] = r;
+        }
+    TSC_HIP(hipMemcpyAsync(P.iroute, ir.data(), sizeof(int) * ir.size(), hipMemcpyHostToDevice, h->stream));
+    TSC_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 int tsc_env_bind_fingerprint(tsc_env *h, const float *pi_dev) {
     if (!h) return tsc::fail("null handle");
     h->P.fp_bound = pi_dev;                      // null: back to the copied fingerprints
@@ -1402,8 +1504,8 @@ int tsc_env_get_state(tsc_env *h, int32_t e, int32_t *n, float *x, float *v, flo
             w[d] = live ? (int)(hm[s] & 0xFFFFu) : 0; r[d] = live ? (int)(hm[s] >> 16) : 0;
         }
     }
-    if (pending) TSC_HIP(hipMemcpy(pending, P.pending + (size_t)e * P.NR, P.NR * 4, hipMemcpyDeviceToHost));
-    if (serial) TSC_HIP(hipMemcpy(serial, P.serial + (size_t)e * P.NR, P.NR * 4, hipMemcpyDeviceToHost));
+    if (pending) TSC_HIP(hipMemcpy(pending, P.pending + (size_t)e * P.NS, P.NS * 4, hipMemcpyDeviceToHost));
+    if (serial) TSC_HIP(hipMemcpy(serial, P.serial + (size_t)e * P.NS, P.NS * 4, hipMemcpyDeviceToHost));
     if (time_sec) TSC_HIP(hipMemcpy(time_sec, P.tsec + e, 4, hipMemcpyDeviceToHost));
     return 0;
 }

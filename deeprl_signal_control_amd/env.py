@@ -45,6 +45,7 @@ class VecTrafficEnv:
         self.seed_stride = self.E if seed_stride is None else seed_stride
         self.cur_episode = 0
         self.cur_sec = 0
+        self._draws_routes = scn.stream_mode is not None and bool((np.asarray(scn.stream_mode) == 2).any())
         L = _lib.lib()
         self._L = L
         sc, self._keep = _lib.scenario_struct(scn)
@@ -173,6 +174,10 @@ class VecTrafficEnv:
             seeds = np.asarray(self.test_seeds, np.int64)[ti]
             self.seeds += self.seed_stride                      # the reference bumps it in test mode too
         s32 = (seeds & 0xFFFFFFFF).astype(np.uint32)
+        if self._draws_routes:           # what gen_rou_file(seed) draws per episode (large_grid init_density > 0: the sinks)
+            from .scenario import draw_stream_routes
+            routes = np.ascontiguousarray(np.stack([draw_stream_routes(self.scn, int(sd)) for sd in seeds]), np.int32)
+            _lib.check(self._L.tsc_env_set_stream_routes(self._h, routes.ctypes.data_as(C.POINTER(C.c_int32))))
         _lib.check(self._L.tsc_env_reset(self._h, s32.ctypes.data_as(C.POINTER(C.c_uint32)),
                                          C.c_void_p(self.obs.data_ptr())))
         self.cur_sec = 0

@@ -101,9 +101,41 @@ class Scenario:
     lane_origin: np.ndarray = None   # f32 [NL] where the SUMO lane of that name begins inside the compiled lane (0 unless
                                      # contract_chains merged upstream pieces into it): `lane.*` TraCI getters count from here
 
+    # insertion streams (include/tsc.h tsc_scenario): None = every route is its own stream (flows[:, 3] = route)
+    stream_entry_lane: np.ndarray = None    # i32 [NS]
+    stream_origin: np.ndarray = None        # f32 [NS] start of the insertion window on the entry lane
+    stream_limit: np.ndarray = None         # f32 [NS] its end (the SUMO entry lane may be one piece of a contracted chain)
+    stream_mode: np.ndarray = None          # i32 [NS] 0 fixed route, 1 per-vehicle draw (turn ratios), 2 per-episode route from the host
+    stream_choice: np.ndarray = None        # i32 [NS, NI, KC, 2] (route, cumulative weight of 65536) per choice interval, route -1 pads
+    choice_interval_sec: int = 1 << 30      # length of a choice interval (time-variant turn ratios); NI = stream_choice.shape[1]
+
     def __post_init__(self):
         if self.lane_origin is None:
             self.lane_origin = np.zeros(len(self.lane_names), np.float32)
+
+    @property
+    def n_stream(self) -> int:
+        return self.n_route if self.stream_entry_lane is None else len(self.stream_entry_lane)
+
+    def streams_ready(self):
+        """Fill the optional stream tables (whole-lane insertion window) once streams are declared."""
+        if self.stream_entry_lane is not None:
+            NS = len(self.stream_entry_lane)
+            if self.stream_origin is None:
+                self.stream_origin = np.zeros(NS, np.float32)
+            if self.stream_limit is None:
+                self.stream_limit = np.asarray(self.lane_len, np.float32)[np.asarray(self.stream_entry_lane)]
+            if self.stream_mode is None:
+                self.stream_mode = np.zeros(NS, np.int32)
+            assert self.stream_choice.ndim == 4 and self.stream_choice.shape[0] == NS and self.stream_choice.shape[3] == 2
+        return self
+
+    def entry_lanes(self):
+        """(entry lane, route) of every way a vehicle can enter: what decides which lanes can ever be occupied."""
+        if self.stream_entry_lane is None:
+            return [(int(l), r) for r, l in enumerate(self.route_entry_lane)]
+        return [(int(self.stream_entry_lane[s]), int(r)) for s in range(self.n_stream)
+                for r in sorted({int(x) for x in self.stream_choice[s, :, :, 0].ravel() if x >= 0})]
 
     @property
     def n_lane(self) -> int:
@@ -268,11 +300,8 @@ _RIGHT, _THROUGH, _LEFT = 0, 1, 2
 
 def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: int = 925,
                      sort_lanes: bool = True, init_density: float = 0.0, **env_kw) -> Scenario:
-    if init_density > 0:
-        # large_grid/data/build_file.py:223-266 seeds every internal edge with vehicles bound for a sink drawn per
-        # episode from np.random: up to 120 x 20 (source lane, sink) routes.  No reference config sets it
-        # (config/*.ini: init_density = 0), and the route tables here are per-OD (n_route <= 255).
-        raise NotImplementedError('init_density > 0 (initial traffic, build_file.py:223-266) is not supported')
+    # init_density > 0: large_grid/data/build_file.py:223-266 seeds every internal edge (and both lanes of a street) with
+    # int(30 * density) vehicles bound for a sink edge drawn per episode from np.random -- see the stream tables below
     L0, L0_END, N = 200.0, 75.0, 5
     pos: Dict[str, Tuple[float, float]] = {}
     for r in range(N):
@@ -335,6 +364,17 @@ def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: in
     for e1, e2, *_ in demand:
         if (e1, e2) not in route_names:
             route_names.append((e1, e2))
+    n_od = len(route_names)
+    init_sinks: List[str] = []
+    if init_density > 0:
+        # routes are destination trees (Bellman-Ford below): one more per sink edge no OD flow ends at.  Sink order =
+        # init_routes' sink_edges (build_file.py:227-236), which np.random.choice indexes
+        in_nodes = [5, 10, 15, 20, 25, 21, 16, 11, 6, 1, 1, 2, 3, 4, 5, 25, 24, 23, 22, 21]
+        out_nodes = [6, 7, 8, 9, 10, 16, 17, 18, 19, 20, 1, 2, 3, 4, 5, 11, 12, 13, 14, 15]
+        init_sinks = ['nt%d_np%d' % (i, j) for i, j in zip(in_nodes, out_nodes)]
+        for e in init_sinks:
+            if all(dst != e for _, dst in route_names):
+                route_names.append((None, e))
     NR = len(route_names)
     tcost = {e: Fraction(int(v[4] * 1000), int(v[3] * 1000)) for e, v in edges.items()}
     next_mv: Dict[Tuple[str, int], int] = {}
@@ -426,17 +466,25 @@ def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: in
             if e == dst:
                 mv_next[l, r] = -1
                 continue
+            if init_density > 0 and to.startswith('np'):
+                mv_next[l, r] = -1                      # initial traffic: whoever ends up on an exit edge leaves there
+                continue
             m = next_mv.get((e, r))
             if m is None or not to.startswith('nt'):
                 continue
             if nl == 2 and ((m == _LEFT) != (lane_k[l] == 1)):
-                continue                                # lane does not serve that movement
+                if init_density <= 0:
+                    continue                            # lane does not serve that movement
+                # initial traffic stands on both lanes of a street whatever its sink (departLane, build_file.py:225);
+                # SUMO would change lanes, here the vehicle takes a movement its lane serves -- the left turn from lane 1,
+                # through (else right) from lane 0 -- and follows the sink's tree from the next edge on
+                m = _LEFT if lane_k[l] == 1 else _THROUGH
             a = approach_of(e)
             e2 = out_edge(to, a, m)
             k2 = lane_choice(e2, r, m, nl == 2)
             mv_next[l, r] = lane_id['%s_%d' % (e2, k2)]
             mv_link[l, r] = 3 * _APPROACH.index(a) + m
-    route_entry = np.array([lane_id['%s_%d' % (src, lane_choice(src, r, None, False))]
+    route_entry = np.array([lane_id['%s_%d' % (src, lane_choice(src, r, None, False))] if src is not None else -1
                             for r, (src, _) in enumerate(route_names)], np.int32)
 
     lane_up = np.full((NL, MAX_UP), -1, np.int32)
@@ -475,6 +523,37 @@ def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: in
 
     rid = {rn: i for i, rn in enumerate(route_names)}
     flows = np.array([[tb, te, vph, rid[(e1, e2)]] for e1, e2, tb, te, vph in demand], np.int32)
+    stream_kw = {}
+    if init_density > 0:
+        # streams: the n_od flows of the demand table, then init_routes' 120 flows in its own order (build_file.py:243-266:
+        # streets nt(i+j) <-> nt(i+j+1), both directions x both lanes; avenues nt(i+j) <-> nt(i+j+5)), each
+        # `number = int(MAX_CAR_NUM * density)` vehicles at t = 0, sink = np.random.choice(sink_edges) per episode
+        car_num = int(30 * init_density)
+        dst_route = {dst: r for r, (_, dst) in enumerate(route_names)}
+        sink_routes = [dst_route[e] for e in init_sinks]
+        init_lanes = []
+        for i in range(1, 25, 5):
+            for j in range(4):
+                n1, n2 = 'nt%d' % (i + j), 'nt%d' % (i + j + 1)
+                init_lanes += ['%s_%s_0' % (n1, n2), '%s_%s_0' % (n2, n1), '%s_%s_1' % (n1, n2), '%s_%s_1' % (n2, n1)]
+        for i in range(1, 6):
+            for j in range(0, 20, 5):
+                n1, n2 = 'nt%d' % (i + j), 'nt%d' % (i + j + 5)
+                init_lanes += ['%s_%s_0' % (n1, n2), '%s_%s_0' % (n2, n1)]
+        NS = n_od + len(init_lanes)
+        KC = len(sink_routes)
+        choice = np.full((NS, 1, KC, 2), -1, np.int32)
+        choice[..., 1] = 0
+        for r in range(n_od):
+            choice[r, 0, 0] = (r, 65536)
+        for k in range(len(init_lanes)):
+            for c, r in enumerate(sink_routes):
+                choice[n_od + k, 0, c] = (r, 65536 * (c + 1) // KC)
+        stream_kw = dict(stream_entry_lane=np.array(list(route_entry[:n_od]) + [lane_id[nm] for nm in init_lanes], np.int32),
+                         stream_mode=np.array([0] * n_od + [2] * len(init_lanes), np.int32), stream_choice=choice)
+        if car_num > 0:
+            flows = np.concatenate([flows, np.array([[0, 1, 3600 * car_num, n_od + k] for k in range(len(init_lanes))], np.int32)])
+        route_entry = np.where(route_entry >= 0, route_entry, 0).astype(np.int32)
 
     scn = Scenario(
         name='large_grid', agent=agent, node_names=node_names, n_agent=N * N,
@@ -490,8 +569,26 @@ def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: in
         neighbors=neighbors, n_s_ls=n_s, n_w_ls=n_w, n_f_ls=n_f, n_a_ls=n_a_ls,
         obs_kind=obs_kind, obs_src=obs_src, flows=flows, obs_len=lens,
         extra={'peak_flow1': peak_flow1, 'peak_flow2': peak_flow2, 'demand': demand},
-        **env_kw)
+        **stream_kw, **env_kw)
+    if init_density > 0:
+        scn.extra.update(init_density=init_density, init_lanes=init_lanes, init_sinks=init_sinks, sink_routes=sink_routes,
+                         n_od=n_od, car_num=car_num)
     return sort_lanes_by_load(scn) if sort_lanes else scn
+
+
+def draw_stream_routes(scn: Scenario, seed: int):
+    """This episode's routes of the streams whose route the reference's generator draws (mode 2): int32 [NS] or None.
+    large_grid with init_density > 0: gen_rou_file(seed) does np.random.seed(seed) and then one
+    np.random.choice(sink_edges) per initial flow, in flow order (large_grid/data/build_file.py:237-240,275-281);
+    RandomState(seed).choice(20) is that stream (pinned against the generator's file by tests/test_init_density.py)."""
+    if scn.stream_mode is None or not (np.asarray(scn.stream_mode) == 2).any():
+        return None
+    rs = np.random.RandomState(int(seed) & 0xFFFFFFFF)
+    routes = scn.stream_choice[:, 0, 0, 0].astype(np.int32).copy()
+    sink_routes = scn.extra['sink_routes']
+    for s_ in np.nonzero(np.asarray(scn.stream_mode) == 2)[0]:
+        routes[s_] = sink_routes[int(rs.choice(len(sink_routes)))]
+    return routes
 
 
 
@@ -711,6 +808,7 @@ def contract_chains(scn: Scenario) -> Scenario:
             if v[idx] >= 0:
                 out[idx] = new_id[resolve(int(v[idx]))[-1]]
         return out
+    old_len = scn.lane_len.copy()
     lane_len = np.array([np.float32(offset[l]) + scn.lane_len[l] for l in keep], np.float32)
     det = np.array([np.float32(offset[l]) + scn.lane_det_start[l] for l in keep], np.float32)
     lane_up = np.full((len(keep), MAX_UP), -1, np.int32)
@@ -737,7 +835,20 @@ def contract_chains(scn: Scenario) -> Scenario:
                 if len(fs) > 1:
                     zp[i, r] = fs.index(i) | (len(fs) << 8)
     scn.mv_zip = zp
+    # a route whose SUMO entry lane became an inner piece of a chain is still inserted on that piece: the insertion window
+    # of its stream starts where the piece does (include/tsc.h stream_origin)
+    entry_off, entry_end = np.zeros(NR, np.float32), np.zeros(NR, np.float32)
+    for r in range(NR):
+        x = int(scn.route_entry_lane[r])
+        full = resolve(first_of[resolve(x)[-1]])
+        entry_off[r] = np.float32(sum(np.float32(scn.lane_len[c]) for c in full[:full.index(x)]))
+        entry_end[r] = entry_off[r] + np.float32(old_len[x])
     scn.route_entry_lane = remap_lane(scn.route_entry_lane).astype(np.int32)
+    if entry_off.any() or (entry_end < scn.lane_len[scn.route_entry_lane]).any():
+        scn.stream_entry_lane = scn.route_entry_lane.copy()
+        scn.stream_origin, scn.stream_limit = entry_off, entry_end
+        scn.stream_mode = np.zeros(NR, np.int32)
+        scn.stream_choice = np.stack([np.arange(NR), np.full(NR, 65536)], 1).reshape(NR, 1, 1, 2).astype(np.int32)
     scn.agent_lanes = remap_lane(scn.agent_lanes).astype(np.int32)
     scn.link_lane = remap_lane(scn.link_lane).astype(np.int32)
     src = scn.obs_src.copy()
@@ -756,8 +867,12 @@ SMALL_GRID_STATE_PHASE_MAP = {'nt1': [0, 1, 2], 'nt2': [1, 0], 'nt3': [1, 0], 'n
 SMALL_GRID_PHASES = {2: ['GGrr', 'rrGG'], 3: ['GGGrrrrrr', 'rrrGGGrrr', 'rrrrrrGGG']}                                      # :35-36
 
 
-def small_grid_demand(num_car_hourly: int, episode_length_sec: int = 3600):
+def small_grid_demand(num_car_hourly: int, episode_length_sec: int = 3600, distributions: bool = False):
     """The demand of small_grid/data/build_file.py as (edge path, begin, end, vph) elements.
+
+    distributions=True returns instead (source flows, mf flows): the source flows as (source edge, interval, begin, end, vph,
+    [(edge path, probability)]) -- what SUMO's jtrrouter samples every vehicle's turns from (build_small_grid draws them per
+    vehicle, `random_turns`) -- and the explicit-route flows as (edge path, begin, end, vph).
 
     The reference writes source flows (`from=` only, vehsPerHour per 600 s, :191-210) and lets SUMO's `jtrrouter` draw every
     vehicle's turns from the ratios of output_turns (:223-307) with a per-episode seed; `jtrrouter` is not in this
@@ -795,7 +910,7 @@ def small_grid_demand(num_car_hourly: int, episode_length_sec: int = 3600):
         for e2, p in t.items():
             out += [([edge] + q, p * pq) for q, pq in paths(e2, i0)]
         return out
-    elements = []
+    elements, src_elems = [], []
     for i0 in range(12):
         tb, te = 600 * i0, 600 * (i0 + 1)
         if tb >= episode_length_sec:
@@ -803,6 +918,7 @@ def small_grid_demand(num_car_hourly: int, episode_length_sec: int = 3600):
         for j, src in enumerate(srcs):
             vph = int(src_flows[j][i0] * 1.0)                # FLOW_MULTIPLIER = 1.0, "%i"
             pp = paths(src, i0)
+            src_elems.append((src, i0, tb, te, vph, [(tuple(path), float(pr)) for path, pr in pp]))
             raw = [vph * p for _, p in pp]
             alloc = [int(np.floor(x)) for x in raw]
             for k in sorted(range(len(pp)), key=lambda k: (-(raw[k] - alloc[k]), k))[:vph - sum(alloc)]:
@@ -813,15 +929,19 @@ def small_grid_demand(num_car_hourly: int, episode_length_sec: int = 3600):
                  'nt4_nt3 nt3_np6', 'nt4_nt3 nt3_nt2 nt2_np5']
     cases = [(3, 4, 5), (0, 3, 4), (1, 2, 5), (4, 5, 9), (5, 6, 9), (4, 7, 8)]
     mf_vph = int(round(3600 * float('%.2f' % (num_car_hourly / float(3600)))))
+    mf_elems = []
     for i, cs in enumerate(cases):
         tb, te = 1200 * i, 1200 * (i + 1)
         if tb >= episode_length_sec or mf_vph <= 0:
             continue
-        elements += [(tuple(mf_routes[c].split()), tb, te, mf_vph) for c in cs]
-    return elements
+        mf_elems += [(tuple(mf_routes[c].split()), tb, te, mf_vph) for c in cs]
+    if distributions:
+        return src_elems, mf_elems
+    return elements + mf_elems
 
 
-def build_small_grid(agent: str = 'greedy', num_extra_car_per_hour: int = 1000, sort_lanes: bool = True, **env_kw) -> Scenario:
+def build_small_grid(agent: str = 'greedy', num_extra_car_per_hour: int = 1000, sort_lanes: bool = True,
+                     random_turns: bool = True, **env_kw) -> Scenario:
     """The 6-intersection benchmark (envs/small_grid_env.py, small_grid/data/build_file.py): 1-lane 20 m/s roads, nt1 with
     three 1-approach phases, the others with two, lane-area detectors on the last 50 m of every incoming lane, the
     unsignalised split node npc.  SUMO orders a node's signal links by incoming edge clockwise from north; the
@@ -926,6 +1046,44 @@ def build_small_grid(agent: str = 'greedy', num_extra_car_per_hour: int = 1000, 
     green, yellow = _signal_tables(phases, kmax)
     rid = {p: i for i, p in enumerate(route_paths)}
     flows = np.array([[tb, te, vph, rid[path]] for path, tb, te, vph in demand], np.int32)
+    stream_kw = {}
+    if random_turns:
+        # every vehicle of a source flow draws its path from the turn ratios, like SUMO's jtrrouter does per episode seed
+        # (small_grid/data/build_file.py:223-335): one stream per source edge, one choice table per 600-s interval (the
+        # ratios at npc vary with time, :283-293); the explicit-route "mf_" flows are one fixed-route stream per path
+        src_elems, mf_elems = small_grid_demand(num_extra_car_per_hour, env_kw.get('episode_length_sec', 3600), distributions=True)
+        srcs = []
+        for src, *_ in src_elems:
+            if src not in srcs:
+                srcs.append(src)
+        mf_paths = []
+        for path, *_ in mf_elems:
+            if path not in mf_paths:
+                mf_paths.append(path)
+        NI = max(i0 for _, i0, *_ in src_elems) + 1
+        KC = max(len(pp) for *_, pp in src_elems)
+        NS = len(srcs) + len(mf_paths)
+        choice = np.full((NS, NI, KC, 2), -1, np.int32)
+        choice[..., 1] = 0
+        fl = []
+        for src, i0, tb, te, vph, pp in src_elems:
+            s_ = srcs.index(src)
+            cum = np.cumsum([pr for _, pr in pp])
+            for k, (path, _) in enumerate(pp):
+                choice[s_, i0, k] = (rid[path], 65536 if k == len(pp) - 1 else int(round(65536 * cum[k] / cum[-1])))
+            fl.append([tb, te, vph, s_])
+        for i0 in range(NI):                      # intervals without a flow element keep the first table (never used)
+            for s_ in range(len(srcs)):
+                if choice[s_, i0, 0, 0] < 0:
+                    choice[s_, i0] = choice[s_, 0]
+        for path, tb, te, vph in mf_elems:
+            s_ = len(srcs) + mf_paths.index(path)
+            choice[s_, :, 0] = (rid[path], 65536)
+            fl.append([tb, te, vph, s_])
+        flows = np.array(fl, np.int32)
+        stream_kw = dict(stream_entry_lane=np.array([piece_first[e] for e in srcs] + [piece_first[p[0]] for p in mf_paths], np.int32),
+                         stream_mode=np.array([1] * len(srcs) + [0] * len(mf_paths), np.int32), stream_choice=choice,
+                         choice_interval_sec=600)
     lane_det = np.where(lane_node >= 0, lane_len - DET_LEN, 0).astype(np.float32)
     scn = Scenario(
         name='small_grid', agent=agent, node_names=node_names, n_agent=A,
@@ -940,7 +1098,7 @@ def build_small_grid(agent: str = 'greedy', num_extra_car_per_hour: int = 1000, 
         neighbors=neighbors, n_s_ls=n_s, n_w_ls=n_w, n_f_ls=n_f, n_a_ls=n_a_ls,
         obs_kind=obs_kind, obs_src=obs_src, flows=flows, obs_len=lens,
         extra={'num_extra_car_per_hour': num_extra_car_per_hour, 'routes': route_paths, 'demand': demand,
-               'state_phase_map': SMALL_GRID_STATE_PHASE_MAP}, **env_kw)
+               'state_phase_map': SMALL_GRID_STATE_PHASE_MAP}, **stream_kw, **env_kw)
     return sort_lanes_by_load(scn) if sort_lanes else scn
 
 
@@ -948,12 +1106,26 @@ def build_small_grid(agent: str = 'greedy', num_extra_car_per_hour: int = 1000, 
 def lane_load(scn: Scenario) -> np.ndarray:
     """Vehicles per episode routed over every lane (static proxy for queue length)."""
     load = np.zeros(scn.n_lane)
-    for tb, te, vph, r in scn.flows:
+    for tb, te, vph, s_ in scn.flows:
         veh = (te - tb) * vph / 3600.0
-        l = int(scn.route_entry_lane[r])
-        while l >= 0:
-            load[l] += veh
-            l = int(scn.mv_next[l, r])
+        if scn.stream_entry_lane is None:
+            ways = [(int(scn.route_entry_lane[s_]), int(s_), 1.0)]
+        else:                                   # a stream's vehicles spread over its routes (cumulative weights of 65536)
+            NI = scn.stream_choice.shape[1]
+            ways = []
+            for i in range(NI):
+                prev = 0
+                for r, c in scn.stream_choice[s_, i]:
+                    if r < 0:
+                        break
+                    ways.append((int(scn.stream_entry_lane[s_]), int(r), max(int(c) - prev, 1) / 65536.0 / NI))
+                    prev = int(c)
+        for l, r, w in ways:
+            hops = 0
+            while l >= 0 and hops <= scn.n_lane:
+                load[l] += veh * w
+                l = int(scn.mv_next[l, r])
+                hops += 1
     return load
 
 
@@ -986,6 +1158,8 @@ def permute_lanes(scn: Scenario, order) -> Scenario:
     scn.mv_prio = scn.mv_prio[order]
     scn.mv_zip = scn.mv_zip[order]
     scn.route_entry_lane = remap(scn.route_entry_lane)
+    if scn.stream_entry_lane is not None:
+        scn.stream_entry_lane = remap(scn.stream_entry_lane)
     scn.agent_lanes = remap(scn.agent_lanes)
     scn.link_lane = remap(scn.link_lane)
     src = scn.obs_src.copy()

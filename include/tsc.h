@@ -70,6 +70,23 @@ typedef struct tsc_scenario {
     double coop_gamma, norm_wave, norm_wait, clip_wave, clip_wait, coef_wait;
     const float *lane_origin;  /* [n_lane] or NULL: where the SUMO lane begins inside a contracted lane chain (scenario.py
                                 * contract_chains); the lane.* getters of the recording path count from here */
+    /* Insertion streams (round 3).  A stream is one <flow> source: an entry lane, its flow elements (flows[.][3] is then
+     * a STREAM index) and the route its vehicles take.  n_stream == 0: every route is its own stream (route_entry[] is the
+     * entry lane, the layout of rounds 1-2).  Otherwise, per stream: stream_entry[s] = entry lane; stream_origin[s] = start
+     * of the insertion window on it (metres; the SUMO entry lane may be an inner piece of a contracted chain);
+     * stream_mode[s]: 0 = fixed route stream_choice[s][0][0];  1 = every vehicle draws its route from stream_choice[s]
+     * ({route, cumulative weight of 65536} pairs, k_choice per stream and interval, route -1 pads) with the counter-based hash of
+     * (seed, stream, serial) -- SUMO's jtrrouter turn ratios (small_grid/data/build_file.py:223-335);  2 = the route is
+     * given per env instance and episode by tsc_env_set_stream_routes() -- the sinks large_grid's init_routes() draws
+     * from np.random (large_grid/data/build_file.py:223-266); stream_choice[s] then lists the routes it may take. */
+    int32_t n_stream, k_choice;
+    const int32_t *stream_entry;   /* [n_stream] */
+    const float   *stream_origin;  /* [n_stream] or NULL */
+    const float   *stream_limit;   /* [n_stream] or NULL */
+    const int32_t *stream_mode;    /* [n_stream] */
+    const int32_t *stream_choice;  /* [n_stream, n_interval, k_choice, 2]; the choices in force at second t: interval
+                                    * min(t / choice_interval_sec, n_interval - 1) (time-variant turn ratios) */
+    int32_t n_interval, choice_interval_sec;
 } tsc_scenario;
 
 typedef struct tsc_env tsc_env;
@@ -97,6 +114,11 @@ int tsc_env_set_stream(tsc_env *h, void *hip_stream);
 /* reset(), envs/env.py:544-561.  seeds: host [E] (the caller does the reference's
  * `seed += 1` bookkeeping); obs: dev float32 [E, A, SMAX] = float32(state) at t = 0. */
 int tsc_env_reset(tsc_env *h, const uint32_t *seeds_host, float *obs_dev);
+
+/* Routes of the mode-2 streams for the NEXT reset(): host int32 [E, n_stream] (entries of other streams are ignored) --
+ * what gen_rou_file(seed) would write for every instance's episode seed (the caller draws them; env.py does it with
+ * numpy's RandomState(seed), the generator the reference's np.random.seed(seed) + np.random.choice uses). */
+int tsc_env_set_stream_routes(tsc_env *h, const int32_t *routes_host);
 
 /* update_fingerprint(policy), envs/env.py:633-635.  pi: dev float32 [E, A, AMAX];
  * entries k >= n_a - 1 are ignored. */

@@ -173,7 +173,8 @@ class OracleEnv:
     def reset(self, test_ind=0):                           # env.py:544-561
         self.prev_action = [0] * self.n_agent              # env.py:448
         seed = self.seed if self.train_mode else self.test_seeds[test_ind]
-        self.ms.reset(seed)
+        from deeprl_signal_control_amd.scenario import draw_stream_routes
+        self.ms.reset(seed, draw_stream_routes(self.scn, seed))
         self.cur_sec = 0
         self.cur_episode += 1
         if self.agent == 'ma2c':

@@ -139,7 +139,8 @@ class Connection:
         self.tripinfo = tripinfo
         if tripinfo:
             self.ms.record()
-        self.ms.reset(seed)
+        from deeprl_signal_control_amd.scenario import draw_stream_routes
+        self.ms.reset(seed, draw_stream_routes(self.scn, seed))
         self.tl_ids = list(scn.node_names)
         self.aidx = {n: i for i, n in enumerate(scn.node_names)}
         self.lidx = {n: i for i, n in enumerate(scn.lane_names)}

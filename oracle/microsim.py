@@ -41,6 +41,8 @@ def lib():
         L.ms_record.argtypes = [C.c_void_p, C.c_int]
         L.ms_trips.argtypes = [C.c_void_p, ip, C.c_int]
         L.ms_network_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+        L.ms_set_streams.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, ip, fp, fp, ip, ip]
+        L.ms_set_stream_routes.argtypes = [C.c_void_p, ip]
         _LIB = L
     return _LIB
 
@@ -70,13 +72,24 @@ class MicroSim:
         self.h = L.ms_create(scn.n_lane, scn.n_route, scn.n_agent, self.kmax, self.cap,
                              len(scn.flows), scn.teleport_sec, *ptrs)
         self.L = L
+        scn.streams_ready()
+        if scn.stream_entry_lane is not None:
+            st = [_i(scn.stream_entry_lane), _f(scn.stream_origin), _f(scn.stream_limit), _i(scn.stream_mode), _i(scn.stream_choice)]
+            self._keep += st
+            L.ms_set_streams(self.h, scn.n_stream, int(scn.stream_choice.shape[1]), int(min(scn.choice_interval_sec, 1 << 30)),
+                             int(scn.stream_choice.shape[2]), st[0].ctypes.data_as(ip), st[1].ctypes.data_as(fp),
+                             st[2].ctypes.data_as(fp), st[3].ctypes.data_as(ip), st[4].ctypes.data_as(ip))
 
     def __del__(self):
         if getattr(self, 'h', None):
             self.L.ms_destroy(self.h)
             self.h = None
 
-    def reset(self, seed):
+    def reset(self, seed, stream_routes=None):
+        """stream_routes: this episode's routes of the mode-2 streams (scenario.draw_stream_routes), int32 [NS]."""
+        if stream_routes is not None:
+            r = _i(stream_routes)
+            self.L.ms_set_stream_routes(self.h, r.ctypes.data_as(C.POINTER(C.c_int32)))
         self.L.ms_reset(self.h, int(seed) & 0xFFFFFFFF)
 
     def set_links(self, agent, chars):

@@ -77,9 +77,9 @@ def test_env_section_builds_the_scenario():
     cfg = _config()
     cfg['ENV_CONFIG']['peak_flow1'] = '2200'
     assert np.asarray(scenario_from_config(cfg['ENV_CONFIG'])[0].flows)[:, 2].sum() > base
-    cfg['ENV_CONFIG']['init_density'] = '0.3'              # initial traffic is not modelled: refused, not ignored
-    with pytest.raises(Exception):
-        scenario_from_config(cfg['ENV_CONFIG'])
+    cfg['ENV_CONFIG']['init_density'] = '0.3'              # initial traffic (large_grid/data/build_file.py:223-266): 120 more streams
+    scn_d = scenario_from_config(cfg['ENV_CONFIG'])[0]
+    assert scn_d.n_stream == 12 + 120 and scn_d.extra['car_num'] == 9 and scn_d.n_route == 20
 
 
 def test_model_section_is_typed_like_the_reference_getters():

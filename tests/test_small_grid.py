@@ -34,7 +34,11 @@ def test_static_tables_and_demand(golden_dir):
             assert sum(vph for path, tb, te, vph in dem if path[0] == s and tb == 600 * i) == v
     mf = [d for d in dem if not d[0][0].startswith('np')]
     assert len(mf) == 9 and all(v == 1008 and te - tb == 1200 for _, tb, te, v in mf)       # probability "0.28" per second
-    assert len(dem) == len(scn.flows) and scn.n_route == 32
+    assert scn.n_route == 32
+    # the env draws every vehicle's turns (random_turns, the default): one flow element per source flow of the reference
+    # file; the expectation routing of round 2 (random_turns=False) has one element per (source flow, path)
+    assert len(scn.flows) == 5 * 6 + 9 and scn.n_stream == 5 + 6
+    assert len(build_small_grid('greedy', random_turns=False, **KW).flows) == len(dem)
     # MARL agents: 'npc' is not a signal node (the reference crashes on it) -> dropped
     ia = build_small_grid('ia2c')
     assert ia.neighbors == [[1, 5], [0, 2], [1, 3], [2, 4], [3, 5], [0, 4]] and ia.n_s_ls == [10, 9, 8, 8, 8, 9] and ia.n_f_ls == [0] * 6

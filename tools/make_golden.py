@@ -218,6 +218,31 @@ def objective_fixtures():
     np.savez_compressed(os.path.join(OUT, 'large_grid_iqll.npz'), **g)
 
 
+def init_density_fixtures():
+    """init_density > 0 (large_grid/data/build_file.py:223-266, config key of envs/large_grid_env.py:67): (a) the initial flows
+    the reference generator writes for several episode seeds -- source edge, sink edge drawn from np.random, departLane, number
+    -- and (b) the reference LargeGridEnv with init_density = 0.2, two short episodes (the second re-draws the sinks under
+    seed + 1)."""
+    from deeprl_signal_control_amd.scenario import build_scenario
+    cfg = fake_traci.ref_config('large_grid', 'ma2c')
+    cfg['ENV_CONFIG']['init_density'] = '0.2'
+    scn = build_scenario('large_grid', 'ma2c', init_density=0.2)
+    env = fake_traci.ref_env('large_grid', 'ma2c', scn=scn, config=cfg)
+    from large_grid.data.build_file import gen_rou_file
+    flows = {}
+    for seed in (12, 13, 10000, 20000):
+        gen_rou_file(env.data_path, 1100, 925, 0.2, seed=seed, thread=7)
+        rou = open(os.path.join(env.data_path, 'exp_7.rou.xml')).read()
+        flows[str(seed)] = [[m.group(1), m.group(2), m.group(3), int(m.group(4)), int(m.group(5))]
+                            for m in re.finditer(r'<flow id="i_(\d+)" departPos="random_free" from="(\S+)" to="(\S+)" begin="0" end="1" '
+                                                 r'departLane="(\d+)" departSpeed="0" number="(\d+)"', rou)]
+        assert len(flows[str(seed)]) == 120
+    with open(os.path.join(OUT, 'large_grid_init_flows.json'), 'w') as f:
+        json.dump(flows, f)
+    g = rollout(env, 40, np.random.RandomState(31), 0.5, True, resets=2)
+    np.savez_compressed(os.path.join(OUT, 'large_grid_ma2c_initd.npz'), **g)
+
+
 def learner_fixtures():
     """Known answers from agents/utils.py (OnPolicyBuffer :182-228, Scheduler :268-281)."""
     fake_traci.install(__import__('deeprl_signal_control_amd.scenario', fromlist=['x']).build_large_grid())
@@ -375,7 +400,7 @@ if __name__ == '__main__':
     only = set(sys.argv[1:])                 # e.g. `python tools/make_golden.py real_net greedy`
     for name, fn in (('env', env_fixtures), ('real_net', real_net_fixtures), ('greedy', greedy_fixtures),
                      ('iql', iql_fixtures), ('learner', learner_fixtures), ('eval', eval_fixtures),
-                     ('small_grid', small_grid_fixtures), ('objective', objective_fixtures), ('refnet', refnet_fixtures)):
+                     ('small_grid', small_grid_fixtures), ('objective', objective_fixtures), ('init_density', init_density_fixtures), ('refnet', refnet_fixtures)):
         if not only or name in only:
             fn()
     for f in sorted(os.listdir(OUT)):
