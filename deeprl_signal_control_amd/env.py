@@ -218,7 +218,7 @@ class VecTrafficEnv:
 
     # -- debug / parity ---------------------------------------------------------------------
     def get_state(self, e=0):
-        NL, NR = self.scn.n_lane, self.scn.n_route
+        NL, NR = self.scn.n_lane, self.scn.n_stream          # pending / serial are per insertion stream
         out = dict(n=np.zeros(NL, np.int32), x=np.zeros((NL, LANE_CAP), np.float32),
                    v=np.zeros((NL, LANE_CAP), np.float32), sf=np.zeros((NL, LANE_CAP), np.float32),
                    w=np.zeros((NL, LANE_CAP), np.int32), r=np.zeros((NL, LANE_CAP), np.int32),

@@ -142,7 +142,8 @@ int tsc_env_step(tsc_env *h, const int32_t *action_dev, float *obs_dev, double *
                  double *global_reward_dev, uint8_t *done_dev, int32_t train_mode);
 
 /* Debug / parity access: vehicle state of env `e` as dense host arrays [n_lane, TSC_LANE_CAP]
- * (front vehicle first) + counts [n_lane] + per-route pending/serial [n_route]. Synchronises. */
+ * (front vehicle first) + counts [n_lane] + per-stream pending/serial [n_stream, = n_route without stream tables].
+ * Synchronises. */
 int tsc_env_get_state(tsc_env *h, int32_t e, int32_t *n, float *x, float *v, float *sf,
                       int32_t *w, int32_t *r, int32_t *pending, int32_t *serial, int32_t *time_sec);
 
