@@ -496,7 +496,8 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     }
                     // zipper merge by readiness: of the feeders of tl whose HEAD wants tl, sees an open signal and can reach
                     // its stop line within this second, the one with the smallest rotating rank (t + rank) % count sends
-                    if (can_cross && (z >> 4) > 1) {
+                    // (large_grid, SPEC 1, has no unsignalised merge: its zip table is all zero, checked at create time)
+                    if (SPEC != 1 && can_cross && (z >> 4) > 1) {
                         const uint32_t ups = s.up4[tl];
                         int best = -1, bestp = 1 << 30;
 #pragma unroll
@@ -805,7 +806,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     const float xt = n > 0 ? tx : (L + kLen) + kS0;
                     float xmax = (xt - kLen) - kS0;
                     float xlo = kLen;
-                    if (P.sorigin) {                                 // the SUMO entry lane is one piece of this (contracted) lane
+                    if (SPEC != 1 && P.sorigin) {                    // the SUMO entry lane is one piece of this (contracted) lane
                         xlo = P.sorigin[2 * r] + kLen;
                         const float hi = P.sorigin[2 * r + 1];
                         if (xmax > hi) xmax = hi;
@@ -817,7 +818,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                         const float ax = xlo + u0 * (xmax - xlo);
                         const float asf = 1.0f + 0.2f * ((u1 + u2) - 1.0f);
                         int rt = r;                                  // the vehicle's route: the stream itself, ...
-                        if (P.sroute) {
+                        if (SPEC == 0 && P.sroute) {                 // (the specialised instantiations have one-to-one streams)
                             const int md = P.smode[r];
                             rt = P.sroute[r];                        // ... the stream's fixed route, ...
                             if (md == 2) rt = P.iroute[(size_t)e * NS + r];      // ... this episode's draw of the host, ...
@@ -1093,6 +1094,7 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     P.clip_wave = sc->clip_wave; P.clip_wait = sc->clip_wait; P.coef_wait = sc->coef_wait;
 
     const int NL = P.NL, NR = P.NR, A = P.A;
+    bool any_zip = false;                   // some lane has more than one feeder without a right-of-way table (zipper merge)
     // insertion streams: none declared -> every route is its own stream
     const bool streams = sc->n_stream > 0;
     const int NS = streams ? sc->n_stream : NR, KC = streams ? sc->k_choice : 1;
@@ -1154,6 +1156,7 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
             zp[i] = (uint8_t)(rank | (cnt << 4));
         }
         UP(zip, uint8_t, zp.data(), zp.size());
+        for (uint8_t v : zp) if (v >> 4 > 1) any_zip = true;
     }
     {
         std::vector<int> se(NS);
@@ -1286,7 +1289,8 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     for (int k = 1; k < 3; ++k) {
         const SpecDims &D = kSpec[k];
         if (P.NS == P.NR && P.NLP == D.NLP && P.NLA == D.NLA && P.NU == D.NU && P.NR == D.NR && P.A == D.A && P.KMAX == D.KMAX && P.PMAX == D.PMAX &&
-            P.LMAX == D.LMAX && P.NBR == D.NBR && P.ctrl == D.ctrl && P.yellow == D.yellow && P.teleport == D.teleport) h->spec = k;
+            P.LMAX == D.LMAX && P.NBR == D.NBR && P.ctrl == D.ctrl && P.yellow == D.yellow && P.teleport == D.teleport &&
+            (k != 1 || (!any_zip && !P.sorigin)) && !P.sroute) h->spec = k;
     }
     if (const char *ev = getenv("TSC_ENV_SPEC")) if (!atoi(ev)) h->spec = 0;
     // vehicles per thread and super-round of the flat phase (TSC_ENV_KF = 1 / 2 / 4 for A/B runs).  With runtime dimensions

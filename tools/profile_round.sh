@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python $ROOT/bench.py --no-cpu-baseline --no-extra"
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o ${TAG} -- $B --steps 3 --warmup 1 > $OUT/${TAG}_bench_rocprof.json 2> $OUT/${TAG}_trace.err
+rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o ${TAG} -- $B --steps 3 --warmup 1 --no-profile > $OUT/${TAG}_bench_rocprof.json 2> $OUT/${TAG}_trace.err
 rocprofv3 --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_fetch -o f -- $B --steps 1 --warmup 1 --no-profile > /dev/null 2> $OUT/${TAG}_pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_write -o w -- $B --steps 1 --warmup 1 --no-profile > /dev/null 2> $OUT/${TAG}_pmc_write.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/${TAG}_pmc_sq -o s -- $B --steps 1 --warmup 1 --no-profile > /dev/null 2> $OUT/${TAG}_pmc_sq.err
