@@ -38,13 +38,13 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 
 
 def pmc_traffic(kernel, default_workload=True):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (profiles/r02_pmc.json: separate
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (profiles/r03_pmc.json: separate
     FETCH_SIZE / WRITE_SIZE passes, KB units; the gfx950 x2 FETCH correction only applies to 16 B/lane streams and
     is NOT applied to these dword-per-lane kernels) or None."""
     if not default_workload:            # the committed counters were collected on the default workload (configs[2]) only
         return None
     try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc.json')))
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc.json')))
         k = d['kernels'][kernel]
         return (k['fetch_kb'] + k['write_kb']) * 1024.0
     except Exception:

@@ -479,80 +479,6 @@ __global__ void __launch_bounds__(64) head_fwd_kernel(const float *__restrict__ 
 //   L = -mean(log_pi[a] Adv) + 0.5 v_coef mean((R - v)^2) - beta mean(entropy), mean over the
 //   T*E samples of one agent.  Writes dL [G][N][8] (pi tower: dlogits, v tower: dv in col 0)
 //   and dH [G][N][64].
-__global__ void __launch_bounds__(64) head_bwd_kernel(const float *__restrict__ params, Layout lay, const int *n_act,
-                                                      const float *Hh, const int *act, const float *Rs, const float *Advs,
-                                                      long long N, float v_coef, float beta, float *dL, float *dH,
-                                                      double *stats) {
-    __shared__ float sp[64][kTLd], sv[64][kTLd];
-    const int a = blockIdx.y, lane = threadIdx.x, na = n_act[a];
-    const long long n0 = (long long)blockIdx.x * 64, left = N - n0;
-    tile_load(Hh + ((long long)(2 * a) * N + n0) * kL, left, sp, lane);
-    tile_load(Hh + ((long long)(2 * a + 1) * N + n0) * kL, left, sv, lane);
-    __syncthreads();
-    float lp = 0.f, lv = 0.f, le = 0.f;
-    if (lane < left) {
-        const long long n = n0 + lane, idx = n * lay.A + a;
-        float pi[kOut], v;
-        head_eval(params, lay, a, na, sp[lane], sv[lane], pi, v);
-        const int ac = act[idx];
-        const float adv = Advs[idx], R = Rs[idx];
-        const float invN = 1.0f / (float)N;
-        float logp[kOut], ent = 0.f;
-        bool inr[kOut];
-#pragma unroll
-        for (int k = 0; k < kOut; ++k) {
-            inr[k] = pi[k] >= 1e-10f;                                  // tf.clip_by_value(pi, 1e-10, 1)
-            logp[k] = k < na ? logf(fminf(fmaxf(pi[k], 1e-10f), 1.0f)) : 0.f;
-            if (k < na) ent -= pi[k] * logp[k];
-        }
-        // dL/dpi_k, then softmax Jacobian: dlogit_k = pi_k (g_k - sum_j pi_j g_j)
-        float gk[kOut], dot = 0.f;
-#pragma unroll
-        for (int k = 0; k < kOut; ++k) {
-            float gpi = 0.f;
-            if (k < na) {
-                if (k == ac && inr[k]) gpi += -adv * invN / fmaxf(pi[k], 1e-10f);
-                gpi += beta * invN * (logp[k] + (inr[k] ? 1.0f : 0.f));
-            }
-            gk[k] = gpi;
-            dot += pi[k] * gpi;
-        }
-        float dl[kOut];
-#pragma unroll
-        for (int k = 0; k < kOut; ++k) dl[k] = k < na ? pi[k] * (gk[k] - dot) : 0.f;
-        const float dv = v_coef * (v - R) * invN;
-        float *o0 = dL + ((long long)(2 * a) * N + n) * kOut, *o1 = dL + ((long long)(2 * a + 1) * N + n) * kOut;
-        *reinterpret_cast<float4 *>(o0) = make_float4(dl[0], dl[1], dl[2], dl[3]);
-        *reinterpret_cast<float4 *>(o0 + 4) = make_float4(dl[4], dl[5], dl[6], dl[7]);
-        *reinterpret_cast<float4 *>(o1) = make_float4(dv, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4 *>(o1 + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float *Wo = params + (long long)(2 * a) * lay.stride + lay.oWo;
-        const float *Wv = params + (long long)(2 * a + 1) * lay.stride + lay.oWo;
-        for (int jj = 0; jj < kL; ++jj) {
-            float sacc = 0.f;
-#pragma unroll
-            for (int k = 0; k < kOut; ++k) sacc += dl[k] * Wo[jj * kOut + k];
-            // FC policy: the head input is relu(.), fold its derivative in here (dZ = dH * (h > 0))
-            const float hp_ = sp[lane][jj], hv_ = sv[lane][jj];
-            sp[lane][jj] = (lay.fc && !(hp_ > 0.f)) ? 0.f : sacc;  // own row only: no hazard
-            sv[lane][jj] = (lay.fc && !(hv_ > 0.f)) ? 0.f : dv * Wv[jj * kOut];
-        }
-        lp = -logp[ac < na ? ac : 0] * adv * invN;
-        lv = 0.5f * v_coef * (R - v) * (R - v) * invN;
-        le = -beta * ent * invN;
-    }
-    __syncthreads();
-    tile_store(dH + ((long long)(2 * a) * N + n0) * kL, left, sp, lane);
-    tile_store(dH + ((long long)(2 * a + 1) * N + n0) * kL, left, sv, lane);
-    if (stats) {   // logging only (policies.py:63-72): one atomic per wave
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { lp += __shfl_down(lp, o); lv += __shfl_down(lv, o); le += __shfl_down(le, o); }
-        if (lane == 0) {
-            atomicAdd(&stats[a * 4 + 0], (double)lp); atomicAdd(&stats[a * 4 + 1], (double)lv);
-            atomicAdd(&stats[a * 4 + 2], (double)le);
-        }
-    }
-}
 
 
 // ------------------------------------------------------------------------------------------------
@@ -2217,7 +2143,6 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     if (const char *ev = getenv("TSC_DBG_THREAD")) m->dbg_tid = atoi(ev);
     m->xcd_map_on = 1;
     if (const char *ev = getenv("TSC_FWD_XCD")) m->xcd_map_on = atoi(ev);
-    if (const char *ev = getenv("TSC_UNFUSED_FWD")) if (atoi(ev)) m->fused_fwd = 0;
     m->fused_dw = !L.fc && (L.H == 224 || L.H == 160);
     if (const char *ev = getenv("TSC_UNFUSED_DW")) if (atoi(ev)) m->fused_dw = 0;
     m->dx_v2 = 1;
@@ -2449,16 +2374,6 @@ int tsc_model_add_transition(tsc_model *m, int32_t t, const float *obs, const ui
 static int launch_head_bwd(tsc_model *m, long long N, double beta) {
     const Layout &L = m->lay;
     hipStream_t st = m->stream;
-    if (getenv("TSC_HEAD_BWD_V1")) {                 // round-1 form (one wave per 64-sample tile + split-K dWo GEMM), for A/B runs
-        {
-            tsc::ProfScope ps7(tsc::KID_HEAD_BWD, m->stream);
-            hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)L.A), dim3(64), 0, st, m->params, L, m->n_act,
-                               m->Hh, m->r_act, m->Rs, m->Advs, N, (float)m->vcoef, (float)beta, m->dL, m->dHh, m->stats);
-        }
-        float *g = m->grads;
-        return gemm(m, tsc::KID_DWO_GEMM, true, tsc::EPI_NONE, (int)L.G, kL, kOut, (int)N, m->Hh, N * kL, kL, 1, m->dL, N * kOut, kOut, g + L.oWo,
-                    L.stride, kOut, nullptr, 0, nullptr, 0, 0, nullptr, 0, g + L.obo, L.stride);
-    }
     int S = (int)((8 * 256 + L.A - 1) / L.A);        // ~8 workgroups per CU
     long long rps = (N + S - 1) / S;
     rps = (rps + 15) / 16 * 16;
