@@ -135,6 +135,7 @@ def scenario_struct(scn):
         clip_wave=scn.clip_wave, clip_wait=scn.clip_wait, coef_wait=scn.coef_wait,
         lane_origin=arr(scn.lane_origin, np.float32, _fp))
     scn.streams_ready()
+    scn.check_limits()
     if scn.stream_entry_lane is not None:
         s.n_stream, s.k_choice = int(scn.n_stream), int(scn.stream_choice.shape[2])
         s.n_interval, s.choice_interval_sec = int(scn.stream_choice.shape[1]), int(min(scn.choice_interval_sec, 1 << 30))

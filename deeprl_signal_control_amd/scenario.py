@@ -130,6 +130,23 @@ class Scenario:
             assert self.stream_choice.ndim == 4 and self.stream_choice.shape[0] == NS and self.stream_choice.shape[3] == 2
         return self
 
+    def check_limits(self):
+        """The fixed capacities of csrc/tsc_env.hip (include/tsc.h TSC_LANE_CAP / TSC_MAX_UP / TSC_MAX_CROSS): a scenario that
+        does not fit is refused here with the remedy, not truncated on the device."""
+        veh = VEH_LEN + MIN_GAP
+        long_ = [self.lane_names[l] for l in range(self.n_lane) if int(self.lane_len[l] // veh) > LANE_CAP]
+        if long_:
+            raise ValueError('lanes %s hold more than %d standing vehicles (%.1f m each): split them into pieces of at most %.0f m '
+                             '(as build_small_grid does with its 400 m edges)' % (long_[:4], LANE_CAP, veh, LANE_CAP * veh))
+        if self.n_route > 254 or self.n_stream > 254:
+            raise ValueError('%d routes / %d insertion streams: at most 254 each (route ids and stream lists are bytes on the device)'
+                             % (self.n_route, self.n_stream))
+        if np.asarray(self.lane_up).shape[1] != MAX_UP:
+            raise ValueError('lane_up must list %d feeder slots per lane' % MAX_UP)
+        if self.control_interval_sec > 8:
+            raise ValueError('control_interval_sec %d > 8 unsupported' % self.control_interval_sec)
+        return self
+
     def entry_lanes(self):
         """(entry lane, route) of every way a vehicle can enter: what decides which lanes can ever be occupied."""
         if self.stream_entry_lane is None:
