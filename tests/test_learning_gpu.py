@@ -1,6 +1,6 @@
 """The HIP path LEARNS: large_grid MA2C at the benchmark batch (E = 1024), Trainer.run's episode loop
 (utils.py:255-308) through tools/learning_curve.py.  The committed curve (profiles/r03_learning_curve.json, 500 episodes at
-the reference's lr 5e-4: -491 -> -166 mean step reward) takes two GPU-minutes; this test runs 18 episodes (108 updates)
+the reference's lr 5e-4: -503 -> -175 mean step reward) takes two GPU-minutes; this test runs 18 episodes (108 updates)
 at lr 5e-3 -- the reference's lr belongs to a batch of 120 samples per update, here an update averages 122 880 -- and asserts
 the trend: the mean step reward of the last four episodes exceeds the first four by a clear margin (measured +7 (+14 under the round-2 simulator spec) against an
 episode-to-episode noise of about 1)."""
