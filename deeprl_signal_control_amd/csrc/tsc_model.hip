@@ -702,6 +702,101 @@ __device__ __forceinline__ int sample_action(const float *pi, int na, unsigned l
 }
 
 // ------------------------------------------------------------------------------------------------
+// FcACPolicy rollout forward in ONE launch (agents/policies.py:214-240; BASELINE configs[1]: IA2C FC, 256 instances):
+//   obs -> relu(obs W1 + b1) -> relu(. Wfc + bfc) -> softmax head / value head -> sampled action.
+// One workgroup per (agent, 64 instances): waves 0-3 evaluate the pi tower, waves 4-7 the V tower; a thread is an
+// instance, a wave a block of output columns, so every weight is wave-uniform (scalar loads, four / eight at a time)
+// and an activation is read from LDS once per four / eight multiply-adds.  The stateless policy needs no activation
+// cache: its update re-evaluates the forward at training shape.  51 us per launch at E = 256 (round 2's four launches per
+// control step -- two grouped GEMMs, heads, sampling -- took 85 us); the 100 workgroups are a latency chain each (quad LDS
+// reads with all 16 units per pass measured slower: 57 us), an MFMA formulation is the next step for this configuration.
+// ------------------------------------------------------------------------------------------------
+constexpr int kFcLdo = 64 + 1;
+__global__ void __launch_bounds__(512) policy_fwd_fc_kernel(const float *__restrict__ params, Layout lay, const int *__restrict__ n_act,
+                                                           const float *__restrict__ obs, int E, float *__restrict__ pi_out,
+                                                           float *__restrict__ v_out, int *action_out, unsigned long long seed,
+                                                           unsigned long long step) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int H = lay.H, SMAX = lay.SMAX, ldx = H + 1;
+    float *ob = (float *)smem_raw;                      // [64][kFcLdo]
+    float *x1 = ob + 64 * kFcLdo;                       // [2 towers][64][H + 1]
+    float *x2 = x1 + 2 * 64 * ldx;                      // [2 towers][64][kFcLdo]
+    const int a = blockIdx.y, e0 = blockIdx.x * 64, tid = threadIdx.x;
+    const int tower = __builtin_amdgcn_readfirstlane(tid >> 8), e = tid & 63;      // wave-uniform: the weight pointers live in SGPRs
+    const int wv = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
+    for (int i = tid; i < 64 * SMAX; i += 512) {
+        const int r = i / SMAX, c = i % SMAX;
+        const int er = e0 + r < E ? e0 + r : E - 1;
+        ob[r * kFcLdo + c] = obs[((long long)er * lay.A + a) * SMAX + c];
+    }
+    __syncthreads();
+    const float *P = params + (long long)(2 * a + tower) * lay.stride;
+    {   // layer 1: this wave's H / 4 columns, four at a time
+        const float *W1 = P + lay.oW1, *b1 = P + lay.ob1;
+        const float *orow = ob + e * kFcLdo;
+        float *xrow = x1 + (tower * 64 + e) * ldx;
+        const int c0 = wv * (H / 4), c1 = c0 + H / 4;
+        for (int c = c0; c < c1; c += 4) {
+            float acc0 = b1[c], acc1 = b1[c + 1], acc2 = b1[c + 2], acc3 = b1[c + 3];
+            // the weights are wave-uniform (scalar loads): twelve rows are requested before the first is used
+            for (int s0 = 0; s0 < SMAX; s0 += 12) {
+                float w[12][4];
+#pragma unroll
+                for (int q = 0; q < 12; ++q) {
+                    const float *wp = W1 + (long long)(s0 + q < SMAX ? s0 + q : SMAX - 1) * H + c;
+                    w[q][0] = wp[0]; w[q][1] = wp[1]; w[q][2] = wp[2]; w[q][3] = wp[3];
+                }
+#pragma unroll
+                for (int q = 0; q < 12; ++q) {          // (-ffp-contract=off: the multiply-adds are explicit)
+                    const float o = s0 + q < SMAX ? orow[s0 + q] : 0.f;
+                    acc0 = fmaf(o, w[q][0], acc0); acc1 = fmaf(o, w[q][1], acc1); acc2 = fmaf(o, w[q][2], acc2); acc3 = fmaf(o, w[q][3], acc3);
+                }
+            }
+            xrow[c] = fmaxf(acc0, 0.f); xrow[c + 1] = fmaxf(acc1, 0.f); xrow[c + 2] = fmaxf(acc2, 0.f); xrow[c + 3] = fmaxf(acc3, 0.f);
+        }
+    }
+    __syncthreads();
+    {   // layer 2: this wave's 16 of the 64 units, eight at a time
+        const float *W2 = P + lay.oWx, *b2 = P + lay.obl;
+        const float *xrow = x1 + (tower * 64 + e) * ldx;
+        float *yrow = x2 + (tower * 64 + e) * kFcLdo;
+#pragma unroll 1
+        for (int j = 16 * wv; j < 16 * wv + 16; j += 8) {
+            float acc[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] = b2[j + q];
+            for (int c0 = 0; c0 < H; c0 += 8) {                  // H % 8 == 0; eight rows of eight weights in flight
+                float w[8][8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float *wp = W2 + (long long)(c0 + r) * kL + j;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) w[r][q] = wp[q];
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float x = xrow[c0 + r];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[q] = fmaf(x, w[r][q], acc[q]);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) yrow[j + q] = fmaxf(acc[q], 0.f);
+        }
+    }
+    __syncthreads();
+    if (tid < 64 && e0 + tid < E) {                     // heads + sampling, one instance per thread
+        float pi[kOut], v;
+        const int na = n_act[a];
+        head_eval(params, lay, a, na, x2 + tid * kFcLdo, x2 + (64 + tid) * kFcLdo, pi, v);
+        const long long idx = (long long)(e0 + tid) * lay.A + a;
+        for (int k = 0; k < lay.AMAX; ++k) pi_out[idx * lay.AMAX + k] = k < kOut ? pi[k] : 0.f;
+        v_out[idx] = v;
+        if (action_out) action_out[idx] = sample_action(pi, na, seed, step, idx);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused rollout forward (one control step, IA2C.forward agents/models.py:185-200): for one agent-tower
 // and a tile of 64 env instances, in ONE launch:
 //   obs -> relu(obs W1 + b1) -> [x | h] [Wx ; Wh] + b -> LSTM cell -> head (softmax / value).
@@ -2310,7 +2405,23 @@ static int model_forward(tsc_model *m, const float *obs, const uint8_t *done, fl
         TSC_HIP(hipGetLastError());
         return 0;
     }
-    // unfused path (FC policy, or shapes the fused kernel does not cover): the training kernels with T = 1
+    if (L.fc && L.H % 16 == 0 && L.SMAX <= 64 && L.AMAX <= kOut) {     // FcACPolicy: one launch (policy_fwd_fc_kernel)
+        const size_t lds = sizeof(float) * ((size_t)64 * kFcLdo + (size_t)2 * 64 * (L.H + 1) + (size_t)2 * 64 * kFcLdo);
+        static bool attr_set = false;
+        if (!attr_set) {
+            TSC_HIP(hipFuncSetAttribute((const void *)policy_fwd_fc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        if (lds <= 160 * 1024) {
+            tsc::ProfScope ps(tsc::KID_FUSED_FWD, m->stream);
+            hipLaunchKernelGGL(policy_fwd_fc_kernel, dim3((unsigned)((E + 63) / 64), (unsigned)L.A), dim3(512), lds, m->stream, m->params, L,
+                               m->n_act, obs, E, pi, v, action, (unsigned long long)seed, (unsigned long long)step);
+            ps.stop();
+            TSC_HIP(hipGetLastError());
+            return 0;
+        }
+    }
+    // unfused path (shapes the fused kernels do not cover): the training kernels with T = 1
     if (dense_forward(m, obs, E, m->X1, L.fc ? m->Hh : m->Z)) return tsc::fail("tsc_model_forward: gemm launch failed");
     if (L.fc) {                                   // stateless: FcACPolicy.forward (agents/policies.py:237-240)
         tsc::ProfScope psh(tsc::KID_HEAD_FWD, m->stream);
