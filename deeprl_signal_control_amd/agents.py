@@ -474,7 +474,7 @@ class VecA2C:
         """First half of IA2C.backward (agents/models.py:174-183): returns + loss + BPTT -> flat gradient buffer."""
         assert self.cur_t == self.n_step, 'backward() needs a full n_step buffer (T %% n_step == 0, utils.py:121)'
         self._cur_lr = self.lr_scheduler.get(self.n_step)
-        cur_beta = self.beta_scheduler.get(self.n_step)
+        self._cur_beta = cur_beta = self.beta_scheduler.get(self.n_step)
         _lib.check(self._L.tsc_model_compute_grads(self._h, C.c_void_p(R.data_ptr()), float(cur_beta)))
 
     def apply_grads(self, scale=1.0, want_stats=False):

@@ -33,8 +33,8 @@ def _make(fx, E):
     cfg = refnet.fixture_model_cfg(fx)
     n_s, n_a, n_w, n_f = (fx[k].tolist() for k in ('n_s_ls', 'n_a_ls', 'n_w_ls', 'n_f_ls'))
     s_max = (max(n_s) + 3) // 4 * 4
-    m = VecA2C(n_s, n_a, n_w, n_f, E, s_max, max(n_a), cfg, device=0, seed=int(fx['seed_w']), name=str(fx['agent']),
-               policy=str(fx['policy']))
+    m = VecA2C(n_s, n_a, n_w, n_f, E, s_max, max(n_a), cfg, total_step=len(fx['actions']), device=0, seed=int(fx['seed_w']),
+               name=str(fx['agent']), policy=str(fx['policy']))      # total_step as main.py passes it (the schedules' horizon)
     return m, s_max
 
 
@@ -62,13 +62,15 @@ def test_hip_replays_reference_learner(name, E, path):
     sl = m.rollout_slots() if path == 'slots' else None
     m.reset()
     worst = dict(pi=0.0, v=0.0, g=0.0, w=0.0)
-    gtol = 1e-4 if E <= 128 else 1e-3
+    # replicated data: every instance adds the same fp32 term, so the rounding of the batch sum is biased and grows with E
+    # (distinct data at E=1024: 3e-6, test_model_gpu.py::test_update_benchmarked_batch_E1024_T120)
+    gtol = 1e-4 if E <= 8 else 3e-4 if E <= 128 else 1e-3
 
     def backward(k, R):
         p = 'bw%d/' % k
         np.testing.assert_allclose(R.cpu().numpy(), np.broadcast_to(fx[p + 'R'], (E, A)), rtol=0, atol=2e-5)
         m.compute_grads(R)
-        assert abs(m.beta_scheduler.val - float(fx[p + 'beta'])) < 1e-12 and abs(m._cur_lr - float(fx[p + 'lr'])) < 1e-12
+        assert abs(m._cur_beta - float(fx[p + 'beta'])) < 1e-12 and abs(m._cur_lr - float(fx[p + 'lr'])) < 1e-12      # schedules (a16)
         Rs, Advs = np.zeros((n_step, E, A), np.float32), np.zeros((n_step, E, A), np.float32)
         from deeprl_signal_control_amd import _lib
         import ctypes as C
