@@ -8,8 +8,8 @@ numbers; the distance to the anchors is asserted as such so that nobody reads "c
 
 Round 3 changed the spec: merge arbitration by readiness, a teleport surrogate that removes a
 blocked head after time-to-teleport, headway 1.0 s.  Monaco under the reference's greedy controller went from a
-permanent gridlock after t = 1300 s (355 trips, 1.96 m/s, 395 s mean wait) to 1271 completed trips (372 of them ended by
-the teleport surrogate), 2.7 m/s and 86 s mean wait.  DESIGN.md section 3 ("calibration") records what was measured
+permanent gridlock after t = 1300 s (355 trips, 1.96 m/s, 395 s mean wait) to 1486 completed trips (489 of them ended by
+the teleport surrogate), 2.8 m/s and 81 s mean wait.  DESIGN.md section 3 ("calibration") records what was measured
 and why the anchors stay out of reach."""
 import numpy as np
 
@@ -52,10 +52,10 @@ def test_monaco_greedy_band():
             w[a, :len(o)] = o
         return list(greedy_actions(scn, w))
     r, peak, tot = _episode(scn, 10000, act)
-    assert -200.0 < r < -90.0 and 538 <= peak <= 734                  # today -136.6, 610: peak inside the published 538-734
+    assert -200.0 < r < -90.0 and 538 <= peak <= 734                  # today -137.0, 608: peak inside the published 538-734
     assert tot['departed'] + tot['pending'] > 2300                    # ~2383 vehicles demanded (A.4)
-    assert tot['arrived'] > 1000 and tot['departed'] > 1500           # today 1271 of 1762 inserted (round 2: 355 of 999)
-    assert 200 < tot['teleported'] < 600                              # 372: the greedy controller starves shared lanes
+    assert tot['arrived'] > 1000 and tot['departed'] > 1500           # today 1486 of 1950 inserted (round 2: 355 of 999)
+    assert 200 < tot['teleported'] < 600                              # 489: the greedy controller starves shared lanes
     assert r / -41.8 > 2.0                                            # still several times MORE congested than SUMO's greedy run
 
 
@@ -86,7 +86,7 @@ def test_monaco_greedy_eval_tables_vs_published():
     ours = dict(avg_queue=np.mean([t['avg_queue'] for t in traffic]), avg_speed_mps=np.mean([t['avg_speed_mps'] for t in traffic]),
                 avg_wait_sec=np.mean([t['avg_wait_sec'] for t in traffic]), peak_cars=max(t['number_total_car'] for t in traffic),
                 trips=len(trips))
-    # today: queue 1.32 veh/lane, 2.72 m/s, 86 s mean wait, 610 concurrent vehicles, 1271 completed trips
+    # today: queue 1.32 veh/lane, 2.79 m/s, 81 s mean wait, 608 concurrent vehicles, 1486 completed trips
     # (round 2: 1.71, 1.96 m/s, 395 s, 644, 355)
     assert 0.8 < ours['avg_queue'] < 2.0 and 2.0 < ours['avg_speed_mps'] < 4.0 and 50 < ours['avg_wait_sec'] < 150
     assert 500 < ours['peak_cars'] < 800 and 1000 < ours['trips'] < 1700
