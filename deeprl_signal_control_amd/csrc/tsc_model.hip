@@ -326,7 +326,9 @@ __global__ void __launch_bounds__(256, 2) lstm_bwd2_kernel(const float *__restri
     // pair r = 4 rt + i  <->  env row 16 rt + 4 kq + i (accumulator register i of row tile rt)
     float gi[NP], gf[NP], go[NP], gu[NP], cc[NP], cpv[NP], dhi[NP];
     unsigned keepbits = 0;
-    auto request = [&](int t) {
+    // c_t of step t is the c_{t-1} the step after it (t + 1, processed before) asked for: only c_{t-1} is loaded per step,
+    // the c_t registers are filled from the previous step's c_{t-1} (`first`: step T - 1 loads both)
+    auto request = [&](int t, bool first) {
         const long long nt = (long long)t * E;
         const float *zt = zg + nt * kG4, *ct = cg + nt * kL, *ht = hg + nt * kL;
         const float *cp_base = t > 0 ? ct - (long long)E * kL : sg;         // c_{t-1}: Cc[t-1] ([e][64]) or the state ([e][128])
@@ -341,13 +343,15 @@ __global__ void __launch_bounds__(256, 2) lstm_bwd2_kernel(const float *__restri
             const int e = e0 + er < E ? e0 + er : E - 1;
             const unsigned oz = (unsigned)(e * kG4 + j) * 4u, oc = (unsigned)(e * kL + j) * 4u;
             gi[r] = ldg(zt, oz); gf[r] = ldg(zt, oz + 256u); go[r] = ldg(zt, oz + 512u); gu[r] = ldg(zt, oz + 768u);
-            cc[r] = ldg(ct, oc); dhi[r] = ldg(ht, oc);
+            if (first) cc[r] = ldg(ct, oc);
+            else cc[r] = cpv[r];
+            dhi[r] = ldg(ht, oc);
             cpv[r] = ldg(cp_base, (unsigned)(e * cp_ld + j) * 4u);
             if (dt[e] == 0) kb |= 1u << r;
         }
         keepbits = kb;
     };
-    request(T - 1);
+    request(T - 1, true);
     for (int t = T - 1; t >= 0; --t) {
         const long long nt = (long long)t * E;
         float *zw = Z + ((long long)g * N + nt) * kG4;
@@ -374,7 +378,7 @@ __global__ void __launch_bounds__(256, 2) lstm_bwd2_kernel(const float *__restri
             row[0] = di; row[64] = df; row[128] = dog; row[192] = du;
         }
         __syncthreads();
-        if (t > 0) request(t - 1);                  // in flight under the MFMAs below
+        if (t > 0) request(t - 1, false);           // in flight under the MFMAs below
         f32x4 acc[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
