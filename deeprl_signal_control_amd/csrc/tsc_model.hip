@@ -1877,7 +1877,7 @@ template <int NCU>   // H / 16
 __global__ void __launch_bounds__(512, 1)
 dx1w1_kernel2(const float *__restrict__ dZ, const float *__restrict__ X1, const float *__restrict__ WxT,
               const float *__restrict__ obs, long long N, int G, int S, long long rows_per_split, int A, int SMAX,
-              float *__restrict__ ws) {
+              float *__restrict__ ws, const int *__restrict__ ftm) {
     constexpr int H = 16 * NCU, NHU = 2 * NCU;                  // half units (column unit x row tile) per chunk
     constexpr int CHI = (NHU + 7) / 8, CLO = NHU / 8;           // tiles of waves 0..3 / 4..7
     static_assert(NHU % 8 == 0 || NHU % 8 == 4, "H must be a multiple of 32");
@@ -1885,7 +1885,7 @@ dx1w1_kernel2(const float *__restrict__ dZ, const float *__restrict__ X1, const 
     float *Az = (float *)smem_raw;                              // [2][32][kD1Ld]
     float *Ob = Az + 2 * 32 * kD1Ld;                            // [2][32][kObLd]
     const int g = blockIdx.x % G, sp = blockIdx.x / G, a = g >> 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, kq = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 15, kq = lane >> 4;
     const long long n0 = (long long)sp * rows_per_split;
     long long n1 = n0 + rows_per_split;
     if (n1 > N) n1 = N;
@@ -1899,6 +1899,10 @@ dx1w1_kernel2(const float *__restrict__ dZ, const float *__restrict__ X1, const 
     const bool a00 = 2 * U0 >= st, a01 = 2 * U0 + 1 < st + cnt, a10 = 2 * U0 + 2 < st + cnt, a11 = 2 * U0 + 3 < st + cnt;
     const int U1 = U0 + 1 < NCU ? U0 + 1 : NCU - 1;             // clamped when the second slot is unused
     const int col0 = 16 * U0 + n, col1 = 16 * U1 + n;
+    // W1 is block-structured (obs rows of one kind feed one block of hidden columns, agents/policies.py:41-61): of the four
+    // 16-feature tiles of dW1 a column unit only accumulates the ones with a structural non-zero (two of four on the
+    // reference's nets: 72 instead of 80 MFMAs per 16 x 16 tile); the others stay zero, as dx1w1_reduce2_kernel writes them
+    const int fm0 = ftm[a * NCU + U0], fm1 = ftm[a * NCU + U1];
     // stationary B operands: bwX[4 j + c] = Wx^T[k = 16 j + 4 kq + c][col]
     float bw0[64], bw1[64];
     {
@@ -1938,7 +1942,7 @@ dx1w1_kernel2(const float *__restrict__ dZ, const float *__restrict__ X1, const 
         *reinterpret_cast<float4 *>(Ob + ((long long)buf * 32 + orow) * kObLd + 4 * oc) = so;
     };
     // one column unit of the chunk in LDS buffer `buf`: both / one of its row tiles
-    auto unit = [&](int buf, long long row, const float (&bw)[64], int col, bool r0, bool r1, f32x4 (&aw)[4], float &bs) {
+    auto unit = [&](int buf, long long row, const float (&bw)[64], int col, bool r0, bool r1, f32x4 (&aw)[4], float &bs, int fm) {
         // relu mask rows 16 r + 4 kq + i of column col: requested first, consumed after the 64 / 128 MFMAs
         float xm0[4], xm1[4];
         int zq = 0;
@@ -1998,7 +2002,8 @@ dx1w1_kernel2(const float *__restrict__ dZ, const float *__restrict__ X1, const 
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int ft = 0; ft < 4; ++ft)
-                    aw[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(Os[i * kObLd + 16 * ft], d[i], aw[ft], 0, 0, 0);
+                    if ((fm >> ft) & 1)                                 // wave-uniform
+                        aw[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(Os[i * kObLd + 16 * ft], d[i], aw[ft], 0, 0, 0);
         };
         if (r0) tail(0, c0, xm0);
         if (r1) tail(1, c1, xm1);
@@ -2010,8 +2015,8 @@ dx1w1_kernel2(const float *__restrict__ dZ, const float *__restrict__ X1, const 
         int buf = 0;
         for (long long row = n0; row < n1; row += 32, buf ^= 1) {
             fetch(row + 32);                                    // lands while this chunk computes
-            if (a00 || a01) unit(buf, row, bw0, col0, a00, a01, accW[0], bsum0);
-            if (a10 || a11) unit(buf, row, bw1, col1, a10, a11, accW[1], bsum1);
+            if (a00 || a01) unit(buf, row, bw0, col0, a00, a01, accW[0], bsum0, fm0);
+            if (a10 || a11) unit(buf, row, bw1, col1, a10, a11, accW[1], bsum1, fm1);
             put(buf ^ 1);
             __syncthreads();
         }
@@ -2092,6 +2097,7 @@ struct tsc_model {
     int16_t *rowrange;          // [A][SMAX][2]
     int *wgmap; int wgmap_S, wgmap_n, xcd_map_on;   // ws forward: blockIdx -> (tower << 8 | split), XCD-affine (TSC_FWD_XCD=0: off)
     int dbg_tid;                // thread of workgroup 0 that writes the clock stamps (TSC_DBG_THREAD)
+    int *ftmask;                // [A][H / 16]: 16-feature tiles of dW1 with a structural non-zero in column unit U (dx1w1_kernel2)
     int *krange;                // [A][8][2]: first-layer MFMA steps (2 obs rows each) that feed hidden column tile w (ws forward)
     float *params, *grads, *ms, *WxT;
     float *Wg;                  // gate-interleaved copy of [Wx ; Wh] for the fused forward (interleave_gates_kernel)
@@ -2206,6 +2212,17 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
                 kr[((size_t)a * 8 + w) * 2] = j0 / 2; kr[((size_t)a * 8 + w) * 2 + 1] = (j1 + 1) / 2;
             }
         TSC_HIP(tsc::upload<int>(&m->krange, kr.data(), kr.size())); m->allocs.push_back(m->krange);
+    }
+    {   // per (agent, 16-column unit): which 16-row tiles of W1 hold a structural non-zero
+        const int ncu = (L.H + 15) / 16;
+        std::vector<int> fm((size_t)L.A * ncu, 0);
+        for (int a = 0; a < L.A; ++a)
+            for (int u = 0; u < ncu; ++u)
+                for (int j = 0; j < L.SMAX && j < 64; ++j) {
+                    const int lo = rr[((size_t)a * L.SMAX + j) * 2], hi = rr[((size_t)a * L.SMAX + j) * 2 + 1];
+                    if (lo < 16 * u + 16 && hi > 16 * u) fm[(size_t)a * ncu + u] |= 1 << (j >> 4);
+                }
+        TSC_HIP(tsc::upload<int>(&m->ftmask, fm.data(), fm.size())); m->allocs.push_back(m->ftmask);
     }
     TSC_HIP(tsc::upload<int>(&m->n_act, cfg->n_act, L.A)); m->allocs.push_back(m->n_act);
     const long long E = n_env, T = m->T, N = E * T, G = L.G, A = L.A;
@@ -2603,7 +2620,7 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
         if (m->dx_v2) {
             {
                 tsc::ProfScope ps(tsc::KID_DX1_GEMM, m->stream);
-#define TSC_DX2(NCU) hipLaunchKernelGGL(dx1w1_kernel2<NCU>, dim3((unsigned)(S * G)), dim3(512), lds, st, m->Z, m->X1, m->WxT, m->r_obs, N, (int)G, S, rps, (int)A, L.SMAX, m->ws)
+#define TSC_DX2(NCU) hipLaunchKernelGGL(dx1w1_kernel2<NCU>, dim3((unsigned)(S * G)), dim3(512), lds, st, m->Z, m->X1, m->WxT, m->r_obs, N, (int)G, S, rps, (int)A, L.SMAX, m->ws, m->ftmask)
                 if (L.H == 224) TSC_DX2(14); else if (L.H == 160) TSC_DX2(10); else if (L.H == 192) TSC_DX2(12); else TSC_DX2(8);
 #undef TSC_DX2
             }
