@@ -283,31 +283,35 @@ __global__ void __launch_bounds__(256, 2) lstm_bwd_kernel(const float *__restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same recurrence re-tiled so that the NEXT step's inputs are in flight during the MFMA phase (round 3).
-// lstm_bwd_kernel keeps a 32-column strip of Wh^T per wave stationary (128 registers): there is no room to hold a
-// second step's inputs, so every step pays its load latency twice (two batches of eight rows) before the MFMAs start
-// -- MFMA busy 35 %, 4.2 ms.  Here a wave owns 16 unit columns (v_mfma_f32_16x16x4_f32, four 16-env row tiles = four
-// independent accumulators): its slice of Wh^T is 64 registers, which leaves room for ALL of a step's inputs when a
-// workgroup takes 32 env instances (RT = 2: 8 (env, unit) pairs x 7 values per lane; 235 VGPRs, two workgroups per CU).
+// The same recurrence re-tiled (round 3) so that the NEXT step's inputs are in flight during the MFMA phase and every
+// global access is 16 bytes wide.  lstm_bwd_kernel keeps a 32-column strip of Wh^T per wave stationary (128 registers): there
+// is no room to hold a second step's inputs, so every step pays its load latency twice before the MFMAs start -- MFMA busy
+// 35 %, 4.2 ms.  Here a wave owns 16 unit columns (v_mfma_f32_16x16x4_f32, two 16-instance row tiles = two independent
+// accumulators): its slice of Wh^T is 64 registers, which leaves room for ALL of a step's inputs of a 32-instance workgroup.
+// The gate math is elementwise, so it runs on its own thread mapping -- a thread owns ONE instance and EIGHT consecutive
+// units (16-byte accesses, eight threads = one 256-byte row; on the MFMA output layout the same data were 48 dword loads per
+// lane and step, 64-byte runs over four rows) -- and only the recurrent dh crosses mappings, through 8 KB of LDS between the
+// two barriers the step has anyway.  c_t of a step is the c_{t-1} the step processed before it asked for: one cache array is
+// read once, not twice.
 // A step: gate math from the registers -> dz to HBM and LDS (row-major, read back as 16-byte A-operand quads) -> barrier
-// -> request the inputs of step t - 1 -> 128 MFMAs (the loads land underneath) -> barrier.
-// Measured (tools/bench_update.py, E = 1024, T = 120): 4.13 -> 4.02 ms.  The prefetch buys little because the kernel
-// moves 2.8 KB per sample and tower (gates in, dz out, c, c_prev, dH): 17 GB per update = 4.3 TB/s -- it runs at the HBM
-// rate the access pattern allows, not at a latency; 64-instance tiles with the inputs fetched in halves spill (RT = 4:
-// 14.5 ms) and are not instantiated.
+// -> request the inputs of step t - 1 -> 64 MFMAs (the loads land underneath) -> dh to LDS -> barrier.
+// Measured (tools/bench_update.py, E = 1024, T = 120): 4.13 ms (strip kernel) -> 4.02 (16-column waves, dword accesses)
+// -> 3.60 (c_t from registers) -> 3.39 ms: 2.56 KB per sample and tower (gates in, dz out, c_prev, dH) = 15.7 GB per update
+// at 4.6 TB/s.  Three workgroups per CU (168 VGPRs, 4 spilled) measured the same (3.35 ms).
 // ------------------------------------------------------------------------------------------------
-constexpr int kDz2Ld = kG4 + 4;   // dz tile [RT * 16 env][256 k + 4]
+constexpr int kDz2Ld = kG4 + 4;   // dz tile [32 env][256 k + 4]
+constexpr int kDh3Ld = kL + 4;    // recurrent dh tile [32 env][64 units + 4]
 
-template <int RT>     // 16-env row tiles per workgroup: 2 (32 envs, three workgroups per CU) or 4
 __global__ void __launch_bounds__(256, 2) lstm_bwd2_kernel(const float *__restrict__ params, Layout lay, float *Z,
-                                                                        const float *Cc, const float *state_bw, const float *dH,
-                                                                        const uint8_t *done, int T, int E) {
-    constexpr int NP = 4 * RT;                      // (env, unit) pairs per lane
+                                                            const float *Cc, const float *state_bw, const float *dH,
+                                                            const uint8_t *done, int T, int E) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float *dzs = (float *)smem_raw;                 // [16 RT env][kDz2Ld]
-    const int g = blockIdx.x, e0 = blockIdx.y * (16 * RT);
+    float *dzs = (float *)smem_raw;                 // [32 env][kDz2Ld]
+    float *dhs = dzs + 32 * kDz2Ld;                 // [32 env][kDh3Ld]
+    const int g = blockIdx.x, e0 = blockIdx.y * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, kq = lane >> 4;
-    const int j = 16 * wave + n;                    // this lane's hidden unit
+    const int j = 16 * wave + n;                    // MFMA phase: this lane's hidden unit
+    const int er = tid >> 3, u0 = (tid & 7) * 8;    // elementwise phase: instance row, first of 8 units
     const long long N = (long long)T * E;
     float bw[64];                                   // bw[4 q + c] = Wh[j][16 q + 4 kq + c] = B[k = 16 q + 4 kq + c][n]
     {
@@ -318,94 +322,106 @@ __global__ void __launch_bounds__(256, 2) lstm_bwd2_kernel(const float *__restri
             bw[4 * q] = w4.x; bw[4 * q + 1] = w4.y; bw[4 * q + 2] = w4.z; bw[4 * q + 3] = w4.w;
         }
     }
-    float dh_rec[NP], dc_rec[NP];
+    float dc_rec[8];
 #pragma unroll
-    for (int r = 0; r < NP; ++r) { dh_rec[r] = 0.f; dc_rec[r] = 0.f; }
+    for (int r = 0; r < 8; ++r) dc_rec[r] = 0.f;
     const float *zg = Z + (long long)g * N * kG4, *cg = Cc + (long long)g * N * kL, *hg = dH + (long long)g * N * kL;
     const float *sg = state_bw + (long long)g * E * 2 * kL;
-    // pair r = 4 rt + i  <->  env row 16 rt + 4 kq + i (accumulator register i of row tile rt)
-    float gi[NP], gf[NP], go[NP], gu[NP], cc[NP], cpv[NP], dhi[NP];
-    unsigned keepbits = 0;
-    // c_t of step t is the c_{t-1} the step after it (t + 1, processed before) asked for: only c_{t-1} is loaded per step,
-    // the c_t registers are filled from the previous step's c_{t-1} (`first`: step T - 1 loads both)
+    const int e = e0 + er < E ? e0 + er : E - 1;
+    const bool live = e0 + er < E;
+    float4 gi[2], gf[2], go[2], gu[2], cc[2], cpv[2], dhi[2];
+    float keep = 0.f, keep_next = 0.f;              // keep of the step being processed / of the step processed before it (t + 1)
+    // c_t of step t is the c_{t-1} the step after it (t + 1, processed before) asked for (`first`: step T - 1 loads both)
     auto request = [&](int t, bool first) {
         const long long nt = (long long)t * E;
         const float *zt = zg + nt * kG4, *ct = cg + nt * kL, *ht = hg + nt * kL;
         const float *cp_base = t > 0 ? ct - (long long)E * kL : sg;         // c_{t-1}: Cc[t-1] ([e][64]) or the state ([e][128])
         const unsigned cp_ld = t > 0 ? kL : 2 * kL;
-        const uint8_t *dt = done + nt;
         int zq = 0;
-        asm volatile("" : "+v"(zq));                // lane offsets are formed per step, not hoisted out of the t loop and spilled
-        unsigned kb = 0;
+        asm volatile("" : "+v"(zq));                // lane offsets are formed per step, not hoisted out of the t loop
+        const unsigned oz = (unsigned)((e + zq) * kG4 + u0) * 4u, oc = (unsigned)((e + zq) * kL + u0) * 4u;
 #pragma unroll
-        for (int r = 0; r < NP; ++r) {
-            const int er = 16 * (r >> 2) + 4 * kq + (r & 3) + zq;
-            const int e = e0 + er < E ? e0 + er : E - 1;
-            const unsigned oz = (unsigned)(e * kG4 + j) * 4u, oc = (unsigned)(e * kL + j) * 4u;
-            gi[r] = ldg(zt, oz); gf[r] = ldg(zt, oz + 256u); go[r] = ldg(zt, oz + 512u); gu[r] = ldg(zt, oz + 768u);
-            if (first) cc[r] = ldg(ct, oc);
-            else cc[r] = cpv[r];
-            dhi[r] = ldg(ht, oc);
-            cpv[r] = ldg(cp_base, (unsigned)(e * cp_ld + j) * 4u);
-            if (dt[e] == 0) kb |= 1u << r;
+        for (int a = 0; a < 2; ++a) {
+            gi[a] = ldg((const float4 *)zt, oz + 16u * a); gf[a] = ldg((const float4 *)zt, oz + 256u + 16u * a);
+            go[a] = ldg((const float4 *)zt, oz + 512u + 16u * a); gu[a] = ldg((const float4 *)zt, oz + 768u + 16u * a);
+            if (first) cc[a] = ldg((const float4 *)ct, oc + 16u * a);
+            else cc[a] = cpv[a];
+            dhi[a] = ldg((const float4 *)ht, oc + 16u * a);
+            cpv[a] = ldg((const float4 *)cp_base, (unsigned)((e + zq) * cp_ld + u0) * 4u + 16u * a);
         }
-        keepbits = kb;
+        keep_next = keep;
+        keep = done[nt + e] == 0 ? 1.0f : 0.0f;
     };
     request(T - 1, true);
     for (int t = T - 1; t >= 0; --t) {
         const long long nt = (long long)t * E;
         float *zw = Z + ((long long)g * N + nt) * kG4;
-        const unsigned kb = keepbits;
+        // recurrent dh of this thread's pairs: what the MFMA phase of step t + 1 left in LDS, cut where step t + 1 began an episode
+        float4 dhr[2];
+        if (t == T - 1) { dhr[0] = dhr[1] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        else {
+            dhr[0] = *reinterpret_cast<const float4 *>(dhs + er * kDh3Ld + u0);
+            dhr[1] = *reinterpret_cast<const float4 *>(dhs + er * kDh3Ld + u0 + 4);
+        }
 #pragma unroll
-        for (int r = 0; r < NP; ++r) {
-            const int er = 16 * (r >> 2) + 4 * kq + (r & 3);
-            const float ig = gi[r], fg = gf[r], og = go[r], ug = gu[r];
-            const float keep = (kb >> r) & 1u ? 1.0f : 0.0f;
-            const float cp = cpv[r] * keep;
-            const float dh = dhi[r] + dh_rec[r];
-            const float tc = tanhf_(cc[r]);
-            const float dog = dh * tc * og * (1.0f - og);
-            const float dc = dh * og * (1.0f - tc * tc) + dc_rec[r];
-            const float di = dc * ug * ig * (1.0f - ig);
-            const float df = dc * cp * fg * (1.0f - fg);
-            const float du = dc * ig * (1.0f - ug * ug);
-            dc_rec[r] = dc * fg * keep;
-            if (e0 + er < E) {
-                const unsigned oz = (unsigned)((e0 + er) * kG4 + j) * 4u;
-                stg(zw, oz, di); stg(zw, oz + 256u, df); stg(zw, oz + 512u, dog); stg(zw, oz + 768u, du);
+        for (int a = 0; a < 2; ++a) {
+            const float igv[4] = {gi[a].x, gi[a].y, gi[a].z, gi[a].w}, fgv[4] = {gf[a].x, gf[a].y, gf[a].z, gf[a].w};
+            const float ogv[4] = {go[a].x, go[a].y, go[a].z, go[a].w}, ugv[4] = {gu[a].x, gu[a].y, gu[a].z, gu[a].w};
+            const float ccv[4] = {cc[a].x, cc[a].y, cc[a].z, cc[a].w}, cpw[4] = {cpv[a].x, cpv[a].y, cpv[a].z, cpv[a].w};
+            const float dhv[4] = {dhi[a].x, dhi[a].y, dhi[a].z, dhi[a].w}, drv[4] = {dhr[a].x, dhr[a].y, dhr[a].z, dhr[a].w};
+            float di[4], df[4], dg[4], du[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int r = 4 * a + c;
+                const float ig = igv[c], fg = fgv[c], og = ogv[c], ug = ugv[c];
+                const float cp = cpw[c] * keep;
+                const float dh = dhv[c] + (keep_next != 0.f ? drv[c] : 0.f);
+                const float tc = tanhf_(ccv[c]);
+                dg[c] = dh * tc * og * (1.0f - og);
+                const float dc = dh * og * (1.0f - tc * tc) + dc_rec[r];
+                di[c] = dc * ug * ig * (1.0f - ig);
+                df[c] = dc * cp * fg * (1.0f - fg);
+                du[c] = dc * ig * (1.0f - ug * ug);
+                dc_rec[r] = dc * fg * keep;
             }
-            float *row = dzs + er * kDz2Ld + j;
-            row[0] = di; row[64] = df; row[128] = dog; row[192] = du;
+            const float4 o_di = make_float4(di[0], di[1], di[2], di[3]), o_df = make_float4(df[0], df[1], df[2], df[3]);
+            const float4 o_do = make_float4(dg[0], dg[1], dg[2], dg[3]), o_du = make_float4(du[0], du[1], du[2], du[3]);
+            if (live) {
+                const unsigned oz = (unsigned)((e0 + er) * kG4 + u0 + 4 * a) * 4u;
+                stg((float4 *)zw, oz, o_di); stg((float4 *)zw, oz + 256u, o_df);
+                stg((float4 *)zw, oz + 512u, o_do); stg((float4 *)zw, oz + 768u, o_du);
+            }
+            float *row = dzs + er * kDz2Ld + u0 + 4 * a;
+            *reinterpret_cast<float4 *>(row) = o_di; *reinterpret_cast<float4 *>(row + 64) = o_df;
+            *reinterpret_cast<float4 *>(row + 128) = o_do; *reinterpret_cast<float4 *>(row + 192) = o_du;
+            __builtin_amdgcn_sched_barrier(0);       // the two halves one after the other (registers)
         }
         __syncthreads();
         if (t > 0) request(t - 1, false);           // in flight under the MFMAs below
-        f32x4 acc[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float4 *A0 = reinterpret_cast<const float4 *>(dzs + n * kDz2Ld + 4 * kq);
+        f32x4 acc[2];
+        acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float4 *Aa = reinterpret_cast<const float4 *>(dzs + n * kDz2Ld + 4 * kq), *Ab = Aa + (16 * kDz2Ld) / 4;
         // two row tiles at a time (two independent accumulators cover the 40-cycle dependent latency); the next quads are
-        // requested before this step's MFMAs and the iterations are kept apart, or all the LDS reads get hoisted (and spilled)
+        // requested before this step's MFMAs and the iterations are kept apart, or all the LDS reads get hoisted
+        float4 pa = Aa[0], pb = Ab[0];
 #pragma unroll
-        for (int half = 0; half < RT / 2; ++half) {
-            const float4 *Aa = A0 + (16 * (2 * half) * kDz2Ld) / 4, *Ab = A0 + (16 * (2 * half + 1) * kDz2Ld) / 4;
-            float4 pa = Aa[0], pb = Ab[0];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const float4 na = Aa[4 * (q + 1 < 16 ? q + 1 : q)], nb = Ab[4 * (q + 1 < 16 ? q + 1 : q)];
-                acc[2 * half] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.x, bw[4 * q], acc[2 * half], 0, 0, 0);
-                acc[2 * half + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb.x, bw[4 * q], acc[2 * half + 1], 0, 0, 0);
-                acc[2 * half] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.y, bw[4 * q + 1], acc[2 * half], 0, 0, 0);
-                acc[2 * half + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb.y, bw[4 * q + 1], acc[2 * half + 1], 0, 0, 0);
-                acc[2 * half] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.z, bw[4 * q + 2], acc[2 * half], 0, 0, 0);
-                acc[2 * half + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb.z, bw[4 * q + 2], acc[2 * half + 1], 0, 0, 0);
-                acc[2 * half] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.w, bw[4 * q + 3], acc[2 * half], 0, 0, 0);
-                acc[2 * half + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb.w, bw[4 * q + 3], acc[2 * half + 1], 0, 0, 0);
-                pa = na; pb = nb;
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        for (int q = 0; q < 16; ++q) {
+            const float4 na = Aa[4 * (q + 1 < 16 ? q + 1 : q)], nb = Ab[4 * (q + 1 < 16 ? q + 1 : q)];
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.x, bw[4 * q], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb.x, bw[4 * q], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.y, bw[4 * q + 1], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb.y, bw[4 * q + 1], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.z, bw[4 * q + 2], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb.z, bw[4 * q + 2], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa.w, bw[4 * q + 3], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb.w, bw[4 * q + 3], acc[1], 0, 0, 0);
+            pa = na; pb = nb;
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int r = 0; r < NP; ++r) dh_rec[r] = (kb >> r) & 1u ? acc[r >> 2][r & 3] : 0.f;
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dhs[(16 * rt + 4 * kq + i) * kDh3Ld + j] = acc[rt][i];
         __syncthreads();
     }
 }
@@ -2112,7 +2128,7 @@ struct tsc_model {
     float *ws, *wsc;            // split-K workspace
     size_t ws_floats, wsc_floats;
     size_t lds_fwd, lds_bwd, lds_fused, lds_ws;
-    int bwd_v2;                 // BPTT with 16-column waves and next-step prefetch (lstm_bwd2_kernel; TSC_LSTM_BWD_V2=0: the strip kernel)
+    int bwd_v2;                 // BPTT with 16-column waves, next-step prefetch and 16-byte accesses (lstm_bwd2_kernel; TSC_LSTM_BWD_V2=0: the strip kernel)
     int fused_fwd;
     int fused_dw;               // dWx | dWh | dbl in one pass (dwxh_kernel)
     int fused_dx;               // dX1 in registers, dW1 | db1 in the same pass (dx1w1_kernel)
@@ -2247,7 +2263,7 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     m->lds_bwd = sizeof(float) * (kG4 * kDzLd);
     m->bwd_v2 = 1;
     if (const char *ev = getenv("TSC_LSTM_BWD_V2")) m->bwd_v2 = atoi(ev);
-    TSC_HIP(hipFuncSetAttribute((const void *)lstm_bwd2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 32 * kDz2Ld)));
+    TSC_HIP(hipFuncSetAttribute((const void *)lstm_bwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 32 * (kDz2Ld + kDh3Ld))));
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fwd));
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fwd));
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bwd));
@@ -2576,7 +2592,7 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
     if (launch_head_bwd(m, N, beta)) return tsc::fail("head_bwd failed");           // + dWo, dbo
     tsc::ProfScope ps8(tsc::KID_LSTM_BWD, m->stream);
     if (m->bwd_v2)
-        hipLaunchKernelGGL(lstm_bwd2_kernel<2>, dim3((unsigned)G, (unsigned)((E + 31) / 32)), dim3(256), sizeof(float) * 32 * kDz2Ld, st,
+        hipLaunchKernelGGL(lstm_bwd2_kernel, dim3((unsigned)G, (unsigned)((E + 31) / 32)), dim3(256), sizeof(float) * 32 * (kDz2Ld + kDh3Ld), st,
                            m->params, L, m->Z, m->Cc, m->state_bw, m->dHh, m->r_done, (int)T, (int)E);
     else
         hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)G, (unsigned)((E + 63) / 64)), dim3(256), m->lds_bwd, st, m->params, L,
