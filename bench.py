@@ -64,7 +64,7 @@ def algorithmic_flops(model, rows):
                 'dwx_gemm': z * rows, 'dwh_gemm': 0.0, 'dx1_gemm': z * rows, 'dw1_gemm': fc * rows, 'dwo_gemm': 0.0}
     fused = fc + G * 2 * H * 4 * L + G * 2 * L * 4 * L + out           # one rollout forward of every tower
     # profile ids keep the names of the grouped GEMMs they started as: with the fused update kernels (default)
-    # 'dwx_gemm' times dwxh_kernel (dWx + dWh + dbl in one pass) and 'dx1_gemm' times dx1w1_kernel (dX1 + dW1 + db1);
+    # 'dwx_gemm' times dwxh_kernel (dWx + dWh + dbl in one pass) and 'dx1_gemm' times dx1w1_kernel2 (dX1 + dW1 + db1);
     # 'dwh_gemm' / 'dw1_gemm' are then only their split reductions
     dwx = G * 2 * H * 4 * L * rows
     dwh = G * 2 * L * 4 * L * rows

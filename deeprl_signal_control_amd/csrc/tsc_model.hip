@@ -178,126 +178,26 @@ __global__ void __launch_bounds__(256, PF ? 1 : 2) lstm_fwd_kernel(const float *
 }
 
 // ------------------------------------------------------------------------------------------------
-// LSTM backward through time.  One workgroup per (group, 64-env tile); lanes keep dc and the
-// recurrent dh of their 16 (env, unit) pairs in registers over the whole sequence.
+// LSTM backward through time (tf.gradients through the n_step-unrolled agents/utils.py:88-116).  One workgroup per
+// (group, 32-env tile); dc and the recurrent dh of every (env, unit) pair stay on chip over the whole sequence.
 //   Z   [G][N][256] in: gates i|f|o|u (post-activation)   out: dz (pre-activation gradients)
 //   Cc  [G][N][64]  c_t;  c_{t-1} = Cc[t-1] or state_bw, masked by done[t]
 //   dH  [G][N][64]  gradient arriving at h_t from the head
-// per step: dz -> LDS (k-major) -> dh_{t-1} = dz * Wh^T on the MFMA (K = 256).
-// Wh^T is the STATIONARY operand: a lane's 128 B values (its unit's row of Wh, one half of the gate columns --
-// the k index of an MFMA step is free to choose, here k = 128*kh + s) stay in registers for all T steps, so
-// LDS holds only the dz tile (70 KB) and two workgroups share a CU: the step is a latency chain
-// (loads -> gate math -> barrier -> 128 MFMAs -> barrier) that one workgroup per CU cannot hide.
-// The step inputs are fetched four accumulator rows at a time (no next-step prefetch: the registers hold Wh^T).
-// ------------------------------------------------------------------------------------------------
-constexpr int kDzLd = 64 + 4;
-constexpr int QR = 8;            // accumulator rows per load batch of lstm_bwd (4: quarters, 8: halves)
-
-__global__ void __launch_bounds__(256, 2) lstm_bwd_kernel(const float *__restrict__ params, Layout lay, float *Z,
-                                                         const float *Cc, const float *state_bw, const float *dH,
-                                                         const uint8_t *done, int T, int E) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float *dzs = (float *)smem_raw;                 // [256 k = gate col][kDzLd m = env]
-    const int g = blockIdx.x, e0 = blockIdx.y * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r0 = 32 * (wave & 1), j0 = 32 * (wave >> 1), li = lane & 31, kh = lane >> 5;
-    const int j = j0 + li;
-    const long long N = (long long)T * E;
-    float bw[128];                                  // Wh[j][128*kh .. 128*kh+127] = B[k = 128*kh + s][n = j]
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(params + (long long)g * lay.stride + lay.oWh + (long long)j * kG4 + 128 * kh);
-#pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const float4 w4 = src[q];
-            bw[4 * q] = w4.x; bw[4 * q + 1] = w4.y; bw[4 * q + 2] = w4.z; bw[4 * q + 3] = w4.w;
-        }
-    }
-    float dh_rec[16], dc_rec[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { dh_rec[r] = 0.f; dc_rec[r] = 0.f; }
-    // workgroup-uniform bases + 32-bit lane offsets (rows past E are clamped for the loads and never stored)
-    const float *zg = Z + (long long)g * N * kG4, *cg = Cc + (long long)g * N * kL, *hg = dH + (long long)g * N * kL;
-    const float *sg = state_bw + (long long)g * E * 2 * kL;
-    for (int t = T - 1; t >= 0; --t) {
-        const long long nt = (long long)t * E;
-        const float *zt = zg + nt * kG4, *ct = cg + nt * kL, *ht = hg + nt * kL;
-        const float *cp_base = t > 0 ? ct - (long long)E * kL : sg;         // c_{t-1}: Cc[t-1] ([e][64]) or the state ([e][128])
-        const unsigned cp_ld = t > 0 ? kL : 2 * kL;
-        const uint8_t *dt = done + nt;
-        unsigned keepbits = 0;
-#pragma unroll
-        for (int qd = 0; qd < 16 / QR; ++qd) {
-            float gi[QR], gf[QR], go[QR], gu[QR], cc[QR], cpv[QR], dhi[QR], kp[QR];
-            int er[QR];
-            int zq = 0;
-            asm volatile("" : "+v"(zq));                // lane offsets are formed here every step, not hoisted out of the t loop and spilled
-#pragma unroll
-            for (int q = 0; q < QR; ++q) {
-                const int r = QR * qd + q;
-                er[q] = r0 + (r & 3) + 8 * (r >> 2) + 4 * kh + zq;
-                const int e = e0 + er[q] < E ? e0 + er[q] : E - 1;
-                const unsigned oz = (unsigned)(e * kG4 + j) * 4u, oc = (unsigned)(e * kL + j) * 4u;
-                gi[q] = ldg(zt, oz); gf[q] = ldg(zt, oz + 256u); go[q] = ldg(zt, oz + 512u); gu[q] = ldg(zt, oz + 768u);
-                cc[q] = ldg(ct, oc); dhi[q] = ldg(ht, oc);
-                cpv[q] = ldg(cp_base, (unsigned)(e * cp_ld + j) * 4u);
-                kp[q] = 1.0f - (float)dt[e];
-            }
-#pragma unroll
-            for (int q = 0; q < QR; ++q) {
-                const int r = QR * qd + q;
-                const float ig = gi[q], fg = gf[q], og = go[q], ug = gu[q];
-                const float keep = kp[q];
-                const float cp = cpv[q] * keep;
-                const float dh = dhi[q] + dh_rec[r];
-                const float tc = tanhf_(cc[q]);
-                const float dog = dh * tc * og * (1.0f - og);
-                const float dc = dh * og * (1.0f - tc * tc) + dc_rec[r];
-                const float di = dc * ug * ig * (1.0f - ig);
-                const float df = dc * cp * fg * (1.0f - fg);
-                const float du = dc * ig * (1.0f - ug * ug);
-                dc_rec[r] = dc * fg * keep;
-                if (keep != 0.f) keepbits |= 1u << r;
-                if (e0 + er[q] < E) {
-                    float *zw = Z + ((long long)g * N + nt) * kG4;
-                    const unsigned oz = (unsigned)((e0 + er[q]) * kG4 + j) * 4u;
-                    stg(zw, oz, di); stg(zw, oz + 256u, df); stg(zw, oz + 512u, dog); stg(zw, oz + 768u, du);
-                }
-                dzs[(j) * kDzLd + er[q]] = di;
-                dzs[(64 + j) * kDzLd + er[q]] = df;
-                dzs[(128 + j) * kDzLd + er[q]] = dog;
-                dzs[(192 + j) * kDzLd + er[q]] = du;
-            }
-            __builtin_amdgcn_sched_barrier(0);          // keep the quarters apart: their loads would all be hoisted (and spilled)
-        }
-        __syncthreads();
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const float *As = dzs + (128 * kh) * kDzLd + r0 + li;
-#pragma unroll
-        for (int s2 = 0; s2 < 128; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[s2 * kDzLd], bw[s2], acc, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dh_rec[r] = (keepbits >> r) & 1u ? acc[r] : 0.f;
-        __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// The same recurrence re-tiled (round 3) so that the NEXT step's inputs are in flight during the MFMA phase and every
-// global access is 16 bytes wide.  lstm_bwd_kernel keeps a 32-column strip of Wh^T per wave stationary (128 registers): there
-// is no room to hold a second step's inputs, so every step pays its load latency twice before the MFMAs start -- MFMA busy
-// 35 %, 4.2 ms.  Here a wave owns 16 unit columns (v_mfma_f32_16x16x4_f32, two 16-instance row tiles = two independent
-// accumulators): its slice of Wh^T is 64 registers, which leaves room for ALL of a step's inputs of a 32-instance workgroup.
+// per step: dz -> LDS (row-major) -> dh_{t-1} = dz * Wh^T on the MFMA (K = 256).  Wh^T is the STATIONARY operand: a wave
+// owns 16 unit columns (v_mfma_f32_16x16x4_f32, two 16-instance row tiles = two independent accumulators), its slice of
+// Wh^T is 64 registers for all T steps -- which leaves room for ALL of the next step's inputs: they are requested before
+// the MFMA phase and land underneath it (round 2's 32-column strips held 128 weight registers and paid every step's
+// load latency twice: MFMA busy 35 %, 4.2 ms).
 // The gate math is elementwise, so it runs on its own thread mapping -- a thread owns ONE instance and EIGHT consecutive
 // units (16-byte accesses, eight threads = one 256-byte row; on the MFMA output layout the same data were 48 dword loads per
 // lane and step, 64-byte runs over four rows) -- and only the recurrent dh crosses mappings, through 8 KB of LDS between the
 // two barriers the step has anyway.  c_t of a step is the c_{t-1} the step processed before it asked for: one cache array is
 // read once, not twice.
-// A step: gate math from the registers -> dz to HBM and LDS (row-major, read back as 16-byte A-operand quads) -> barrier
+// A step: gate math from the registers -> dz to HBM and LDS (read back as 16-byte A-operand quads) -> barrier
 // -> request the inputs of step t - 1 -> 64 MFMAs (the loads land underneath) -> dh to LDS -> barrier.
-// Measured (tools/bench_update.py, E = 1024, T = 120): 4.13 ms (strip kernel) -> 4.02 (16-column waves, dword accesses)
+// Measured (tools/bench_update.py, E = 1024, T = 120): 4.13 ms (round 2) -> 4.02 (16-column waves, dword accesses)
 // -> 3.60 (c_t from registers) -> 3.39 ms: 2.56 KB per sample and tower (gates in, dz out, c_prev, dH) = 15.7 GB per update
-// at 4.6 TB/s.  Three workgroups per CU (168 VGPRs, 4 spilled) measured the same (3.35 ms).
+// at 4.6 TB/s.  Three workgroups per CU (168 VGPRs, 4 spilled) measured the same (3.35 ms); 64-instance tiles spill.
 // ------------------------------------------------------------------------------------------------
 constexpr int kDz2Ld = kG4 + 4;   // dz tile [32 env][256 k + 4]
 constexpr int kDh3Ld = kL + 4;    // recurrent dh tile [32 env][64 units + 4]
@@ -1717,178 +1617,23 @@ __global__ void dwxh_reduce_kernel(const float *__restrict__ ws, int G, int S, l
 // First-layer gradients of one tower in ONE pass over the n-step batch, without ever writing dX1:
 //   dX1 = (dZ Wx^T) * relu'(X1)   (32-row chunks, never leaves the registers)
 //   dW1 = obs^T dX1,  db1 = colsum(dX1)        (agents/utils.py:66-74 through tf.gradients)
-// Work split of the 8-wave workgroup (one per CU, S x G workgroups, each a fixed row range of one tower):
-//   * waves 0..NCT-1 each own one 32-column strip of X1.  Their slice of Wx^T (256 x 32) is the STATIONARY MFMA
-//     operand: 128 registers per lane, loaded once.  Per chunk: 128 MFMAs (A = the dZ chunk, row-major in LDS,
-//     one 16-byte read per four steps),
-//     mask with X1 > 0, then the masked accumulator tile is fed STRAIGHT back as the B operand of the dW1 product
-//     (accumulator row (r, lane half) = contraction index of step r), A = the obs chunk from LDS: 32 more MFMAs;
-//   * the remaining wave(s) are LOADERS: they fetch the next dZ / obs chunk with 16-byte loads while the others
-//     compute, and copy it into the other LDS buffer.
-// Replaces the dX1 GEMM (second column tile 25 % empty, dZ read twice), the 11 GB dX1 round trip through HBM and
-// the dW1 GEMM.  Deterministic: partial dW1 / db1 per workgroup, added in split order by dx1w1_reduce_kernel,
-// which also applies the structural zeros of the block-diagonal first layer.
+// One 8-wave workgroup per CU (S x G workgroups, each a fixed row range of one tower).  The unit of work is a 16 x 16
+// tile of the chunk's dX1 (v_mfma_f32_16x16x4_f32): 2 row tiles x H/16 column units per 32-row chunk, dealt out so that the
+// two waves of every SIMD (w, w + 4) own the same number of tiles (H = 224: 4 + 3 of 28), a column unit possibly split
+// between two waves by row tile (round 2 gave a 32-column strip to each of 7 waves and kept the eighth as a loader: 7/8 of
+// the MFMA rate at best).  All eight waves compute; the next chunk (dZ rows, row-major like HBM, and the obs rows) is
+// fetched into registers at the top of a chunk and written to the other LDS buffer at its end (five 16-byte loads per
+// thread).  A wave keeps the Wx^T slices of its (at most two) column units stationary (64 registers each); per tile 64
+// MFMAs give dX1, masked by X1 > 0, and the accumulator registers go STRAIGHT back in as the B operand of the dW1 product
+// against the obs tile (accumulator row = contraction index of the step), only for the 16-feature tiles of W1 that hold a
+// structural non-zero in the column unit.
+// Replaces the dX1 GEMM (second column tile 25 % empty, dZ read twice), the 11 GB dX1 round trip through HBM and the dW1
+// GEMM.  Deterministic: partial dW1 | db1 per (workgroup, row-tile slot), added in that order by dx1w1_reduce2_kernel, which
+// also applies the structural zeros of the block-diagonal first layer.
 // ------------------------------------------------------------------------------------------------
 constexpr int kD1Ld = 260;       // dZ chunk [32 rows][256 k + 4]: row-major like HBM, read as 16-byte A-operand quads
 constexpr int kObLd = 68;        // obs chunk [32 rows][64 features + 4]
 
-template <int NCT>   // H / 32
-__global__ void __launch_bounds__(512, 1)
-dx1w1_kernel(const float *__restrict__ dZ, const float *__restrict__ X1, const float *__restrict__ WxT,
-             const float *__restrict__ obs, long long N, int G, int S, long long rows_per_split, int A, int SMAX,
-             float *__restrict__ ws) {
-    constexpr int H = 32 * NCT, NLT = 512 - 64 * NCT;           // loader threads
-    constexpr int NZQ = 32 * 64, NOQ = 32 * 16;                 // float4s per chunk: dZ (32 x 256), obs (32 x 64, zero padded)
-    constexpr int NQ = (NZQ + NOQ + NLT - 1) / NLT;             // staging slots per loader thread
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float *Az = (float *)smem_raw;                              // [2][32][kD1Ld]
-    float *Ob = Az + 2 * 32 * kD1Ld;                            // [2][32][kObLd]
-    const int g = blockIdx.x % G, sp = blockIdx.x / G, a = g >> 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
-    const long long n0 = (long long)sp * rows_per_split;
-    long long n1 = n0 + rows_per_split;
-    if (n1 > N) n1 = N;
-    const float *dz = dZ + (long long)g * N * kG4, *x1 = X1 + (long long)g * N * H;
-    const long long AS = (long long)A * SMAX;
-    const int sq = SMAX >> 2;                                   // float4s per obs row
-    float *w = ws + ((long long)sp * G + g) * ((long long)65 * H);
-    if (wave >= NCT) {
-        // ---------------- loader waves ----------------
-        const int lt = tid - 64 * NCT;
-        // sub-batches of 8 float4s, software-pipelined (load batch b+1, then scatter batch b): a chunk's 40 slots
-        // as one register array end up in scratch
-        constexpr int SB = 8, NB = (NQ + SB - 1) / SB;
-        auto load1 = [&](int idx, long long row0) {
-            if (idx >= NZQ + NOQ) idx = NZQ + NOQ - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < NZQ) {                                 // dZ: 64 float4 per row, coalesced
-                long long row = row0 + (idx >> 6);
-                if (row >= n1) row = n1 - 1;
-                v = *reinterpret_cast<const float4 *>(dz + row * kG4 + 4 * (idx & 63));
-            } else {
-                const int j = idx - NZQ, c4 = j & 15;
-                long long row = row0 + (j >> 4);
-                if (row >= n1) row = n1 - 1;
-                if (c4 < sq) v = *reinterpret_cast<const float4 *>(obs + row * AS + (long long)a * SMAX + 4 * c4);
-            }
-            return v;
-        };
-        auto store1 = [&](int idx, int buf, const float4 &v) {
-            if (idx < NZQ) {
-                *reinterpret_cast<float4 *>(Az + ((long long)buf * 32 + (idx >> 6)) * kD1Ld + 4 * (idx & 63)) = v;
-            } else if (idx < NZQ + NOQ) {
-                const int j = idx - NZQ;
-                *reinterpret_cast<float4 *>(Ob + ((long long)buf * 32 + (j >> 4)) * kObLd + 4 * (j & 15)) = v;
-            }
-        };
-        // stage chunk [row0, row0 + 32) into LDS buffer buf
-        auto stage = [&](long long row0, int buf) {
-            float4 c0, c1, c2, c3, c4, c5, c6, c7, d0, d1, d2, d3, d4, d5, d6, d7;
-#define TSC_LD8(p, b) do { const int i0 = lt + NLT * SB * (b); p##0 = load1(i0, row0); p##1 = load1(i0 + NLT, row0); p##2 = load1(i0 + 2 * NLT, row0); p##3 = load1(i0 + 3 * NLT, row0); p##4 = load1(i0 + 4 * NLT, row0); p##5 = load1(i0 + 5 * NLT, row0); p##6 = load1(i0 + 6 * NLT, row0); p##7 = load1(i0 + 7 * NLT, row0); } while (0)
-#define TSC_ST8(p, b) do { const int i0 = lt + NLT * SB * (b); store1(i0, buf, p##0); store1(i0 + NLT, buf, p##1); store1(i0 + 2 * NLT, buf, p##2); store1(i0 + 3 * NLT, buf, p##3); store1(i0 + 4 * NLT, buf, p##4); store1(i0 + 5 * NLT, buf, p##5); store1(i0 + 6 * NLT, buf, p##6); store1(i0 + 7 * NLT, buf, p##7); } while (0)
-            TSC_LD8(c, 0);
-#pragma unroll
-            for (int b2 = 0; b2 < NB; b2 += 2) {
-                if (b2 + 1 < NB) TSC_LD8(d, b2 + 1);
-                TSC_ST8(c, b2);
-                if (b2 + 2 < NB) TSC_LD8(c, b2 + 2);
-                if (b2 + 1 < NB) TSC_ST8(d, b2 + 1);
-            }
-#undef TSC_LD8
-#undef TSC_ST8
-        };
-        if (n0 < n1) {
-            stage(n0, 0);
-            __syncthreads();
-            int buf = 0;
-            for (long long row = n0; row < n1; row += 32, buf ^= 1) {
-                stage(row + 32, buf ^ 1);                   // while the MFMA waves work on `buf`
-                __syncthreads();
-            }
-        }
-        return;
-    }
-    // ---------------- MFMA waves: column strip [32 * wave, 32 * wave + 32) ----------------
-    const int col = 32 * wave + li;
-    float bw[128];                                              // Wx^T[k = 128 * kh + s][col]
-    {
-        const float *src = WxT + (long long)g * kG4 * H + (long long)(128 * kh) * H + col;
-#pragma unroll
-        for (int s2 = 0; s2 < 128; ++s2) bw[s2] = src[(long long)s2 * H];
-    }
-    f32x16 accW[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accW[mt][r] = 0.f;
-    float bsum = 0.f;
-    if (n0 < n1) {
-        __syncthreads();
-        int buf = 0;
-        for (long long row = n0; row < n1; row += 32, buf ^= 1) {
-            // relu mask of this chunk: in flight under the 128 MFMAs
-            float xm[16];
-            int zq = 0;
-            asm volatile("" : "+v"(zq));
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                long long rr = row + ((r & 3) + 8 * (r >> 2) + 4 * kh + zq);
-                if (rr >= n1) rr = n1 - 1;
-                xm[r] = x1[rr * H + col];
-            }
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            // A operand: row li of the chunk, k = 128 * kh + s2 -- four MFMA steps per 16-byte LDS read
-            const float4 *As = reinterpret_cast<const float4 *>(Az + ((long long)buf * 32 + li) * kD1Ld + 128 * kh);
-            // the next quad is requested before this one's MFMAs (pinned by sched_barrier): after a barrier the two waves of a
-            // SIMD run in lock-step, so an LDS wait in front of every second quad is a wait of the whole MFMA pipe
-            float4 a4 = As[0];
-#pragma unroll
-            for (int j4 = 0; j4 < 32; ++j4) {
-                const float4 an = As[j4 + 1 < 32 ? j4 + 1 : j4];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bw[4 * j4], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bw[4 * j4 + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bw[4 * j4 + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bw[4 * j4 + 3], acc, 0, 0, 0);
-                a4 = an;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            const float *Os = Ob + (long long)buf * 32 * kObLd + li;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rho = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const float d = (xm[r] > 0.f && row + rho < n1) ? acc[r] : 0.f;        // dX1[row + rho][col]
-                bsum += d;
-                accW[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[rho * kObLd], d, accW[0], 0, 0, 0);
-                accW[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[rho * kObLd + 32], d, accW[1], 0, 0, 0);
-            }
-            __syncthreads();
-        }
-    }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int f = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * kh;       // obs feature
-            w[(long long)f * H + col] = accW[mt][r];
-        }
-    bsum += __shfl_xor(bsum, 32, 64);
-    if (kh == 0) w[(long long)64 * H + col] = bsum;
-}
-
-// ------------------------------------------------------------------------------------------------
-// The same pass re-tiled for an even MFMA load (round 3).  dx1w1_kernel gives a 32-column strip to each of 7 waves and
-// keeps the eighth as a loader: three SIMDs carry two strips, one carries one -- 7/8 of the MFMA rate at best, and every
-// wave waits at the chunk barrier for the slowest SIMD.  Here the unit of work is a 16 x 16 tile of the chunk's dX1
-// (v_mfma_f32_16x16x4_f32): 2 row tiles x H/16 column units per 32-row chunk, dealt out so that the two waves of every
-// SIMD (w, w + 4) own the same number of tiles (H = 224: 4 + 3 of 28), a column unit possibly split between two waves
-// by row tile.  All eight waves compute; the next chunk is fetched into registers at the top of a chunk and written to
-// the other LDS buffer at its end (five 16-byte loads per thread).  A wave keeps the Wx^T slices of its (at most two)
-// column units stationary (64 registers each); per tile 64 MFMAs give dX1, masked by X1 > 0, and the accumulator
-// registers go straight back in as the B operand of 16 MFMAs against the obs tile (contraction order = accumulator row
-// order, the trick of dx1w1_kernel).  Partial dW1 | db1 per (workgroup, row-tile slot), folded by dx1w1_reduce2_kernel.
-// ------------------------------------------------------------------------------------------------
 template <int NCU>   // H / 16
 __global__ void __launch_bounds__(512, 1)
 dx1w1_kernel2(const float *__restrict__ dZ, const float *__restrict__ X1, const float *__restrict__ WxT,
@@ -2083,26 +1828,6 @@ __global__ void dx1w1_reduce2_kernel(const float *__restrict__ ws, int G, int S,
     }
 }
 
-// grads[g][oW1 .. +SMAX*H) and [ob1 .. +H) = sum over splits, in split order; structural zeros of W1 applied
-__global__ void dx1w1_reduce_kernel(const float *__restrict__ ws, int G, int S, int H, int SMAX, const int16_t *__restrict__ rr,
-                                    float *__restrict__ grads, long long stride, long long oW1, long long ob1) {
-    const long long per = (long long)65 * H, out = (long long)(SMAX + 1) * H;
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= out * G) return;
-    const long long g = i / out, j = i % out;
-    const int f = (int)(j / H), n = (int)(j % H);
-    const long long src = f < SMAX ? j : (long long)64 * H + n;
-    float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc += ws[((long long)s * G + g) * per + src];
-    if (f < SMAX) {
-        const int16_t *q = rr + ((g >> 1) * SMAX + f) * 2;
-        if (n < q[0] || n >= q[1]) acc = 0.f;
-        grads[g * stride + oW1 + j] = acc;
-    } else {
-        grads[g * stride + ob1 + n] = acc;
-    }
-}
-
 struct tsc_model {
     Layout lay;
     int E, T, device;
@@ -2127,12 +1852,10 @@ struct tsc_model {
     double *norm2, *stats, *norm_part;
     float *ws, *wsc;            // split-K workspace
     size_t ws_floats, wsc_floats;
-    size_t lds_fwd, lds_bwd, lds_fused, lds_ws;
-    int bwd_v2;                 // BPTT with 16-column waves, next-step prefetch and 16-byte accesses (lstm_bwd2_kernel; TSC_LSTM_BWD_V2=0: the strip kernel)
+    size_t lds_fwd, lds_fused, lds_ws;
     int fused_fwd;
     int fused_dw;               // dWx | dWh | dbl in one pass (dwxh_kernel)
-    int fused_dx;               // dX1 in registers, dW1 | db1 in the same pass (dx1w1_kernel)
-    int dx_v2;                  // ... as 16 x 16 tiles dealt evenly over the SIMDs (dx1w1_kernel2; TSC_DX_V2=0: the strip kernel)
+    int fused_dx;               // dX1 in registers, dW1 | db1 in the same pass (dx1w1_kernel2)
     int inplace;                // the running rollout is written straight into the buffer's slots (tsc_model_rollout_slot): slot T -> 0 carry
     int cached_next;            // next rollout slot whose activations the fused forward will cache; T = all cached
     long long *dbg;
@@ -2260,13 +1983,9 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     m->ws_floats = (size_t)48 << 20; m->wsc_floats = (size_t)1 << 20;      // 192 MiB + 4 MiB
     MALLOC(m->ws, float, m->ws_floats); MALLOC(m->wsc, float, m->wsc_floats);
     m->lds_fwd = sizeof(float) * (64 * kWhLd + 64 * kHsLd);
-    m->lds_bwd = sizeof(float) * (kG4 * kDzLd);
-    m->bwd_v2 = 1;
-    if (const char *ev = getenv("TSC_LSTM_BWD_V2")) m->bwd_v2 = atoi(ev);
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_bwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * 32 * (kDz2Ld + kDh3Ld))));
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fwd));
     TSC_HIP(hipFuncSetAttribute((const void *)lstm_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fwd));
-    TSC_HIP(hipFuncSetAttribute((const void *)lstm_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bwd));
     m->dbg = nullptr;
     m->cached_next = 0;
     m->inplace = 0;
@@ -2277,9 +1996,7 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     if (const char *ev = getenv("TSC_FWD_XCD")) m->xcd_map_on = atoi(ev);
     m->fused_dw = !L.fc && (L.H == 224 || L.H == 160);
     if (const char *ev = getenv("TSC_UNFUSED_DW")) if (atoi(ev)) m->fused_dw = 0;
-    m->dx_v2 = 1;
-    if (const char *ev = getenv("TSC_DX_V2")) m->dx_v2 = atoi(ev);
-    m->fused_dx = !L.fc && (L.H == 224 || L.H == 160 || (m->dx_v2 && (L.H == 192 || L.H == 128))) && L.SMAX <= 64 && L.SMAX % 4 == 0;
+    m->fused_dx = !L.fc && (L.H == 224 || L.H == 160 || L.H == 192 || L.H == 128) && L.SMAX <= 64 && L.SMAX % 4 == 0;
     if (const char *ev = getenv("TSC_UNFUSED_DX")) if (atoi(ev)) m->fused_dx = 0;
     if (m->fused_dx) {
         const int lds = (int)(sizeof(float) * (2 * 32 * kD1Ld + 2 * 32 * kObLd));
@@ -2287,8 +2004,6 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
         TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel2<10>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel2<12>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel2<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
     m->lds_ws = sizeof(float) * ((size_t)32 * (L.H + 64 + 4) + 64 * kWsLdx + (size_t)kL * kWsLdg + (size_t)kG4 * kWsLdg + 528 + (kWsBuf + 2) * 32 * kOut + (size_t)L.SMAX * L.H);
     if (m->fused_fwd && (L.H == 224 || L.H == 160) && m->lds_ws <= 160 * 1024) {
@@ -2591,12 +2306,8 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
     }
     if (launch_head_bwd(m, N, beta)) return tsc::fail("head_bwd failed");           // + dWo, dbo
     tsc::ProfScope ps8(tsc::KID_LSTM_BWD, m->stream);
-    if (m->bwd_v2)
-        hipLaunchKernelGGL(lstm_bwd2_kernel, dim3((unsigned)G, (unsigned)((E + 31) / 32)), dim3(256), sizeof(float) * 32 * (kDz2Ld + kDh3Ld), st,
-                           m->params, L, m->Z, m->Cc, m->state_bw, m->dHh, m->r_done, (int)T, (int)E);
-    else
-        hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)G, (unsigned)((E + 63) / 64)), dim3(256), m->lds_bwd, st, m->params, L,
-                           m->Z, m->Cc, m->state_bw, m->dHh, m->r_done, (int)T, (int)E);
+    hipLaunchKernelGGL(lstm_bwd2_kernel, dim3((unsigned)G, (unsigned)((E + 31) / 32)), dim3(256), sizeof(float) * 32 * (kDz2Ld + kDh3Ld), st,
+                       m->params, L, m->Z, m->Cc, m->state_bw, m->dHh, m->r_done, (int)T, (int)E);
     ps8.stop();
     tsc::ProfScope ps9(tsc::KID_TRANSPOSE, m->stream);
     hipLaunchKernelGGL(transpose_wx_kernel, dim3((unsigned)((G * L.H * kG4 + 255) / 256)), dim3(256), 0, st, m->params, L, m->WxT);
@@ -2629,33 +2340,21 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
              kG4, nullptr, 0, nullptr, 0, 0, nullptr, 0, nullptr, 0)) return tsc::fail("gemm failed");
     }
     if (m->fused_dx && L.ob1 == L.oW1 + (long long)L.SMAX * L.H && (size_t)((long long)S * G * 2 * 65 * L.H) <= m->ws_floats) {
-        // dX1 stays in registers: dW1 | db1 come out of the same pass (dx1w1_kernel)
+        // dX1 stays in registers: dW1 | db1 come out of the same pass (dx1w1_kernel2)
         long long rps = (N + S - 1) / S;
         rps = (rps + 31) / 32 * 32;                  // whole 32-row chunks
         const size_t lds = sizeof(float) * (2 * 32 * kD1Ld + 2 * 32 * kObLd);
-        if (m->dx_v2) {
-            {
-                tsc::ProfScope ps(tsc::KID_DX1_GEMM, m->stream);
+        {
+            tsc::ProfScope ps(tsc::KID_DX1_GEMM, m->stream);
 #define TSC_DX2(NCU) hipLaunchKernelGGL(dx1w1_kernel2<NCU>, dim3((unsigned)(S * G)), dim3(512), lds, st, m->Z, m->X1, m->WxT, m->r_obs, N, (int)G, S, rps, (int)A, L.SMAX, m->ws, m->ftmask)
-                if (L.H == 224) TSC_DX2(14); else if (L.H == 160) TSC_DX2(10); else if (L.H == 192) TSC_DX2(12); else TSC_DX2(8);
+            if (L.H == 224) TSC_DX2(14); else if (L.H == 160) TSC_DX2(10); else if (L.H == 192) TSC_DX2(12); else TSC_DX2(8);
 #undef TSC_DX2
-            }
+        }
+        {
             tsc::ProfScope ps(tsc::KID_DW1_GEMM, m->stream);
             const long long tot = (long long)(L.SMAX + 1) * L.H * G;
             hipLaunchKernelGGL(dx1w1_reduce2_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m->ws, (int)G, S, L.H, L.SMAX,
                                m->rowrange, g, L.stride, L.oW1, L.ob1);
-        } else {
-        {
-            tsc::ProfScope ps(tsc::KID_DX1_GEMM, m->stream);
-            if (L.H == 224) hipLaunchKernelGGL(dx1w1_kernel<7>, dim3((unsigned)(S * G)), dim3(512), lds, st, m->Z, m->X1, m->WxT, m->r_obs, N, (int)G, S, rps, (int)A, L.SMAX, m->ws);
-            else hipLaunchKernelGGL(dx1w1_kernel<5>, dim3((unsigned)(S * G)), dim3(512), lds, st, m->Z, m->X1, m->WxT, m->r_obs, N, (int)G, S, rps, (int)A, L.SMAX, m->ws);
-        }
-        {
-            tsc::ProfScope ps(tsc::KID_DW1_GEMM, m->stream);
-            const long long tot = (long long)(L.SMAX + 1) * L.H * G;
-            hipLaunchKernelGGL(dx1w1_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m->ws, (int)G, S, L.H, L.SMAX,
-                               m->rowrange, g, L.stride, L.oW1, L.ob1);
-        }
         }
         TSC_HIP(hipGetLastError());
         m->cached_next = 0;

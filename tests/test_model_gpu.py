@@ -282,13 +282,11 @@ def test_forward_sample_equals_forward_then_sample():
 
 
 @pytest.mark.parametrize('agent,knob', [('ma2c', 'TSC_UNFUSED_DW'), ('ia2c', 'TSC_UNFUSED_DW'),
-                                        ('ma2c', 'TSC_UNFUSED_DX'), ('ia2c', 'TSC_UNFUSED_DX'),
-                                        ('ma2c', 'TSC_DX_V2'), ('ia2c', 'TSC_DX_V2'), ('ma2c', 'TSC_LSTM_BWD_V2')])
+                                        ('ma2c', 'TSC_UNFUSED_DX'), ('ia2c', 'TSC_UNFUSED_DX')])
 def test_fused_update_kernels_equal_grouped_gemms(agent, knob, monkeypatch):
-    """dwxh_kernel (dWx | dWh | dbl in one pass, whole tower output in accumulators) and dx1w1_kernel (dX1 kept in
-    registers, dW1 | db1 from the same pass) against the grouped GEMMs they replace, and the round-3 re-tilings
-    (dx1w1_kernel2, lstm_bwd2_kernel; knob = 0 selects the round-2 kernel) against the kernels they replace: same gradient
-    up to fp32 summation order, structural zeros of W1 exactly zero."""
+    """dwxh_kernel (dWx | dWh | dbl in one pass, whole tower output in accumulators) and dx1w1_kernel2 (dX1 kept in
+    registers, dW1 | db1 from the same pass, only the structurally non-zero feature tiles of W1) against the grouped GEMMs
+    they replace: same gradient up to fp32 summation order, structural zeros of W1 exactly zero."""
     E, T = 40, 9
     rng = np.random.RandomState(11)
     grads = []

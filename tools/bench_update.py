@@ -2,7 +2,7 @@
 """Time the A2C update's kernels alone (no simulator): fill one rollout of the benchmark shape through the fused forward
 (random observations, E env instances, T = n_step), then run compute_grads `--reps` times with HIP-event timing on.
     python tools/bench_update.py [--envs 1024] [--agent ma2c] [--reps 3]
-Environment knobs of the library (TSC_LSTM_BWD_V2, TSC_DX_V2, ...) select kernel variants for A/B runs."""
+Environment knobs of the library (TSC_UNFUSED_DW, TSC_UNFUSED_DX) select kernel variants for A/B runs."""
 import argparse
 import os
 import sys
