@@ -1994,7 +1994,7 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     if (const char *ev = getenv("TSC_DBG_THREAD")) m->dbg_tid = atoi(ev);
     m->xcd_map_on = 1;
     if (const char *ev = getenv("TSC_FWD_XCD")) m->xcd_map_on = atoi(ev);
-    m->fused_dw = !L.fc && (L.H == 224 || L.H == 160);
+    m->fused_dw = !L.fc && (L.H == 224 || L.H == 160 || L.H == 192 || L.H == 128);
     if (const char *ev = getenv("TSC_UNFUSED_DW")) if (atoi(ev)) m->fused_dw = 0;
     m->fused_dx = !L.fc && (L.H == 224 || L.H == 160 || L.H == 192 || L.H == 128) && L.SMAX <= 64 && L.SMAX % 4 == 0;
     if (const char *ev = getenv("TSC_UNFUSED_DX")) if (atoi(ev)) m->fused_dx = 0;
@@ -2006,12 +2006,14 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
         TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel2<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
     m->lds_ws = sizeof(float) * ((size_t)32 * (L.H + 64 + 4) + 64 * kWsLdx + (size_t)kL * kWsLdg + (size_t)kG4 * kWsLdg + 528 + (kWsBuf + 2) * 32 * kOut + (size_t)L.SMAX * L.H);
-    if (m->fused_fwd && (L.H == 224 || L.H == 160) && m->lds_ws <= 160 * 1024) {
+    if (m->fused_fwd && (L.H == 224 || L.H == 160 || L.H == 192 || L.H == 128) && m->lds_ws <= 160 * 1024) {
         // weight-stationary variant (TSC_FWD_WS=0 falls back to the tile-per-workgroup kernel)
         const char *ev = getenv("TSC_FWD_WS");
         if (!(ev && ev[0] == '0')) m->fused_fwd = 2;
         TSC_HIP(hipFuncSetAttribute((const void *)policy_fwd_ws_kernel<144>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_ws));
         TSC_HIP(hipFuncSetAttribute((const void *)policy_fwd_ws_kernel<112>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_ws));
+        TSC_HIP(hipFuncSetAttribute((const void *)policy_fwd_ws_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_ws));
+        TSC_HIP(hipFuncSetAttribute((const void *)policy_fwd_ws_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_ws));
     }
     if (m->fused_fwd)
         TSC_HIP(hipFuncSetAttribute((const void *)policy_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fused));
@@ -2143,7 +2145,7 @@ static int model_forward(tsc_model *m, const float *obs, const uint8_t *done, fl
 #define TSC_WS(KS2) hipLaunchKernelGGL(policy_fwd_ws_kernel<KS2>, dim3(nwg), dim3(512), m->lds_ws, m->stream, m->params, \
                                        L, m->n_act, obs, done, m->state_fw, (int)advance, E, S, pi, v, action, (unsigned long long)seed,     \
                                        (unsigned long long)step, (int)tslot, (long long)m->T * E, m->X1, m->Z, m->Hh, m->Cc, m->Hp, m->dbg, m->Wg, m->krange, m->dbg_tid, wgm)
-            if (L.H == 224) TSC_WS(144); else TSC_WS(112);
+            if (L.H == 224) TSC_WS(144); else if (L.H == 160) TSC_WS(112); else if (L.H == 192) TSC_WS(128); else TSC_WS(96);
 #undef TSC_WS
             ps.stop();
             TSC_HIP(hipGetLastError());
@@ -2324,8 +2326,9 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
         rps += rps & 1;                           // a k-step is two rows
         {
             tsc::ProfScope ps(tsc::KID_DWX_GEMM, m->stream);
-            if (NT == 9) hipLaunchKernelGGL(dwxh_kernel<9>, dim3((unsigned)(S * G)), dim3(512), 0, st, m->X1, m->Hp, m->Z, N, (int)G, S, rps, m->ws);
-            else hipLaunchKernelGGL(dwxh_kernel<7>, dim3((unsigned)(S * G)), dim3(512), 0, st, m->X1, m->Hp, m->Z, N, (int)G, S, rps, m->ws);
+#define TSC_DWXH(NT_) hipLaunchKernelGGL(dwxh_kernel<NT_>, dim3((unsigned)(S * G)), dim3(512), 0, st, m->X1, m->Hp, m->Z, N, (int)G, S, rps, m->ws)
+            if (NT == 9) TSC_DWXH(9); else if (NT == 7) TSC_DWXH(7); else if (NT == 8) TSC_DWXH(8); else TSC_DWXH(6);
+#undef TSC_DWXH
         }
         {
             tsc::ProfScope ps(tsc::KID_DWH_GEMM, m->stream);

@@ -380,7 +380,7 @@ def _read_cache(m, what, g, row0, nrows, width):
     ('large_grid', 'ma2c', 200, '1'),       # ragged last tile (200 = 6 x 32 + 8)
     ('large_grid', 'ia2c', 1024, '1'),      # H = 160 instantiation
     ('large_grid', 'ma2c', 200, '0'),       # TSC_FWD_WS=0: policy_fwd_fused_kernel, ragged 64-instance tile
-    ('real_net', 'ma2c', 200, '1'),         # Monaco: H = 192 -> policy_fwd_fused_kernel, n_a 2..6, no wait state
+    ('real_net', 'ma2c', 200, '1'),         # Monaco: H = 192 -> policy_fwd_ws_kernel<128>, n_a 2..6, no wait state
     ('real_net', 'ia2c', 96, '1'),
 ])
 def test_forward_sample_multi_tile_vs_oracle(scenario, agent, E, ws, monkeypatch):
