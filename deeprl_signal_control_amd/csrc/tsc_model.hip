@@ -629,7 +629,8 @@ __device__ __forceinline__ int sample_action(const float *pi, int na, unsigned l
 // and an activation is read from LDS once per four / eight multiply-adds.  The stateless policy needs no activation
 // cache: its update re-evaluates the forward at training shape.  51 us per launch at E = 256 (round 2's four launches per
 // control step -- two grouped GEMMs, heads, sampling -- took 85 us); the 100 workgroups are a latency chain each (quad LDS
-// reads with all 16 units per pass measured slower: 57 us), an MFMA formulation is the next step for this configuration.
+// reads with all 16 units per pass measured slower: 57 us).  Since the MFMA formulation below (22.7 us) this kernel serves first
+// layers that are not a multiple of 32 columns wide, and TSC_FC_MFMA=0.
 // ------------------------------------------------------------------------------------------------
 constexpr int kFcLdo = 64 + 1;
 __global__ void __launch_bounds__(512) policy_fwd_fc_kernel(const float *__restrict__ params, Layout lay, const int *__restrict__ n_act,
@@ -715,6 +716,110 @@ __global__ void __launch_bounds__(512) policy_fwd_fc_kernel(const float *__restr
         if (action_out) action_out[idx] = sample_action(pi, na, seed, step, idx);
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// The same forward on the matrix cores (round 3).  policy_fwd_fc_kernel above is a latency chain of ~2 x 10^4 dependent
+// multiply-adds per thread: 51 us per launch whatever E is.  Here one workgroup takes (agent, 32 instances, both
+// towers): layer 1 is 2 H/32 column tiles of [32 x SMAX] x [SMAX x 32] (v_mfma_f32_32x32x2_f32, SMAX / 2 steps each,
+// obs k-major in LDS, W1 straight from L2 into the B operand), layer 2 is 4 column tiles of [32 x H] x [H x 32] with
+// the contraction cut in two halves (eight waves, H / 4 dependent MFMAs each; the halves meet in LDS).  Every weight a
+// wave needs is requested before the first barrier, so the launch costs two L2 round trips plus ~4k cycles of MFMA chains.
+// ------------------------------------------------------------------------------------------------
+constexpr int kFmLd = 33;        // [k or row][32 instances / columns + 1]
+
+template <int NCT>               // H / 32
+__global__ void __launch_bounds__(512, 1)
+policy_fwd_fc_mfma_kernel(const float *__restrict__ params, Layout lay, const int *__restrict__ n_act,
+                          const float *__restrict__ obs, int E, float *__restrict__ pi_out, float *__restrict__ v_out,
+                          int *action_out, unsigned long long seed, unsigned long long step) {
+    constexpr int H = 32 * NCT, LDX = H + 1, NS2 = H / 4, NU = 2 * NCT;
+    static_assert(NU <= 16, "two layer-1 units per wave at most");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *Os = (float *)smem_raw;                      // [64 k][kFmLd]: obs tile, k-major
+    float *X1s = Os + 64 * kFmLd;                       // [2 towers][32][LDX]
+    float *P2 = X1s + 2 * 32 * LDX;                     // [8 waves][32][kFmLd]: layer-2 partial tiles (one K half each)
+    float *X2s = P2 + 8 * 32 * kFmLd;                   // [2 towers][32][kFcLdo]
+    const int a = blockIdx.y, e0 = blockIdx.x * 32, tid = threadIdx.x, lane = tid & 63, li = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int SMAX = lay.SMAX, KS1 = (SMAX + 1) >> 1;
+    const float *Pa = params + (long long)(2 * a) * lay.stride;
+    // ---- every global operand is requested up front
+    // layer 2: wave -> (tower, column tile, K half); B[k][n] = W2[k][32 ct + n]
+    const int t2 = wave >> 2, ct2 = (wave >> 1) & 1, kh2 = wave & 1;
+    float w2[NS2];
+    {
+        const float *W2 = Pa + (long long)t2 * lay.stride + lay.oWx + (long long)(kh2 * (H / 2) + kh) * kL + 32 * ct2 + li;
+#pragma unroll
+        for (int s = 0; s < NS2; ++s) w2[s] = W2[(long long)(2 * s) * kL];
+    }
+    // layer 1: unit u = tower * NCT + column tile; wave w owns units w and w + 8
+    float w1[2][32], b1v[2];
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+        const int u = wave + 8 * uu < NU ? wave + 8 * uu : NU - 1;
+        const float *P = Pa + (long long)(u / NCT) * lay.stride;
+        const int col = 32 * (u % NCT) + li;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const int k = 2 * s + kh < SMAX ? 2 * s + kh : SMAX - 1;
+            w1[uu][s] = P[lay.oW1 + (long long)k * H + col];
+        }
+        b1v[uu] = P[lay.ob1 + col];
+    }
+    for (int i = tid; i < 32 * SMAX; i += 512) {
+        const int r = i / SMAX, c = i % SMAX;
+        const int er = e0 + r < E ? e0 + r : E - 1;
+        Os[c * kFmLd + r] = obs[((long long)er * lay.A + a) * SMAX + c];
+    }
+    if (SMAX & 1) { if (tid < 32) Os[SMAX * kFmLd + tid] = 0.f; }      // the odd last step multiplies a zero row
+    __syncthreads();
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+        const int u = wave + 8 * uu;
+        if (u < NU) {                                                   // wave-uniform
+            const int tower = u / NCT, ct = u % NCT;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 32; ++s)
+                if (s < KS1) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[(2 * s + kh) * kFmLd + li], w1[uu][s], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                X1s[(tower * 32 + row) * LDX + 32 * ct + li] = fmaxf(acc[r] + b1v[uu], 0.f);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float *xr = X1s + (t2 * 32 + li) * LDX + kh2 * (H / 2) + kh;
+#pragma unroll
+        for (int s = 0; s < NS2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[2 * s], w2[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) P2[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * kFmLd + li] = acc[r];
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * 32 * kL; i += 512) {                      // the two K halves + bias, relu
+        const int t = i >> 11, row = (i >> 6) & 31, j = i & 63, w0 = t * 4 + (j >> 5) * 2, c = j & 31;
+        const float v = (P2[(w0 * 32 + row) * kFmLd + c] + P2[((w0 + 1) * 32 + row) * kFmLd + c]) + Pa[(long long)t * lay.stride + lay.obl + j];
+        X2s[(t * 32 + row) * kFcLdo + j] = fmaxf(v, 0.f);
+    }
+    __syncthreads();
+    if (tid < 32 && e0 + tid < E) {                     // heads + sampling, one instance per thread
+        float pi[kOut], v;
+        const int na = n_act[a];
+        head_eval(params, lay, a, na, X2s + tid * kFcLdo, X2s + (32 + tid) * kFcLdo, pi, v);
+        const long long idx = (long long)(e0 + tid) * lay.A + a;
+        for (int k = 0; k < lay.AMAX; ++k) pi_out[idx * lay.AMAX + k] = k < kOut ? pi[k] : 0.f;
+        v_out[idx] = v;
+        if (action_out) action_out[idx] = sample_action(pi, na, seed, step, idx);
+    }
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // Fused rollout forward (one control step, IA2C.forward agents/models.py:185-200): for one agent-tower
@@ -1855,6 +1960,7 @@ struct tsc_model {
     size_t lds_fwd, lds_fused, lds_ws;
     int fused_fwd;
     int fused_dw;               // dWx | dWh | dbl in one pass (dwxh_kernel)
+    int fc_mfma;                // FcACPolicy rollout forward on the matrix cores (TSC_FC_MFMA=0: the per-thread kernel)
     int fused_dx;               // dX1 in registers, dW1 | db1 in the same pass (dx1w1_kernel2)
     int inplace;                // the running rollout is written straight into the buffer's slots (tsc_model_rollout_slot): slot T -> 0 carry
     int cached_next;            // next rollout slot whose activations the fused forward will cache; T = all cached
@@ -1992,6 +2098,8 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     m->lds_fused = sizeof(float) * ((size_t)(L.H + 64) * kXLd + kL * kOut + kOut + 8);   // activations + head weights
     m->fused_fwd = !L.fc && (L.H % 32 == 0) && (L.SMAX <= 64) && (L.SMAX % 4 == 0) && ((L.H + 64) % 8 == 0) && m->lds_fused <= 160 * 1024;
     if (const char *ev = getenv("TSC_DBG_THREAD")) m->dbg_tid = atoi(ev);
+    m->fc_mfma = 1;
+    if (const char *ev = getenv("TSC_FC_MFMA")) m->fc_mfma = atoi(ev);
     m->xcd_map_on = 1;
     if (const char *ev = getenv("TSC_FWD_XCD")) m->xcd_map_on = atoi(ev);
     m->fused_dw = !L.fc && (L.H == 224 || L.H == 160 || L.H == 192 || L.H == 128);
@@ -2155,6 +2263,23 @@ static int model_forward(tsc_model *m, const float *obs, const uint8_t *done, fl
                            L, m->n_act, obs, done, m->state_fw, (int)advance, E, n_tiles, pi, v, action,
                            (unsigned long long)seed, (unsigned long long)step, m->dbg, (int)tslot, (long long)m->T * E,
                            m->X1, m->Z, m->Hh, m->Cc, m->Hp, m->Wg);
+        ps.stop();
+        TSC_HIP(hipGetLastError());
+        return 0;
+    }
+    if (L.fc && (L.H == 160 || L.H == 128) && L.SMAX <= 64 && L.AMAX <= kOut && m->fc_mfma) {   // FcACPolicy (IA2C: large_grid / Monaco) on the matrix cores
+        const size_t lds = sizeof(float) * ((size_t)64 * kFmLd + (size_t)2 * 32 * (L.H + 1) + (size_t)8 * 32 * kFmLd + (size_t)2 * 32 * kFcLdo);
+        static bool attr_set2 = false;
+        if (!attr_set2) {
+            TSC_HIP(hipFuncSetAttribute((const void *)policy_fwd_fc_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            TSC_HIP(hipFuncSetAttribute((const void *)policy_fwd_fc_mfma_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set2 = true;
+        }
+        tsc::ProfScope ps(tsc::KID_FUSED_FWD, m->stream);
+#define TSC_FCM(NCT) hipLaunchKernelGGL(policy_fwd_fc_mfma_kernel<NCT>, dim3((unsigned)((E + 31) / 32), (unsigned)L.A), dim3(512), lds, m->stream, m->params, L, \
+                                        m->n_act, obs, E, pi, v, action, (unsigned long long)seed, (unsigned long long)step)
+        if (L.H == 128) TSC_FCM(4); else TSC_FCM(5);
+#undef TSC_FCM
         ps.stop();
         TSC_HIP(hipGetLastError());
         return 0;

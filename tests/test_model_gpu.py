@@ -151,6 +151,37 @@ def test_forward_matches_oracle(agent, E, policy):
     m.close()
 
 
+@pytest.mark.parametrize('scenario,agent,E,mfma', [('large_grid', 'ia2c', 256, '1'), ('large_grid', 'ia2c', 45, '0'),
+                                                   ('real_net', 'ia2c', 70, '1'), ('real_net', 'ia2c', 33, '0')])
+def test_fc_policy_forward_kernels(scenario, agent, E, mfma, monkeypatch):
+    """FcACPolicy rollout forward (agents/policies.py:214-240; IA2C only: the reference has no working fingerprint variant): the
+    MFMA kernel (policy_fwd_fc_mfma_kernel, first layers of 160 / 128 columns = large_grid / Monaco, heterogeneous n_a on
+    Monaco, ragged last tile) and the per-thread kernel (TSC_FC_MFMA=0) against the float64 oracle: pi, v, sampled action."""
+    from oracle.nets_oracle import choice_from_uniform, sample_uniform
+    monkeypatch.setenv('TSC_FC_MFMA', mfma)
+    scn, m, o = _make(agent, E, 4, policy='fc', scenario=scenario, seed=3)
+    rng = np.random.RandomState(5)
+    m.reset(); o.reset()
+    flips = 0
+    for t in range(3):
+        obs = _rand_obs(scn, E, rng)
+        step = m.sample_step
+        pi, v, act = m.forward_sample(torch.from_numpy(obs).cuda(), False, cache=False)
+        pi, v, act = pi.cpu().numpy(), v.cpu().numpy(), act.cpu().numpy()
+        opi, ov = o.forward(obs, np.zeros(E), 'pv')
+        for a in range(scn.n_agent):
+            na = scn.n_a_ls[a]
+            np.testing.assert_allclose(pi[:, a, :na], opi[a], atol=2e-5, err_msg='pi t=%d a=%d' % (t, a))
+            assert np.all(pi[:, a, na:] == 0)
+        np.testing.assert_allclose(v, ov, atol=2e-5)
+        for e in range(E):
+            for a in range(scn.n_agent):
+                u = sample_uniform(m.sample_seed, step, e * scn.n_agent + a)
+                flips += int(act[e, a] != choice_from_uniform(pi[e, a, :scn.n_a_ls[a]], u))
+    assert flips == 0                      # the action is np.random.choice on the kernel's own pi and the documented uniform
+    m.close()
+
+
 def test_sampling_is_numpy_choice_on_documented_uniform():
     from oracle.nets_oracle import choice_from_uniform, sample_uniform
     scn, m, o = _make('ma2c', 16, 4, seed=11)
