@@ -195,8 +195,8 @@ def extra_lines(env, model, scn, n_ctrl=240):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=None, help='timed iterations (default 6; 20 for the short iterations of c2 / c5)')
-    ap.add_argument('--warmup', type=int, default=None, help='untimed iterations before (default 2; 10 for c2 / c5)')
+    ap.add_argument('--steps', type=int, default=None, help='timed iterations (default 10; 20 for the short iterations of c2 / c5)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed iterations before (default 4; 10 for c2 / c5)')
     ap.add_argument('--envs', type=int, default=1024, help='env instances per GPU')
     ap.add_argument('--agent', default='ma2c', choices=['ma2c', 'ia2c'])
     ap.add_argument('--scenario', default='large_grid', choices=['large_grid', 'real_net'])
@@ -218,9 +218,9 @@ def main():
     # an iteration of c2 / c5 is 9-13 ms: two of them do not bring a cold device up to its clocks, six are 60 ms of timed region
     short = args.config in ('c2', 'c5')
     if args.steps is None:
-        args.steps = 20 if short else 6
+        args.steps = 20 if short else 10
     if args.warmup is None:
-        args.warmup = 10 if short else 2
+        args.warmup = 10 if short else 4
     if args.config == 'c2':
         args.scenario, args.agent, args.policy, args.envs = 'large_grid', 'ia2c', 'fc', 256
     elif args.config == 'c3':

@@ -1320,7 +1320,7 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
             const float4 c4n = make_float4(cn[0], cn[1], cn[2], cn[3]), h4n = make_float4(hn[0], hn[1], hn[2], hn[3]);
             if (advance) {
                 float *st = stb + (long long)e0c * 2 * kL;
-                *reinterpret_cast<float4 *>(st + st_lane) = c4n; *reinterpret_cast<float4 *>(st + (st_lane + kL)) = h4n;
+                st_stream4(st + st_lane, c4n); st_stream4(st + (st_lane + kL), h4n);
             }
             if (tslot >= 0) {                                  // what lstm_fwd_kernel<true> would store
                 float *zr = Zc + nbc * kG4;
