@@ -15,13 +15,15 @@
 // RMSProp accumulator use the same layout, so the gradient buffer is one contiguous RCCL
 // all-reduce.  The three input FCs (wave / fingerprint / wait) are one block-diagonal
 // [SMAX x H] matrix with structural zeros (kept zero by a row-range mask on its gradient).
-// Kernels (all fp32, v_mfma_f32_32x32x2_f32 for every contraction):
+// Kernels (all fp32, v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 for every contraction):
 //   rollout ......... policy_fwd_ws_kernel: one launch per control step, [Wx ; Wh] stationary in registers, tiles
-//                     software-pipelined over two barrier intervals, also fills the activation cache the update reads (policy_fwd_fused_kernel: tile-per-workgroup
-//                     variant; grouped GEMMs + lstm_fwd + head_fwd: training-shape re-forward / FC policy)
-//   update .......... head_bwd2 (persistent, loss gradient + dH + dWo | dbo) -> lstm_bwd (Wh^T stationary in registers, dc/dh in registers over the n_step
-//                     time steps) -> dwxh (dWx | dWh | dbl, whole tower output in accumulators) -> dx1w1 (dX1 in
-//                     registers, chained into dW1 | db1) -> grad_norm -> rmsprop; the FC-policy path on the grouped
+//                     software-pipelined over two barrier intervals, also fills the activation cache the update reads
+//                     (policy_fwd_fused_kernel: tile-per-workgroup variant; policy_fwd_fc_mfma_kernel: FcACPolicy;
+//                     grouped GEMMs + lstm_fwd + head_fwd: training-shape re-forward)
+//   update .......... head_bwd2 (persistent, loss gradient + dH + dWo | dbo) -> lstm_bwd2 (Wh^T stationary in registers,
+//                     dc in registers / dh through LDS over the n_step time steps, next step's inputs in flight under the
+//                     MFMAs) -> dwxh (dWx | dWh | dbl, whole tower output in accumulators) -> dx1w1_kernel2 (dX1 in
+//                     registers, chained into dW1 | db1) -> grad_norm -> rmsprop; the FC-policy update on the grouped
 //                     split-K GEMM (tsc_gemm.h)
 #include "tsc_common.h"
 #include "tsc_gemm.h"
