@@ -32,7 +32,8 @@
 
 namespace {
 
-constexpr float kLen = 5.0f, kS0 = 2.5f, kAcc = 5.0f, kDec = 10.0f, kTHead = 1.0f;   // headway = SUMO's default tau
+constexpr float kLen = 5.0f, kS0 = 2.0f /* standstill gap (SUMO minGap 2.5 less the storage of its junction interiors) */,
+                kAcc = 5.0f, kDec = 10.0f, kTHead = 1.0f;   // headway = SUMO's default tau
 constexpr float kICab = 0.070710678f /* 1 / (2 sqrt(acc dec)): a multiply instead of an IEEE division */, kHalt = 0.1f, kYieldT = 3.0f, kYieldD = 10.0f;
 constexpr int kCap = TSC_LANE_CAP, kMaxCross = TSC_MAX_CROSS, kMaxUp = TSC_MAX_UP;
 

@@ -32,8 +32,9 @@ import numpy as np
 VEH_LEN = 5.0        # vType length=5            (build_file.py:279)
 VEH_ACCEL = 5.0      # vType accel=5
 VEH_DECEL = 10.0     # vType decel=10
-MIN_GAP = 2.5        # SUMO default minGap (not in the reference tree)
-LANE_CAP = 28        # vehicle slots per lane: 200 m / 7.5 m = 26.7 -> 27 (+1)
+MIN_GAP = 2.5        # SUMO default minGap (not in the reference tree): sizes lane pieces and contracted chains
+STAND_GAP = 2.0      # standstill gap of the microsim spec (csrc/tsc_env.hip kS0)
+LANE_CAP = 28        # vehicle slots per lane: 200 m / 7.5 m = 26.7 -> 27 (+1); hand-offs stop at LANE_CAP - MAX_CROSS
 MAX_CROSS = 4        # vehicles that may leave one lane in one sim-step
 MAX_UP = 4           # upstream feeder lanes per lane
 DET_LEN = 50.0       # lane-area detector covers the last 50 m
@@ -133,7 +134,7 @@ class Scenario:
     def check_limits(self):
         """The fixed capacities of csrc/tsc_env.hip (include/tsc.h TSC_LANE_CAP / TSC_MAX_UP / TSC_MAX_CROSS): a scenario that
         does not fit is refused here with the remedy, not truncated on the device."""
-        veh = VEH_LEN + MIN_GAP
+        veh = VEH_LEN + MIN_GAP          # sizing rule; hand-offs into a lane stop at LANE_CAP - MAX_CROSS vehicles whatever its length
         long_ = [self.lane_names[l] for l in range(self.n_lane) if int(self.lane_len[l] // veh) > LANE_CAP]
         if long_:
             raise ValueError('lanes %s hold more than %d standing vehicles (%.1f m each): split them into pieces of at most %.0f m '

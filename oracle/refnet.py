@@ -97,7 +97,7 @@ def fixture_model_cfg(fx):
     elif str(fx['agent']) == 'ia2c':
         cfg['reward_norm'] = 3000.0
     if str(fx['agent']) == 'ia2c' and str(fx['policy']) == 'lstm':
-        cfg.update(max_grad_norm=1.8, lr_decay='linear', lr_min=1e-4, entropy_decay='linear', entropy_coef_min=0.002, entropy_ratio=1.0)
+        cfg.update(max_grad_norm=2.1, lr_decay='linear', lr_min=1e-4, entropy_decay='linear', entropy_coef_min=0.002, entropy_ratio=1.0)
     return cfg
 
 

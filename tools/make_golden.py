@@ -377,14 +377,14 @@ def refnet_fixtures():
     Trainer.run of utils.py, unmodified, over oracle/fake_tf.py) on the reference's env classes (over oracle/fake_traci.py),
     one shortened training episode per configuration -- see oracle/refnet.py for what is recorded.
       refnet_ma2c_large ..... config_ma2c_large.ini, 2 x 120 steps (FPLstmACPolicy, 25 agents; bootstrap 'v' call, terminal R = 0)
-      refnet_ia2c_large ..... config_ia2c_large.ini, 240 steps = 2 updates, max_grad_norm 1.8 so that clip_by_global_norm bites,
+      refnet_ia2c_large ..... config_ia2c_large.ini, 240 steps = 2 updates, max_grad_norm 2.1 so that clip_by_global_norm bites,
                               linear lr / entropy-coefficient schedules (agents/models.py:53-69: the LR_MIN / ENTROPY_COEF_MIN getters)
       refnet_fc_large ....... the same with the reference's FcACPolicy swapped in (BASELINE configs[1])
       refnet_ma2c_real ...... config_ma2c_real.ini, 3 x 40 steps (28 agents, 2..6 actions, no wait inputs)"""
     from oracle import refnet
     for name, kw in (('refnet_ma2c_large', dict(scenario='large_grid', agent='ma2c', seed_w=101, episode_sec=1200, full_agents=(3,))),
                      ('refnet_ia2c_large', dict(scenario='large_grid', agent='ia2c', seed_w=102, episode_sec=1200,
-                                                model_over=dict(max_grad_norm=1.8, lr_decay='linear', lr_min=1e-4, entropy_decay='linear',
+                                                model_over=dict(max_grad_norm=2.1, lr_decay='linear', lr_min=1e-4, entropy_decay='linear',
                                                                 entropy_coef_min=0.002, entropy_ratio=1.0))),
                      ('refnet_fc_large', dict(scenario='large_grid', agent='ia2c', seed_w=103, episode_sec=600, policy='fc')),
                      ('refnet_ma2c_real', dict(scenario='real_net', agent='ma2c', seed_w=104, episode_sec=600))):
