@@ -17,8 +17,11 @@ The timed region carries no profiling; a second pass of the same loop, HIP event
 stream, gives the per-kernel table.  `--config c2 | c3 | c5` select BASELINE.json configs[1], [2] (default), [4].
 
 Adds `roofline` (dominant kernel, timed live with HIP events on the launch stream) and
-`cpu_baseline` (the CPU oracle -- C microsim + NumPy env wrapper + torch-CPU nets -- on a bounded
-sample of the same workload, rank 0, N = 1 only).
+`cpu_baseline` (the CPU oracle -- C microsim + NumPy env wrapper + torch-CPU nets, float32 like the reference and float64
+like the checker -- on a bounded sample of the same workload, rank 0, N = 1 only; it also quotes the committed timing of the
+reference's own env class over the fake TraCI backend, which exists in the build container only).  The plain driver
+line (`python bench.py`, N = 1) also carries short runs of the other single-GPU configurations, BASELINE.json configs[1]
+(c2) and configs[4]'s per-GPU share (c5), under `extra.configs`.
 """
 import argparse
 import json
@@ -38,17 +41,30 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 
 
 def pmc_traffic(kernel, default_workload=True):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc summary (profiles/r03_pmc.json: separate
-    FETCH_SIZE / WRITE_SIZE passes, KB units; the gfx950 x2 FETCH correction only applies to 16 B/lane streams and
-    is NOT applied to these dword-per-lane kernels) or None."""
+    """(HBM bytes per launch of `kernel`, source) from the newest committed rocprofv3 --pmc summary (profiles/rNN_pmc.json:
+    separate FETCH_SIZE / WRITE_SIZE passes, KB units; the gfx950 x2 FETCH correction only applies to 16 B/lane streams and
+    is NOT applied to these dword-per-lane kernels) or (None, None).  It is a COMMITTED measurement of an earlier run of this
+    very command (one iteration from reset: fewer vehicles than the timed window), not a counter read in this run -- the
+    JSON line says so in `traffic_source`."""
     if not default_workload:            # the committed counters were collected on the default workload (configs[2]) only
-        return None
-    try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'r03_pmc.json')))
-        k = d['kernels'][kernel]
-        return (k['fetch_kb'] + k['write_kb']) * 1024.0
-    except Exception:
-        return None
+        return None, None
+    for tag in ('r04', 'r03'):
+        try:
+            d = json.load(open(os.path.join(ROOT, 'profiles', '%s_pmc.json' % tag)))
+            k = d['kernels'][kernel]
+            return (k['fetch_kb'] + k['write_kb']) * 1024.0, ('profiles/%s_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of '
+                                                             'one iteration from reset, mean live vehicles ~300 per instance): committed '
+                                                             'measurement, not collected in this run' % tag)
+        except Exception:
+            continue
+    return None, None
+
+
+def fused_update_kernels(model):
+    """Which kernels the update of this model runs (mirrors tsc_model_create, csrc/tsc_model.hip): the one-pass kernels
+    ('dwx_gemm' = dWx | dWh | dbl, 'dx1_gemm' = dX1 in registers + dW1 | db1 -- for the FcACPolicy also dWfc | dbfc) or the
+    generic grouped GEMMs the profile ids are named after."""
+    return model.H in (224, 160, 192, 128) and model.s_max <= 64 and model.s_max % 4 == 0
 
 
 def algorithmic_flops(model, rows):
@@ -58,8 +74,12 @@ def algorithmic_flops(model, rows):
     fc = sum(2 * (nw * fw + nf * fp + nt * ft) for nw, nf, nt in zip(model.n_wave_ls, model.n_f_ls, model.n_w_ls)) * 2
     H, L, G = model.H, model.Lh, model.G
     out = sum(2 * L * (na + 1) for na in model.n_a_ls)
+    fused_update = fused_update_kernels(model)
     if model.policy == 'fc':            # FcACPolicy: the second layer is fc(H -> L), no recurrence (agents/policies.py:227-235)
         z = G * 2 * H * L
+        if fused_update:                # fc_bwd_kernel ('dx1_gemm'): dX1 in registers -> dW1 | db1, and dWfc | dbfc, in one pass
+            return {'policy_fwd_fused': (fc + z + out) * rows, 'fc_gemm': fc * rows, 'zx_gemm': z * rows, 'lstm_fwd': 0.0, 'lstm_bwd': 0.0,
+                    'dwx_gemm': 0.0, 'dwh_gemm': 0.0, 'dx1_gemm': (2 * z + fc) * rows, 'dw1_gemm': 0.0, 'dwo_gemm': 0.0}
         return {'policy_fwd_fused': (fc + z + out) * rows, 'fc_gemm': fc * rows, 'zx_gemm': z * rows, 'lstm_fwd': 0.0, 'lstm_bwd': 0.0,
                 'dwx_gemm': z * rows, 'dwh_gemm': 0.0, 'dx1_gemm': z * rows, 'dw1_gemm': fc * rows, 'dwo_gemm': 0.0}
     fused = fc + G * 2 * H * 4 * L + G * 2 * L * 4 * L + out           # one rollout forward of every tower
@@ -68,7 +88,6 @@ def algorithmic_flops(model, rows):
     # 'dwh_gemm' / 'dw1_gemm' are then only their split reductions
     dwx = G * 2 * H * 4 * L * rows
     dwh = G * 2 * L * 4 * L * rows
-    fused_update = model.policy == 'lstm' and H in (160, 224)
     return {'policy_fwd_fused': fused * rows, 'fc_gemm': fc * rows, 'zx_gemm': G * 2 * H * 4 * L * rows,
             'lstm_fwd': G * 2 * L * 4 * L * rows, 'lstm_bwd': G * 2 * L * 4 * L * rows,
             'dwx_gemm': dwx + dwh if fused_update else dwx, 'dwh_gemm': 0.0 if fused_update else dwh,
@@ -79,33 +98,34 @@ def algorithmic_flops(model, rows):
 def cpu_baseline(n_env=48, n_step=120, threads=8):
     """Same iteration on the host: oracle/ (test infrastructure) = C microsim + NumPy restatement of
     envs/env.py + torch-CPU restatement of agents/policies.py.  Bounded sample: n_env env instances,
-    one iteration (n_step control steps + update)."""
-    from deeprl_signal_control_amd.agents import VecA2C  # noqa: F401  (layout helper only)
+    one iteration (n_step control steps + update), run twice: with float32 nets (the reference's TensorFlow arithmetic:
+    `value`) and with the float64 nets the parity tests use as the checker (`value_float64_nets`).  SURVEY 8(d) baseline (i)
+    -- the reference's OWN env class over the fake TraCI backend, which only exists in the build container -- is quoted
+    from the committed profiles/r04_oracle_a.json (tools/time_oracle_a.py)."""
     from deeprl_signal_control_amd.scenario import build_large_grid
     from oracle.env_oracle import OracleEnv
+    import oracle.nets_oracle as nets
     from oracle.nets_oracle import OracleA2C, choice_from_uniform
     from deeprl_signal_control_amd.agents import ortho_init
     torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))   # 128 threads on 64-wide matmuls is slower than 8
     scn = build_large_grid('ma2c')
-    rng = np.random.RandomState(0)
     nw = [s - w - f for s, w, f in zip(scn.n_s_ls, scn.n_w_ls, scn.n_f_ls)]
-    towers = []
-    for a in range(scn.n_agent):
-        for tower in ('pi', 'v'):
-            p = {'fcw_w': ortho_init((nw[a], 128), rng), 'fcw_b': np.zeros(128, np.float32),
-                 'fcf_w': ortho_init((scn.n_f_ls[a], 64), rng), 'fcf_b': np.zeros(64, np.float32),
-                 'fct_w': ortho_init((scn.n_w_ls[a], 32), rng), 'fct_b': np.zeros(32, np.float32),
-                 'lstm_wx': ortho_init((224, 256), rng), 'lstm_wh': ortho_init((64, 256), rng),
-                 'lstm_b': np.zeros(256, np.float32)}
-            n_out = scn.n_a_ls[a] if tower == 'pi' else 1
-            p['out_w'] = ortho_init((64, n_out), rng); p['out_b'] = np.zeros(n_out, np.float32)
-            towers.append(p)
-    envs = [OracleEnv(scn, seed=12 + e) for e in range(n_env)]
-    model = OracleA2C(towers, nw, scn.n_w_ls, scn.n_f_ls, scn.n_a_ls, n_env)
-    t0 = time.perf_counter()
-    obs = [e.reset() for e in envs]
-    done = np.ones(n_env)
     S = scn.s_max
+
+    def towers():
+        rng = np.random.RandomState(0)
+        tw = []
+        for a in range(scn.n_agent):
+            for tower in ('pi', 'v'):
+                p = {'fcw_w': ortho_init((nw[a], 128), rng), 'fcw_b': np.zeros(128, np.float32),
+                     'fcf_w': ortho_init((scn.n_f_ls[a], 64), rng), 'fcf_b': np.zeros(64, np.float32),
+                     'fct_w': ortho_init((scn.n_w_ls[a], 32), rng), 'fct_b': np.zeros(32, np.float32),
+                     'lstm_wx': ortho_init((224, 256), rng), 'lstm_wh': ortho_init((64, 256), rng),
+                     'lstm_b': np.zeros(256, np.float32)}
+                n_out = scn.n_a_ls[a] if tower == 'pi' else 1
+                p['out_w'] = ortho_init((64, n_out), rng); p['out_b'] = np.zeros(n_out, np.float32)
+                tw.append(p)
+        return tw
 
     def pack(obs):
         o = np.zeros((n_env, scn.n_agent, S))
@@ -113,23 +133,38 @@ def cpu_baseline(n_env=48, n_step=120, threads=8):
             for a in range(scn.n_agent):
                 o[e, a, :len(obs[e][a])] = obs[e][a]
         return o
-    for t in range(n_step):
-        ob = pack(obs)
-        pis, v = model.forward(ob, done, 'pv')
-        acts = np.zeros((n_env, scn.n_agent), np.int64)
-        rew = np.zeros((n_env, scn.n_agent))
-        dpost = np.zeros(n_env)
-        for e in range(n_env):
-            envs[e].update_fingerprint([pis[a][e] for a in range(scn.n_agent)])
-            acts[e] = [choice_from_uniform(pis[a][e], rng.rand()) for a in range(scn.n_agent)]
-            obs[e], r, d, _ = envs[e].step(list(acts[e]))
-            rew[e], dpost[e] = r, d
-        model.add_transition(ob, done, acts, rew, v, dpost)
-        done = dpost
-    _, R = model.forward(pack(obs), np.zeros(n_env), 'v')
-    grads, _ = model.compute_grads(R, 0.01)
-    model.apply_grads(grads, 5e-4)
-    dt = time.perf_counter() - t0
+
+    def iteration(dtype):
+        saved = nets.DT
+        nets.DT = dtype                       # the restatement's working precision (module-level; restored below)
+        try:
+            rng = np.random.RandomState(0)
+            envs = [OracleEnv(scn, seed=12 + e) for e in range(n_env)]
+            model = OracleA2C(towers(), nw, scn.n_w_ls, scn.n_f_ls, scn.n_a_ls, n_env)
+            t0 = time.perf_counter()
+            obs = [e.reset() for e in envs]
+            done = np.ones(n_env)
+            for t in range(n_step):
+                ob = pack(obs)
+                pis, v = model.forward(ob, done, 'pv')
+                acts = np.zeros((n_env, scn.n_agent), np.int64)
+                rew = np.zeros((n_env, scn.n_agent))
+                dpost = np.zeros(n_env)
+                for e in range(n_env):
+                    envs[e].update_fingerprint([pis[a][e] for a in range(scn.n_agent)])
+                    acts[e] = [choice_from_uniform(pis[a][e], rng.rand()) for a in range(scn.n_agent)]
+                    obs[e], r, d, _ = envs[e].step(list(acts[e]))
+                    rew[e], dpost[e] = r, d
+                model.add_transition(ob, done, acts, rew, v, dpost)
+                done = dpost
+            _, R = model.forward(pack(obs), np.zeros(n_env), 'v')
+            grads, _ = model.compute_grads(R, 0.01)
+            model.apply_grads(grads, 5e-4)
+            return time.perf_counter() - t0
+        finally:
+            nets.DT = saved
+    dt32 = iteration(torch.float32)
+    dt64 = iteration(torch.float64)
     steps = scn.n_agent * n_env * n_step * scn.control_interval_sec
     # for scale: the C microsim alone (no env wrapper, no nets), one instance, one core, one full episode
     from oracle.microsim import MicroSim
@@ -141,11 +176,22 @@ def cpu_baseline(n_env=48, n_step=120, threads=8):
             ms.set_links(a, scn.phases[a][(t // 30) % 5])
         ms.step(5)
     sim_dt = time.perf_counter() - t1
-    return {'value': steps / dt, 'unit': 'env-steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': 'oracle/ (C microsim + NumPy env wrapper + float64 torch-CPU nets): %d env instances x %d control '
-                      'steps + 1 update, %.1f s' % (n_env, n_step, dt),
-            'sim_only_value': scn.n_agent * 3600 / sim_dt,
-            'sim_only_sample': 'oracle/microsim.c alone, 1 instance, 1 core, 3600 simulated seconds, %.2f s' % sim_dt}
+    out = {'value': steps / dt32, 'unit': 'env-steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+           'sample': 'oracle/ (C microsim + NumPy env wrapper + float32 torch-CPU nets = the reference\'s TensorFlow arithmetic): %d env '
+                     'instances x %d control steps + 1 update, %.1f s' % (n_env, n_step, dt32),
+           'value_float64_nets': steps / dt64,
+           'sample_float64_nets': 'the same with the float64 nets the parity tests check against, %.1f s' % dt64,
+           'sim_only_value': scn.n_agent * 3600 / sim_dt,
+           'sim_only_sample': 'oracle/microsim.c alone, 1 instance, 1 core, 3600 simulated seconds, %.2f s' % sim_dt}
+    try:                                # SURVEY 8(d) baseline (i), measured where /root/reference exists (not on this box)
+        oa = json.load(open(os.path.join(ROOT, 'profiles', 'r04_oracle_a.json')))
+        out['reference_env_over_fake_traci'] = {
+            'source': 'profiles/r04_oracle_a.json (tools/time_oracle_a.py, build container, 1 core): committed measurement, NOT timed in this run',
+            'env_only': {k: oa['oracle_a_env'][k] for k in ('value', 'unit', 'what')},
+            'training_loop': {k: oa['oracle_a_training_loop'][k] for k in ('value', 'unit', 'what')}}
+    except Exception:
+        pass
+    return out
 
 
 def extra_lines(env, model, scn, n_ctrl=240):
@@ -192,6 +238,154 @@ def extra_lines(env, model, scn, n_ctrl=240):
     return out
 
 
+PRESETS = {'c2': ('large_grid', 'ia2c', 'fc', 256), 'c3': ('large_grid', 'ma2c', 'lstm', 1024), 'c5': ('real_net', 'ma2c', 'lstm', 512)}
+
+
+def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warmup, want_extra, want_cpu, want_profile):
+    """Build the env instances and the learner of one configuration on this rank's GPU, time `steps` A2C iterations after
+    `warmup` (barrier + device synchronisation on both sides, MAX over ranks) and return the JSON line as a dict (rank 0)."""
+    from deeprl_signal_control_amd import _lib
+    from deeprl_signal_control_amd.agents import VecA2C
+    from deeprl_signal_control_amd.env import VecTrafficEnv
+    from deeprl_signal_control_amd.scenario import build_scenario
+    from deeprl_signal_control_amd.trainer import MultiBatchTrainer, VecTrainer
+
+    scn = build_scenario(scenario, agent)
+    if scenario == 'large_grid':        # config/config_{ma2c,ia2c}_large.ini
+        mcfg, seed0, tseeds = dict(reward_norm=2000.0 if agent == 'ma2c' else 3000.0, batch_size=120), 12, (10000, 20000)
+    else:                               # config/config_{ma2c,ia2c}_real.ini
+        mcfg, seed0, tseeds = dict(reward_norm=1.0, batch_size=40), 42, (10000, 20000, 30000)
+    B = max(1, args.batches)
+    assert E % B == 0
+    Eb = E // B
+    envs, models = [], []
+    for b in range(B):
+        envs.append(VecTrafficEnv(scn, Eb, device=local, seed=seed0 + rank * E + b * Eb, seed_stride=E * world,
+                                  test_seeds=tseeds))
+        # same weight-init seed on every rank / half-batch (replicas of one learner), own action stream each
+        mdl = VecA2C(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, scn.n_f_ls, Eb, scn.s_max, int(scn.green_tab.shape[1]), mcfg,
+                     device=local, seed=0, name=agent, policy=policy, replica=b)
+        models.append(mdl)
+    env, model = envs[0], models[0]
+    tr = VecTrainer(env, model) if B == 1 else MultiBatchTrainer(envs, models)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(warmup):
+        tr.run_iteration()
+    sync()
+    for e_ in envs:
+        e_.live_vehicle_mean(1)                       # reset the window accumulators
+    # ---- the timed region: profile-free (no event pairs between dependent launches) --------------------------------
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.run_iteration()
+    sync()
+    dt = time.perf_counter() - t0
+    # window mean over the timed region of the vehicles in the network per env instance (SURVEY 8d's V)
+    live = float(np.mean([e_.live_vehicle_mean(steps * model.n_step) for e_ in envs]))
+    msr = tr.mean_step_reward()
+    # ---- a second, profiled pass of the same loop: HIP events on the launch stream around every kernel -------------
+    prof, psteps, live_prof, dt_prof = {}, args.profile_steps or steps, None, None
+    if want_profile:
+        _lib.profile(enable=max(1, args.profile_stride), reset=True)
+        t1 = time.perf_counter()
+        for _ in range(psteps):
+            tr.run_iteration()
+        sync()
+        dt_prof = time.perf_counter() - t1
+        prof = _lib.profile()
+        _lib.profile(enable=False)
+        live_prof = float(np.mean([e_.live_vehicle_mean(psteps * model.n_step) for e_ in envs]))
+    extra = {}
+    if rank == 0 and world == 1 and B == 1 and want_extra:
+        extra = extra_lines(env, model, scn)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    out = None
+    if rank == 0:
+        n_step, ctrl = model.n_step, scn.control_interval_sec
+        env_steps = scn.n_agent * E * world * n_step * ctrl * steps
+        out = {'metric': 'env-steps/s (agents x envs x sim-steps/s), %s %s' % (scenario, agent.upper()),
+               'value': env_steps / dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': steps,
+               'warmup': warmup, 'ms_per_step': 1e3 * dt / steps, 'higher_is_better': True,
+               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': '%s (%d agents), %s %s policy%s, %d env instances per GPU; step = %d control steps '
+                                      '(x%d sim-steps) of every instance + 1 A2C update (%sclip, RMSProp%s)'
+                                      % ('large_grid 5x5' if scenario == 'large_grid' else 'real_net Monaco', scn.n_agent,
+                                         agent.upper(), policy.upper(),
+                                         ' (neighbour fingerprint gather)' if agent == 'ma2c' else '', E, n_step, ctrl,
+                                         'BPTT, ' if policy == 'lstm' else '', ', RCCL grad all-reduce' if world > 1 else ''),
+                          'envs_per_gpu': E, 'n_step': n_step, 'agents': scn.n_agent,
+                          'parallelism': 'env-sharded x%d%s' % (world, ', %d half-batches on separate streams' % B if B > 1 else ''),
+                          'mean_live_vehicles_per_env': live, 'live_vehicles': 'window mean over the timed region',
+                          'mean_step_reward': msr}}
+        is_default = (scenario, agent, policy, E) == ('large_grid', 'ma2c', 'lstm', 1024)
+        if prof:
+            total = sum(ms for ms, _ in prof.values())
+            dom = max(prof, key=lambda k: prof[k][0])
+            ms, cnt = prof[dom]
+            avg_s = ms / cnt * 1e-3
+            kern = {k: {'ms_total': round(v[0], 3), 'launches': v[1]} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+            # per-kernel roofline fraction: MFMA kernels against the fp32 MFMA peak, the simulator against HBM
+            fl_all = algorithmic_flops(model, E * n_step)
+            for k, d in kern.items():
+                avg = d['ms_total'] / d['launches'] * 1e-3
+                if k == 'env_step':
+                    d['frac_hbm'] = round((32.0 * live_prof + 16.0 * scn.n_lane + scn.n_agent * 52.0 / 5.0) * ctrl * E / avg / 1e9 / PEAK_HBM_GBS, 4)
+                elif k == 'policy_fwd_fused':
+                    d['frac_mfma'] = round(algorithmic_flops(model, E)[k] / avg / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+                elif fl_all.get(k, 0.0) > 0 and d['launches'] == psteps:
+                    d['frac_mfma'] = round(fl_all[k] / avg / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+            traffic, traffic_src = pmc_traffic(dom, is_default)
+            if dom == 'env_step':
+                V, Ln, A = live_prof, scn.n_lane, scn.n_agent           # SURVEY.md 8d: 32 V + 16 L + A*52/5 B per env-sim-step (V = window mean)
+                bytes_launch = (32.0 * V + 16.0 * Ln + A * 52.0 / 5.0) * ctrl * E
+                ach = bytes_launch / avg_s / 1e9
+                roof = {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                        'frac': ach / PEAK_HBM_GBS, 'traffic': traffic}
+            else:
+                fl = algorithmic_flops(model, E * n_step)
+                if dom == 'policy_fwd_fused':                         # one launch per control step, rows = E
+                    ach = algorithmic_flops(model, E)[dom] / avg_s / 1e12
+                elif dom in ('fc_gemm', 'zx_gemm', 'lstm_fwd') and cnt != psteps:
+                    # launched both per control step (rows = E) and once per update (rows = E * n_step)
+                    tot_fl = fl[dom] * psteps + algorithmic_flops(model, E)[dom] * (cnt - psteps)
+                    ach = tot_fl / (ms * 1e-3) / 1e12
+                else:
+                    ach = fl.get(dom, 0.0) / avg_s / 1e12
+                roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
+                        'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic}
+            roof['traffic_source'] = traffic_src
+            roof['timed'] = ('HIP events on the launch stream around every %slaunch, in a second pass of %d iterations of the same loop '
+                             'right after the timed region (the timed region itself carries no events); that pass took %.2f ms '
+                             'per iteration' % ('%d-th per-control-step ' % args.profile_stride if args.profile_stride > 1 else '',
+                                                psteps, 1e3 * dt_prof / psteps))
+            roof['mean_live_vehicles_per_env'] = live_prof
+            roof['avg_launch_ms'] = ms / cnt
+            roof['share_of_kernel_time'] = ms / total
+            roof['kernel_time_ms_total'] = total
+            out['roofline'] = roof
+            out['kernels'] = kern
+        if extra:
+            out['extra'] = extra
+        if world == 1 and want_cpu:
+            out['cpu_baseline'] = cpu_baseline()
+    for m_ in models:
+        m_.close()
+    for e_ in envs:
+        e_.close()
+    del tr, models, envs, env, model
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -203,7 +397,7 @@ def main():
     ap.add_argument('--policy', default='lstm', choices=['lstm', 'fc'], help='fc = FcACPolicy (BASELINE configs[1], ia2c only)')
     ap.add_argument('--batches', type=int, default=1, help='independent half-batches per GPU on separate HIP streams')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-extra', action='store_true', help='skip the sim-only / sim+forward lines (SURVEY 8d)')
+    ap.add_argument('--no-extra', action='store_true', help='skip the sim-only / sim+forward lines (SURVEY 8d) and the other single-GPU configs')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--profile-stride', type=int, default=1,
                     help='profiled pass: HIP-event timing of every n-th launch of the per-control-step kernels (1 = all)')
@@ -221,12 +415,10 @@ def main():
         args.steps = 20 if short else 10
     if args.warmup is None:
         args.warmup = 10 if short else 4
-    if args.config == 'c2':
-        args.scenario, args.agent, args.policy, args.envs = 'large_grid', 'ia2c', 'fc', 256
-    elif args.config == 'c3':
-        args.scenario, args.agent, args.policy, args.envs = 'large_grid', 'ma2c', 'lstm', 1024
-    elif args.config == 'c5':
-        args.scenario, args.agent, args.policy, args.envs = 'real_net', 'ma2c', 'lstm', 512
+    if args.config:
+        args.scenario, args.agent, args.policy, args.envs = PRESETS[args.config]
+    # the plain driver line (no --config / --envs ... given) also carries the other single-GPU configurations of BASELINE.json
+    plain = (args.config is None and (args.scenario, args.agent, args.policy, args.envs, args.batches) == ('large_grid', 'ma2c', 'lstm', 1024, 1))
 
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -242,137 +434,24 @@ def main():
     assert world == args.gpus, '--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world)
     torch.cuda.set_device(local)
 
-    from deeprl_signal_control_amd import _lib
-    from deeprl_signal_control_amd.agents import VecA2C
-    from deeprl_signal_control_amd.env import VecTrafficEnv
-    from deeprl_signal_control_amd.scenario import build_scenario
-    from deeprl_signal_control_amd.trainer import MultiBatchTrainer, VecTrainer
-
-    E = args.envs
-    scn = build_scenario(args.scenario, args.agent)
-    if args.scenario == 'large_grid':        # config/config_{ma2c,ia2c}_large.ini
-        mcfg, seed0, tseeds = dict(reward_norm=2000.0 if args.agent == 'ma2c' else 3000.0, batch_size=120), 12, (10000, 20000)
-    else:                                    # config/config_{ma2c,ia2c}_real.ini
-        mcfg, seed0, tseeds = dict(reward_norm=1.0, batch_size=40), 42, (10000, 20000, 30000)
-    B = max(1, args.batches)
-    assert E % B == 0
-    Eb = E // B
-    envs, models = [], []
-    for b in range(B):
-        envs.append(VecTrafficEnv(scn, Eb, device=local, seed=seed0 + rank * E + b * Eb, seed_stride=E * world,
-                                  test_seeds=tseeds))
-        # same weight-init seed on every rank / half-batch (replicas of one learner), own action stream each
-        mdl = VecA2C(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, scn.n_f_ls, Eb, scn.s_max, int(scn.green_tab.shape[1]), mcfg,
-                     device=local, seed=0, name=args.agent, policy=args.policy, replica=b)
-        models.append(mdl)
-    env, model = envs[0], models[0]
-    tr = VecTrainer(env, model) if B == 1 else MultiBatchTrainer(envs, models)
-
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
-
-    for _ in range(args.warmup):
-        tr.run_iteration()
-    sync()
-    for e_ in envs:
-        e_.live_vehicle_mean(1)                       # reset the window accumulators
-    live = []
-    # ---- the timed region: profile-free (no event pairs between dependent launches) --------------------------------
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr.run_iteration()
-    sync()
-    dt = time.perf_counter() - t0
-    # window mean over the timed region of the vehicles in the network per env instance (SURVEY 8d's V)
-    live.append(float(np.mean([e_.live_vehicle_mean(args.steps * model.n_step) for e_ in envs])))
-    msr = tr.mean_step_reward()
-    # ---- a second, profiled pass of the same loop: HIP events on the launch stream around every kernel -------------
-    prof, psteps, live_prof, dt_prof = {}, args.profile_steps or args.steps, None, None
-    if not args.no_profile:
-        _lib.profile(enable=max(1, args.profile_stride), reset=True)
-        t1 = time.perf_counter()
-        for _ in range(psteps):
-            tr.run_iteration()
-        sync()
-        dt_prof = time.perf_counter() - t1
-        prof = _lib.profile()
-        _lib.profile(enable=False)
-        live_prof = float(np.mean([e_.live_vehicle_mean(psteps * model.n_step) for e_ in envs]))
-    extra = {}
-    if rank == 0 and world == 1 and B == 1 and not args.no_extra:
-        extra = extra_lines(env, model, scn)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-
+    out = run_config(args, rank, world, local, args.scenario, args.agent, args.policy, args.envs, args.steps, args.warmup,
+                     want_extra=not args.no_extra, want_cpu=False, want_profile=not args.no_profile)
+    if rank == 0 and world == 1 and plain and not args.no_extra:
+        # BASELINE.json configs[1] and configs[4] (per-GPU share), same method, short runs: value, iteration time, window-mean
+        # vehicles and the dominant kernel's roofline fraction of each -- one driver-run line evidences c2 / c3 / c5
+        cfgs = {}
+        for name in ('c2', 'c5'):
+            sc, ag, po, E = PRESETS[name]
+            o = run_config(args, rank, world, local, sc, ag, po, E, 20, 10, want_extra=False, want_cpu=False, want_profile=not args.no_profile)
+            c = {'workload': o['config']['workload'], 'value': o['value'], 'unit': o['unit'], 'ms_per_step': o['ms_per_step'],
+                 'steps': o['steps'], 'warmup': o['warmup'], 'mean_live_vehicles_per_env': o['config']['mean_live_vehicles_per_env']}
+            if 'roofline' in o:
+                r = o['roofline']
+                c['roofline'] = {k: r[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms', 'share_of_kernel_time')}
+                c['kernels'] = o['kernels']
+            cfgs[name] = c
+        out.setdefault('extra', {})['configs'] = cfgs
     if rank == 0:
-        n_step, ctrl = model.n_step, scn.control_interval_sec
-        env_steps = scn.n_agent * E * world * n_step * ctrl * args.steps
-        out = {'metric': 'env-steps/s (agents x envs x sim-steps/s), %s %s' % (args.scenario, args.agent.upper()),
-               'value': env_steps / dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': args.steps,
-               'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
-               'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-               'config': {'workload': '%s (%d agents), %s %s policy%s, %d env instances per GPU; step = %d control steps '
-                                      '(x%d sim-steps) of every instance + 1 A2C update (%sclip, RMSProp%s)'
-                                      % ('large_grid 5x5' if args.scenario == 'large_grid' else 'real_net Monaco', scn.n_agent,
-                                         args.agent.upper(), args.policy.upper(),
-                                         ' (neighbour fingerprint gather)' if args.agent == 'ma2c' else '', E, n_step, ctrl,
-                                         'BPTT, ' if args.policy == 'lstm' else '', ', RCCL grad all-reduce' if world > 1 else ''),
-                          'envs_per_gpu': E, 'n_step': n_step, 'agents': scn.n_agent,
-                          'parallelism': 'env-sharded x%d%s' % (world, ', %d half-batches on separate streams' % B if B > 1 else ''),
-                          'mean_live_vehicles_per_env': live[-1], 'live_vehicles': 'window mean over the timed region',
-                          'mean_step_reward': msr}}
-        is_default = (args.scenario, args.agent, args.policy, E) == ('large_grid', 'ma2c', 'lstm', 1024)
-        if prof:
-            total = sum(ms for ms, _ in prof.values())
-            dom = max(prof, key=lambda k: prof[k][0])
-            ms, cnt = prof[dom]
-            avg_s = ms / cnt * 1e-3
-            kern = {k: {'ms_total': round(v[0], 3), 'launches': v[1]} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
-            # per-kernel roofline fraction: MFMA kernels against the fp32 MFMA peak, the simulator against HBM
-            fl_all = algorithmic_flops(model, E * n_step)
-            for k, d in kern.items():
-                avg = d['ms_total'] / d['launches'] * 1e-3
-                if k == 'env_step':
-                    d['frac_hbm'] = round((32.0 * live_prof + 16.0 * scn.n_lane + scn.n_agent * 52.0 / 5.0) * ctrl * E / avg / 1e9 / PEAK_HBM_GBS, 4)
-                elif k == 'policy_fwd_fused':
-                    d['frac_mfma'] = round(algorithmic_flops(model, E)[k] / avg / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
-                elif fl_all.get(k, 0.0) > 0 and d['launches'] == psteps:
-                    d['frac_mfma'] = round(fl_all[k] / avg / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
-            if dom == 'env_step':
-                V, Ln, A = live_prof, scn.n_lane, scn.n_agent           # 32 V + 16 L + A*52/5 B per env-sim-step (V = window mean)
-                bytes_launch = (32.0 * V + 16.0 * Ln + A * 52.0 / 5.0) * ctrl * E
-                ach = bytes_launch / avg_s / 1e9
-                roof = {'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                        'frac': ach / PEAK_HBM_GBS, 'traffic': pmc_traffic(dom, is_default)}
-            else:
-                rows = E * n_step if dom not in ('fc_gemm', 'zx_gemm', 'lstm_fwd') else None
-                fl = algorithmic_flops(model, E * n_step)
-                if dom == 'policy_fwd_fused':                         # one launch per control step, rows = E
-                    ach = algorithmic_flops(model, E)[dom] / avg_s / 1e12
-                elif dom in ('fc_gemm', 'zx_gemm', 'lstm_fwd'):
-                    # launched both per control step (rows = E) and once per update (rows = E * n_step)
-                    tot_fl = fl[dom] * psteps + algorithmic_flops(model, E)[dom] * (cnt - psteps)
-                    ach = tot_fl / (ms * 1e-3) / 1e12
-                else:
-                    ach = fl.get(dom, 0.0) / avg_s / 1e12
-                roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
-                        'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': pmc_traffic(dom, is_default)}
-            roof['timed'] = ('HIP events on the launch stream around every %slaunch, in a second pass of %d iterations of the same loop '
-                             'right after the timed region (the timed region itself carries no events); that pass took %.2f ms '
-                             'per iteration' % ('%d-th per-control-step ' % args.profile_stride if args.profile_stride > 1 else '',
-                                                psteps, 1e3 * dt_prof / psteps))
-            roof['mean_live_vehicles_per_env'] = live_prof
-            roof['avg_launch_ms'] = ms / cnt
-            roof['share_of_kernel_time'] = ms / total
-            roof['kernel_time_ms_total'] = total
-            out['roofline'] = roof
-            out['kernels'] = kern
-        if extra:
-            out['extra'] = extra
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))

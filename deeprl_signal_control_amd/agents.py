@@ -192,6 +192,9 @@ def coerce_config(model_config, defaults):
     return cfg
 
 
+CKPT_FORMAT = 2      # checkpoint npz `format` entry: 2 = counters hold the BASE seed (absent = rounds 1-2: the derived per-rank seed)
+
+
 def replica_sample_seed(seed, rank=0, replica=0):
     """Action-sampling stream of one replica (torch.distributed rank x half-batch index).  Replicas must share the
     weight-init seed, so the sampling seed is derived from (seed, rank, replica): identical parameters, independent
@@ -199,6 +202,15 @@ def replica_sample_seed(seed, rank=0, replica=0):
     x = (int(seed) * 0x9E3779B97F4A7C15 + (int(rank) + 1) * 0xBF58476D1CE4E5B9 + (int(replica) + 1) * 0x94D049BB133111EB) & ((1 << 64) - 1)
     x ^= x >> 31
     return x & ((1 << 63) - 1) if (rank or replica) else int(seed)
+
+
+def resume_sample_seed(stored_seed, fmt, rank=0, replica=0):
+    """(base_seed or None, sample_seed) from the seed slot of a checkpoint's `counters`: format >= 2 stores the BASE seed and
+    every rank / replica re-derives its own stream; files without a `format` entry (rounds 1-2) stored the stream seed the
+    saving rank had already derived, which is used as it is."""
+    if fmt is not None and int(fmt) >= 2:
+        return int(stored_seed), replica_sample_seed(int(stored_seed), rank, replica)
+    return None, int(stored_seed)
 
 
 def allreduce_grads_(flat_grad, group=None):
@@ -343,6 +355,13 @@ class VecA2C:
         parameters and the RMSProp accumulator from rank `src`.  No-op without an initialised process group."""
         if self.world <= 1:
             return
+        # The communicator's FIRST collective (lazy RCCL init: bootstrap, xGMI topology, channel set-up) happens here, fenced
+        # by device synchronisations, on the very buffer and stream every update uses afterwards (the gradient buffer is
+        # still all zeros: the sum leaves it unchanged) -- so the first all-reduce inside backward() is an ordinary one.
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.stream(self.stream):
+            torch.distributed.all_reduce(self.grad_tensor(), op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        torch.cuda.synchronize(self.device)
         for what, setter in (('params', self._L.tsc_model_set_params), ('ms', self._L.tsc_model_set_opt_state)):
             t = torch.from_numpy(self.get_flat(what)).to(self.device)
             torch.distributed.broadcast(t, src=src, group=self.pg)
@@ -502,7 +521,8 @@ class VecA2C:
         np.savez(os.path.join(model_dir, 'checkpoint-%d.npz' % int(global_step)), params=self.get_flat('params'),
                  ms=self.get_flat('ms'), layout=np.array(self.layout.as_tuple() + (self.s_max,), np.int64),
                  dims=np.array([self.n_wave_ls, self.n_w_ls, self.n_f_ls, self.n_a_ls], np.int64),
-                 counters=np.array([self.sample_step, self.base_seed, self.lr_scheduler.n, self.beta_scheduler.n], np.int64))
+                 counters=np.array([self.sample_step, self.base_seed, self.lr_scheduler.n, self.beta_scheduler.n], np.int64),
+                 format=np.int64(CKPT_FORMAT))
 
     def load(self, model_dir, checkpoint=None):
         save_file, save_step = None, 0
@@ -532,8 +552,9 @@ class VecA2C:
         _lib.check(self._L.tsc_model_set_opt_state(self._h, ms.ctypes.data_as(C.c_void_p)))
         if 'counters' in z.files:            # action-RNG stream and lr / beta schedules resume where they stopped; the checkpoint holds
             # the BASE seed, every rank / replica re-derives its own stream from it (independent exploration survives a resume)
-            self.sample_step, self.base_seed = int(z['counters'][0]), int(z['counters'][1])
-            self.sample_seed = replica_sample_seed(self.base_seed, self.rank, self.replica)
+            self.sample_step, seed = int(z['counters'][0]), int(z['counters'][1])
+            base, self.sample_seed = resume_sample_seed(seed, z['format'] if 'format' in z.files else None, self.rank, self.replica)
+            self.base_seed = self.base_seed if base is None else base
             self.lr_scheduler.n, self.beta_scheduler.n = int(z['counters'][2]), int(z['counters'][3])
         return True
 

@@ -80,7 +80,8 @@ struct EnvDev {
     uint32_t *seed;
     int *prev_action;              // [E][A]
     float *fp;                     // [E][A][PMAX]
-    unsigned long long *arrived;   // [E]
+    unsigned long long *arrived;   // [E] vehicles that reached the end of their route this episode
+    unsigned long long *teleported; // [E] heads the teleport surrogate took out of the network (truncated trips, NOT arrivals)
     double *reward_acc;            // [E] running sum of the global reward (training-curve logging, utils.py:161,296-305)
     const float *fp_bound;         // zero-copy fingerprint source (tsc_env_bind_fingerprint) or null
     long long *dbg;                // optional: shader-clock stamps of workgroup 0 / thread 0 (tsc_env_debug_clock)
@@ -266,7 +267,7 @@ __global__ void reset_kernel(EnvDev P, const uint32_t *seeds, float *obs) {
         float p = (float)(1.0 / (double)na);                       // envs/env.py:263-269
         for (int k = 0; k < P.PMAX; ++k) P.fp[((size_t)e * P.A + a) * P.PMAX + k] = k < na - 1 ? p : 0.0f;
     }
-    if (l == 0) { P.tsec[e] = 0; P.seed[e] = seeds[e]; P.arrived[e] = 0ull; P.n_trips[e] = 0; }
+    if (l == 0) { P.tsec[e] = 0; P.seed[e] = seeds[e]; P.arrived[e] = 0ull; P.teleported[e] = 0ull; P.n_trips[e] = 0; }
     __syncthreads();
     emit_obs(P, s, e, obs);
 }
@@ -412,7 +413,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         s.up4[l] = b8(up0) | b8(up1) << 8 | b8(up2) << 16 | b8(up3) << 24;
         s.nout[l] = 0;
     }
-    unsigned arrived = 0;
+    unsigned arrived = 0, tele = 0;
     __syncthreads();
     TSC_STAMP();
 
@@ -524,15 +525,16 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     if (tl < -1) can_cross = false;
                 }
                 // teleport (SUMO --time-to-teleport): the head, standing for >= teleport seconds, whose way is still blocked
-                // (merge slot, capacity, no room behind the target's tail) leaves the network where it stands
+                // (merge slot, capacity, no room behind the target's tail) leaves the network where it stands.  SUMO would
+                // move it along its route and its trip would end later: the surrogate TRUNCATES the trip, so it is counted
+                // as a teleport, not as an arrival, and its trip row carries a negative arrival second
                 if (i == 0 && !can_cross && tl >= 0 && w >= P.teleport) {
-                    ++arrived;
+                    ++tele;
                     if constexpr (REC) {
-                        ++rq_arr;
                         const int k = atomicAdd(&P.n_trips[e], 1);
                         if (k < P.trip_cap) {
                             int *tr = P.trips + ((size_t)e * P.trip_cap + k) * 6;
-                            tr[0] = r; tr[1] = (int)(cur.r0 >> 16); tr[2] = (int)(cur.r0 & 0xFFFFu); tr[3] = t + 1;
+                            tr[0] = r; tr[1] = (int)(cur.r0 >> 16); tr[2] = (int)(cur.r0 & 0xFFFFu); tr[3] = -(t + 1);
                             tr[4] = (int)(cur.r1 & 0xFFFFu); tr[5] = (int)(cur.r1 >> 16);
                         }
                     }
@@ -895,6 +897,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     }
     for (int r = l; r < NS; r += blockDim.x) { P.pending[(size_t)e * NS + r] = s.pend[r]; P.serial[(size_t)e * NS + r] = s.ser[r]; }
     if (arrived) atomicAdd(&P.arrived[e], (unsigned long long)arrived);
+    if (tele) atomicAdd(&P.teleported[e], (unsigned long long)tele);
     if (l == 0) { P.tsec[e] = t; done[e] = t >= P.episode ? 1 : 0; }
     TSC_STAMP();
     __syncthreads();
@@ -1158,6 +1161,10 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
         }
         UP(zip, uint8_t, zp.data(), zp.size());
         for (uint8_t v : zp) if (v >> 4 > 1) any_zip = true;
+        // the merge arbitration packs a lane's feeders into bytes (Smem::up4, 0xFF = none): a feeder index >= 255 would be
+        // left out of the winner search and wait for the teleport
+        if (any_zip && NL > 255)
+            return tsc::fail("tsc_env_create: zipper merges need lane indices < 255 (feeders are bytes on the device), the scenario has %d lanes", NL);
     }
     {
         std::vector<int> se(NS);
@@ -1263,6 +1270,7 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     ALLOC(prev_action, int, (size_t)n_env * A);
     ALLOC(fp, float, (size_t)n_env * A * P.PMAX);
     ALLOC(arrived, unsigned long long, n_env);
+    ALLOC(teleported, unsigned long long, n_env);
     ALLOC(reward_acc, double, n_env);
     ALLOC(n_trips, int, n_env); ALLOC(live_acc, unsigned long long, n_env);
     {
@@ -1366,6 +1374,14 @@ int tsc_env_read_trips(tsc_env *h, int32_t e, int32_t *trips_host, int32_t max_t
     if (n > P.trip_cap) n = P.trip_cap;
     if (n > max_trips) n = max_trips;
     if (n > 0) TSC_HIP(hipMemcpy(trips_host, P.trips + (size_t)e * P.trip_cap * 6, sizeof(int) * (size_t)n * 6, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tsc_env_counters(tsc_env *h, uint64_t *arrived_host, uint64_t *teleported_host) {
+    if (!h || (!arrived_host && !teleported_host)) return tsc::fail("tsc_env_counters: bad arguments");
+    TSC_HIP(hipStreamSynchronize(h->stream));
+    if (arrived_host) TSC_HIP(hipMemcpy(arrived_host, h->P.arrived, sizeof(uint64_t) * h->P.E, hipMemcpyDeviceToHost));
+    if (teleported_host) TSC_HIP(hipMemcpy(teleported_host, h->P.teleported, sizeof(uint64_t) * h->P.E, hipMemcpyDeviceToHost));
     return 0;
 }
 

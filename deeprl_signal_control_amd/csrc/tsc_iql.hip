@@ -116,7 +116,8 @@ __global__ void iql_sample_kernel(int E, int A, int B, long long size, unsigned 
 }
 
 // minibatch rows of agent a: row = e * B + i  <-  transition idx[e][a][i] of instance e
-__global__ void iql_gather_kernel(int E, int A, int SMAX, int B, long long cap, const int *idx, const float *r_obs,
+// (a caller-supplied index outside the filled part [0, size) of the ring is clamped into it: no out-of-bounds read)
+__global__ void iql_gather_kernel(int E, int A, int SMAX, int B, long long cap, int size, const int *idx, const float *r_obs,
                                   const float *r_next, const int *r_act, const float *r_rew, const uint8_t *r_done, float *S,
                                   float *S1, int *act, float *rew, uint8_t *done) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -126,14 +127,16 @@ __global__ void iql_gather_kernel(int E, int A, int SMAX, int B, long long cap, 
         const int c = (int)(i % q4);
         const long long row = (i / q4) % R, a = i / ((long long)q4 * R);
         const long long e = row / B;
-        const int s = idx[(e * A + a) * B + row % B];
+        int s = idx[(e * A + a) * B + row % B];
+        s = s < 0 ? 0 : s >= size ? size - 1 : s;
         const long long src = ((e * cap + s) * A + a) * SMAX + 4 * c;
         reinterpret_cast<float4 *>(S)[i] = *reinterpret_cast<const float4 *>(r_obs + src);
         reinterpret_cast<float4 *>(S1)[i] = *reinterpret_cast<const float4 *>(r_next + src);
     }
     if (i < (long long)A * R) {
         const long long row = i % R, a = i / R, e = row / B;
-        const int s = idx[(e * A + a) * B + row % B];
+        int s = idx[(e * A + a) * B + row % B];
+        s = s < 0 ? 0 : s >= size ? size - 1 : s;
         act[i] = r_act[(e * cap + s) * A + a];
         rew[i] = r_rew[(e * cap + s) * A + a];
         done[i] = r_done[e * cap + s];
@@ -459,7 +462,7 @@ static int iql_compute_grads(tsc_iql *h, uint64_t seed, uint64_t update_index, c
     hipStream_t st = h->stream;
     const long long E = h->E, A = L.A, R = E * h->B;
     TSC_HIP(hipMemsetAsync(h->stats, 0, sizeof(double) * A * 2, st));
-    if (idx_dev) {      // the caller's draw (e.g. the reference's random.sample): indices are clamped by the gather's caller contract
+    if (idx_dev) {      // the caller's draw (e.g. the reference's random.sample); the gather clamps every index into [0, size)
         TSC_HIP(hipMemcpyAsync(h->idx, idx_dev, sizeof(int) * E * A * h->B, hipMemcpyDeviceToDevice, st));
     } else {
         hipLaunchKernelGGL(iql_sample_kernel, dim3((unsigned)((E * A + 127) / 128)), dim3(128), 0, st, (int)E, (int)A, h->B, size,
@@ -467,7 +470,7 @@ static int iql_compute_grads(tsc_iql *h, uint64_t seed, uint64_t update_index, c
     }
     const long long tot = A * R * (L.SMAX / 4);
     hipLaunchKernelGGL(iql_gather_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (int)E, (int)A, L.SMAX, h->B, h->cap,
-                       h->idx, h->r_obs, h->r_next, h->r_act, h->r_rew, h->r_done, h->S, h->S1, h->act, h->rew, h->done);
+                       (int)size, h->idx, h->r_obs, h->r_next, h->r_act, h->r_rew, h->r_done, h->S, h->S1, h->act, h->rew, h->done);
     TSC_HIP(hipGetLastError());
     // Q(s') first (its activations are not needed afterwards), then Q(s) with the activations the backward pass reads
     if (q_forward(h, h->S1, R * L.SMAX, L.SMAX, R, h->X1, h->X2, h->Q)) return tsc::fail("gemm launch failed");

@@ -102,6 +102,15 @@ class VecTrafficEnv:
             self.traffic_data = [[] for _ in range(self.E)]
             self.control_data = [[] for _ in range(self.E)]
             self.trip_data = [[] for _ in range(self.E)]
+            self.teleported_trips = [0] * self.E     # trips of the episode the teleport surrogate truncated (not in trip_data)
+
+    def counters(self):
+        """Per-instance counters of the running episode: (arrived, teleported), int64 [E] each.  `arrived` is the episode sum
+        of simulation.getArrivedNumber (envs/env.py:413); `teleported` counts the heads the teleport surrogate removed after
+        --time-to-teleport seconds (envs/env.py:283-284; SUMO would move them on, so they are not arrivals)."""
+        arr, tel = np.zeros(self.E, np.uint64), np.zeros(self.E, np.uint64)
+        _lib.check(self._L.tsc_env_counters(self._h, arr.ctypes.data_as(C.c_void_p), tel.ctypes.data_as(C.c_void_p)))
+        return arr.astype(np.int64), tel.astype(np.int64)
 
     def _record_step(self, action):
         """Append this control step's rows (reference dict keys; envs/env.py:429-437, :582-587)."""
@@ -138,6 +147,10 @@ class VecTrafficEnv:
                 buf = np.zeros((cnt.value, 6), np.int32)
                 _lib.check(self._L.tsc_env_read_trips(self._h, e, buf.ctypes.data_as(C.c_void_p), len(buf), C.byref(cnt)))
             tr = buf[:cnt.value]
+            # a negative arrival marks a trip the teleport surrogate truncated (include/tsc.h tsc_env_read_trips): SUMO's
+            # tripinfo file only lists vehicles that arrived, so the reference's collect_tripinfo never sees such a row
+            self.teleported_trips[e] += int((tr[:, 3] < 0).sum())
+            tr = tr[tr[:, 3] >= 0]
             tr = tr[np.lexsort((tr[:, 1], tr[:, 0], tr[:, 3]))]
             for r, ser, dep, arr, wsec, wcnt in tr:
                 self.trip_data[e].append({'episode': self.cur_episode, 'id': 'f_%d.%d' % (r, ser), 'depart_sec': '%.2f' % dep,

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .agents import Scheduler, allreduce_grads_, coerce_config, ortho_init, replica_sample_seed
+from .agents import CKPT_FORMAT, resume_sample_seed, Scheduler, allreduce_grads_, coerce_config, ortho_init, replica_sample_seed
 
 IQL_DEFAULTS = dict(max_grad_norm=40.0, gamma=0.99, lr_init=1e-4, lr_decay='constant', lr_min=0.0, epsilon_init=1.0,
                     epsilon_min=0.01, epsilon_decay='linear', epsilon_ratio=0.5, num_fc=128, num_h=64, batch_size=20,
@@ -303,6 +303,9 @@ class VecIQL:
         """minibatch_step with the caller's draw: idx int32 [E, A, batch_size] (device), ring slots of every (instance,
         agent) -- ReplayBuffer.sample_transition's pick (include/tsc.h tsc_iql_compute_grads_at)."""
         assert idx.dtype == torch.int32 and idx.is_contiguous() and tuple(idx.shape) == (self.E, self.n_agent, self.n_step)
+        lo, hi, size = int(idx.min()), int(idx.max()), self.replay_size()[0]
+        if lo < 0 or hi >= size:        # the library would clamp; an index nobody filled is a caller bug (random.sample cannot produce one)
+            raise ValueError('minibatch_step_at: ring slots [%d, %d] outside the filled part [0, %d)' % (lo, hi, size))
         _lib.check(self._L.tsc_iql_compute_grads_at(self._h, C.c_void_p(idx.data_ptr())))
         self.update_step += 1
         stats = np.zeros((self.n_agent, 2), np.float64) if want_stats else None
@@ -325,7 +328,8 @@ class VecIQL:
         m, v, t = self.get_opt_state()
         np.savez(os.path.join(model_dir, 'checkpoint-%d.npz' % int(global_step)), params=self.get_flat(), adam_m=m, adam_v=v,
                  layout=np.array(self.layout.as_tuple() + (self.s_max,), np.int64),
-                 counters=np.array([t, self.act_step, self.update_step, self.base_seed, self.lr_scheduler.n, self.eps_scheduler.n], np.int64))
+                 counters=np.array([t, self.act_step, self.update_step, self.base_seed, self.lr_scheduler.n, self.eps_scheduler.n], np.int64),
+                 format=np.int64(CKPT_FORMAT))
 
     def load(self, model_dir, checkpoint=None):
         save_file, save_step = None, 0
@@ -348,8 +352,9 @@ class VecIQL:
         m, v = np.ascontiguousarray(z['adam_m'], np.float32), np.ascontiguousarray(z['adam_v'], np.float32)
         c = [int(x) for x in z['counters']]
         _lib.check(self._L.tsc_iql_set_opt_state(self._h, m.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p), c[0]))
-        self.act_step, self.update_step, self.base_seed = c[1], c[2], c[3]     # the BASE seed: every rank / replica re-derives its stream
-        self.sample_seed = replica_sample_seed(self.base_seed, self.rank, self.replica)
+        self.act_step, self.update_step = c[1], c[2]
+        base, self.sample_seed = resume_sample_seed(c[3], z['format'] if 'format' in z.files else None, self.rank, self.replica)
+        self.base_seed = self.base_seed if base is None else base
         self.replay_seed = self.sample_seed ^ 0x5DEECE66D
         self.lr_scheduler.n, self.eps_scheduler.n = c[4], c[5]
         return True

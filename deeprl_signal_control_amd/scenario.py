@@ -142,6 +142,9 @@ class Scenario:
         if self.n_route > 254 or self.n_stream > 254:
             raise ValueError('%d routes / %d insertion streams: at most 254 each (route ids and stream lists are bytes on the device)'
                              % (self.n_route, self.n_stream))
+        if self.n_lane > 255 and (np.asarray(self.mv_zip) >> 8 > 1).any():
+            raise ValueError('%d lanes with zipper merges: the merge arbitration keeps a lane\'s feeders as bytes on the device, '
+                             'lane indices must stay below 255' % self.n_lane)
         if np.asarray(self.lane_up).shape[1] != MAX_UP:
             raise ValueError('lane_up must list %d feeder slots per lane' % MAX_UP)
         if self.control_interval_sec > 8:
@@ -603,9 +606,16 @@ def draw_stream_routes(scn: Scenario, seed: int):
         return None
     rs = np.random.RandomState(int(seed) & 0xFFFFFFFF)
     routes = scn.stream_choice[:, 0, 0, 0].astype(np.int32).copy()
-    sink_routes = scn.extra['sink_routes']
-    for s_ in np.nonzero(np.asarray(scn.stream_mode) == 2)[0]:
-        routes[s_] = sink_routes[int(rs.choice(len(sink_routes)))]
+    m2 = np.nonzero(np.asarray(scn.stream_mode) == 2)[0]
+    cand = scn.stream_choice[m2, 0, :, 0]                      # [n, KC] candidate routes of every drawn stream, -1 padded
+    K = (cand >= 0).sum(axis=1)
+    if (K == K[0]).all():
+        # one vectorised draw: RandomState.choice(K, size=n) consumes the legacy stream exactly like n scalar choice(K)
+        # calls (tests/test_init_density.py), at 1/1000 of their cost (E x 120 calls per reset before)
+        routes[m2] = cand[np.arange(len(m2)), rs.choice(int(K[0]), size=len(m2))]
+    else:
+        for j, s_ in enumerate(m2):
+            routes[s_] = cand[j, int(rs.choice(int(K[j])))]
     return routes
 
 

@@ -153,6 +153,10 @@ int tsc_env_get_state(tsc_env *h, int32_t e, int32_t *n, float *x, float *v, flo
  * 64 + 2E entries). */
 int tsc_env_debug_clock(tsc_env *h, int32_t enable, int64_t *stamps64_host);
 
+/* Per-instance counters of the running episode, uint64 [E] each (either pointer may be null): vehicles that reached the
+ * end of their route (simulation.getArrivedNumber summed over the episode, envs/env.py:413) and vehicles the teleport
+ * surrogate removed (SUMO --time-to-teleport, envs/env.py:283-284; they are NOT arrivals).  Host pointers. Synchronises. */
+int tsc_env_counters(tsc_env *h, uint64_t *arrived_host, uint64_t *teleported_host);
 /* Mean number of live vehicles per env (roofline bookkeeping). Synchronises. */
 int tsc_env_live_vehicles(tsc_env *h, double *mean_live);
 /* sum over instances and control steps since the last reset of the accumulator of the vehicles in
@@ -169,7 +173,10 @@ int tsc_env_record(tsc_env *h, int32_t enable, int32_t trip_cap);
  * incoming lane in (agent, ild) order (-1-padded lanes report 0).  Host pointers. Synchronises. */
 int tsc_env_read_record(tsc_env *h, int64_t *ints_host, double *speed_host, int32_t *queue_host);
 /* Finished trips of instance e since reset(): rows {route, serial within the route, depart_sec, arrival_sec, waiting
- * seconds, waiting count}; *count = trips finished (may exceed max_trips / the capacity given to tsc_env_record). */
+ * seconds, waiting count}; *count = trips finished (may exceed max_trips / the capacity given to tsc_env_record).
+ * A row with a NEGATIVE arrival_sec (= -second) is a trip the teleport surrogate truncated (DESIGN.md 3 rule 1): SUMO
+ * would have moved that vehicle on and written its tripinfo later, so collect_tripinfo (envs/env.py:498-515) must not
+ * count it as a finished trip. */
 int tsc_env_read_trips(tsc_env *h, int32_t e, int32_t *trips_host, int32_t max_trips, int32_t *count);
 
 /* ---- model: replaces IA2C / MA2C (agents/models.py:132-262) + LstmACPolicy / FPLstmACPolicy
@@ -317,7 +324,8 @@ int tsc_iql_replay_size(tsc_iql *h, int64_t *size, int64_t *cum_size);       /* 
  * of every agent in the contiguous buffer tsc_iql_grad_buffer() returns (parameter layout). */
 int tsc_iql_compute_grads(tsc_iql *h, uint64_t seed, uint64_t update_index);
 /* The same with the caller's draw instead of the built-in one: idx dev i32 [E, A, batch_size], every entry a ring slot
- * in [0, replay size) -- what ReplayBuffer.sample_transition's random.sample picked (agents/utils.py:252-258).  Lets a
+ * in [0, replay size) -- what ReplayBuffer.sample_transition's random.sample picked (agents/utils.py:252-258); an entry
+ * outside that range is clamped into it (never an out-of-bounds read; validate on the host if it matters).  Lets a
  * host that owns the sampling (or a recorded reference run, tests/test_refnet_iql_gpu.py) drive the update. */
 int tsc_iql_compute_grads_at(tsc_iql *h, const int32_t *idx_dev);
 int tsc_iql_grad_buffer(tsc_iql *h, float **grad_dev, int64_t *count);

@@ -123,10 +123,13 @@ class _Simulation:
 
 def write_tripinfo(path, trips):
     """SUMO's --tripinfo-output as far as envs/env.py:498-515 reads it (id, depart, arrival, duration, waitingCount,
-    waitingTime); vehicle ids are f_<route>.<serial within the route>."""
+    waitingTime); vehicle ids are f_<route>.<serial within the route>.  Rows with a negative arrival are trips the
+    teleport surrogate truncated (oracle/microsim.c): SUMO only writes vehicles that arrived, so they are left out."""
     with open(path, 'w') as f:
         f.write('<tripinfos>\n')
         for r, ser, dep, arr, wsec, wcnt in trips:
+            if arr < 0:
+                continue
             f.write('    <tripinfo id="f_%d.%d" depart="%.2f" arrival="%.2f" duration="%.2f" waitingCount="%d" waitingTime="%.2f"/>\n'
                     % (r, ser, dep, arr, arr - dep, wcnt, wsec))
         f.write('</tripinfos>\n')

@@ -122,3 +122,29 @@ def test_window_mean_live_vehicles():
     assert abs(env.live_vehicle_mean(40) - tot / 40) < 1e-9
     assert env.live_vehicle_mean(1) == 0.0                    # accumulator was reset
     env.close()
+
+
+@pytest.mark.gpu
+def test_teleported_trips_are_counted_apart_from_arrivals():
+    """A full greedy Monaco episode starves a few heads for time-to-teleport seconds: the teleport surrogate
+    takes them out of the network.  They are truncated trips, not arrivals: the device counters, the per-second
+    number_arrived_car and the trip table (like SUMO's tripinfo file) leave them out and report them apart; the oracle
+    agrees on every figure."""
+    from deeprl_signal_control_amd.env import TrafficEnv
+    from oracle.env_oracle import OracleEnv
+    scn = build_real_net('greedy', norm_wave=1.0, clip_wave=-1.0)
+    env = TrafficEnv(scn, is_record=True, seed=42, test_seeds=(10000,))
+    orc = OracleEnv(scn, seed=42, train_mode=False, test_seeds=(10000,), is_record=True)
+    _run(env, scn)
+    _run(orc, scn)
+    tot = orc.ms.totals()
+    arrived, teleported = env.vec.counters()
+    assert 50 < tot['teleported'] < 300 and tot['arrived'] > 2000
+    assert (int(arrived[0]), int(teleported[0])) == (tot['arrived'], tot['teleported'])
+    assert env.vec.teleported_trips[0] == orc.teleported_trips == tot['teleported']
+    assert len(env.trip_data) == len(orc.trip_data) == tot['arrived']
+    key = lambda r: (float(r['arrival_sec']), r['id'])
+    assert sorted(env.trip_data, key=key) == sorted(orc.trip_data, key=key)
+    assert sum(r['number_arrived_car'] for r in env.traffic_data) == tot['arrived']
+    assert [r['number_arrived_car'] for r in env.traffic_data] == [r['number_arrived_car'] for r in orc.traffic_data]
+    env.close()

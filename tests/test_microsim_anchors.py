@@ -55,8 +55,9 @@ def test_monaco_greedy_band():
     r, peak, tot = _episode(scn, 10000, act)
     assert -60.0 < r < -25.0 and 150 <= peak <= 400                   # today -37.2, 240 concurrent vehicles (published greedy run: 322)
     assert tot['departed'] + tot['pending'] > 2300                    # ~2383 vehicles demanded (A.4)
-    assert tot['arrived'] > 2000 and tot['departed'] > 2200           # today 2252 of 2343 inserted (round 2: 355 of 999)
-    assert tot['teleported'] < 300                                    # 117: heads the first-argmax greedy controller starves for 300 s
+    assert tot['arrived'] > 2000 and tot['departed'] > 2200           # today 2135 of 2343 inserted finish their route (round 2: 355 of 999)
+    assert tot['teleported'] < 300                                    # 117 more are taken out by the teleport surrogate (heads the
+    #                                                                   first-argmax greedy controller starves for 300 s): NOT arrivals
     assert 0.6 < r / -41.8 < 1.4                                      # the published greedy reward, within 40 %
 
 
@@ -87,7 +88,8 @@ def test_monaco_greedy_eval_tables_vs_published():
     ours = dict(avg_queue=np.mean([t['avg_queue'] for t in traffic]), avg_speed_mps=np.mean([t['avg_speed_mps'] for t in traffic]),
                 avg_wait_sec=np.mean([t['avg_wait_sec'] for t in traffic]), peak_cars=max(t['number_total_car'] for t in traffic),
                 trips=len(trips))
-    # today: queue 0.33 veh/lane, 4.49 m/s, 48 s mean wait, 240 concurrent vehicles, 2252 completed trips
+    # today: queue 0.33 veh/lane, 4.49 m/s, 48 s mean wait, 240 concurrent vehicles, 2135 completed trips (+ 117 truncated by the
+    # teleport surrogate, which the trip table leaves out like SUMO's tripinfo file would)
     # (before the standstill gap of 2.0 m: 1.32, 2.79 m/s, 81 s, 608, 1486; round 2: 1.71, 1.96 m/s, 395 s, 644, 355)
     assert 0.2 < ours['avg_queue'] < 0.6 and 3.8 < ours['avg_speed_mps'] < 5.5 and 30 < ours['avg_wait_sec'] < 80
     assert 150 < ours['peak_cars'] < 400 and 2000 < ours['trips'] < 2400

@@ -114,3 +114,63 @@ def test_param_layout_roundtrip():
     # structural zeros of the block-diagonal W1 are zero in the packed buffer
     W1 = flat.reshape(lay.G, lay.stride)[0, :lay.ob1].reshape(SMAX, lay.H)
     assert np.all(W1[:NW[0], 128:] == 0) and np.all(W1[NW[0]:NW[0] + NT[0], :192] == 0)
+
+
+# ---- eight ranks (one node of MI355X as the driver launches it), gloo on CPU ------------------------------------------
+def _worker8(rank, world, port, out):
+    """What every rank of `bench.py --gpus 8` does around the device work: derive its env shard and its action stream, all-reduce
+    the flat gradient buffer of the benchmarked model once per update, reduce the timing with MAX, resume from a checkpoint
+    written by rank 0."""
+    from deeprl_signal_control_amd.agents import (CKPT_FORMAT, replica_sample_seed, resume_sample_seed)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    dist = torch.distributed
+    E, seed0, base = 1024, 12, 0
+    seeds = shard_seeds(seed0, E, rank)
+    sample_seed = replica_sample_seed(base, rank, 0)
+    # the flat gradient buffer of large_grid MA2C (25 agents, both towers): one collective, in place
+    lay = ParamLayout([12 + 6 * k for k in (2, 3, 3, 3, 2) * 5], [6] * 25, [8, 12, 12, 12, 8] * 5, [5] * 25, 52, (128, 64, 32))
+    g = torch.full((lay.n_param,), float(rank + 1), dtype=torch.float32)
+    g[rank::world] += 0.5                                    # rank-dependent pattern: a wrong reduction order / subset shows
+    ptr = g.data_ptr()
+    scale = allreduce_grads_(g)
+    assert g.data_ptr() == ptr and scale == 1.0 / world
+    # max-over-ranks timing (bench.py): every rank ends with the slowest rank's time
+    t = torch.tensor([10.0 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # checkpoint written by rank 0 (format 2: the BASE seed), resumed by everyone
+    path = os.path.join(out, 'checkpoint-120.npz')
+    if rank == 0:
+        np.savez(path, counters=np.array([77, base, 120, 120], np.int64), format=np.int64(CKPT_FORMAT))
+        np.savez(os.path.join(out, 'old.npz'), counters=np.array([77, 424242, 120, 120], np.int64))
+    dist.barrier()
+    z, zo = np.load(path), np.load(os.path.join(out, 'old.npz'))
+    b, resumed = resume_sample_seed(int(z['counters'][1]), z['format'], rank, 0)
+    _, old = resume_sample_seed(int(zo['counters'][1]), None, rank, 0)
+    np.save(os.path.join(out, 'r8_%d.npy' % rank),
+            np.array([seeds[0], seeds[-1], sample_seed, resumed, b, old, int(t.item()), int(2 * float(g[0])), int(2 * float(g[1])), lay.n_param], np.int64))
+    np.save(os.path.join(out, 'g8_%d.npy' % rank), g[:64].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_shards_streams_allreduce_and_resume(tmp_path):
+    from deeprl_signal_control_amd.agents import replica_sample_seed
+    world, port = 8, 30517 + os.getpid() % 1000
+    mp.spawn(_worker8, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rows = [np.load(tmp_path / ('r8_%d.npy' % r)) for r in range(world)]
+    # env shards: rank r owns global instances [r E, (r + 1) E) -> seeds seed0 + index, a partition of 8192 instances
+    assert [(int(r[0]), int(r[1])) for r in rows] == [(12 + 1024 * k, 12 + 1024 * k + 1023) for k in range(world)]
+    # action streams: rank 0 keeps the base seed (single-GPU runs are unchanged), all eight differ, a resume re-derives them
+    streams = [int(r[2]) for r in rows]
+    assert streams[0] == 0 and len(set(streams)) == world
+    assert [int(r[3]) for r in rows] == [replica_sample_seed(0, k, 0) for k in range(world)] and all(int(r[4]) == 0 for r in rows)
+    assert all(int(r[5]) == 424242 for r in rows)              # a round-1/2 file: the stored stream seed, not derived again
+    assert all(int(r[6]) == 10 + world - 1 for r in rows)      # MAX over ranks
+    # the all-reduced buffer: sum_k (k + 1) = 36 everywhere, + 0.5 exactly once per element; identical on every rank
+    g = [np.load(tmp_path / ('g8_%d.npy' % r)) for r in range(world)]
+    for k in range(1, world):
+        np.testing.assert_array_equal(g[0], g[k])
+    np.testing.assert_array_equal(g[0], np.full(64, 36.5, np.float32))
+    assert int(rows[0][9]) > 4_000_000                          # 17.3 MB padded (DESIGN.md 2)
