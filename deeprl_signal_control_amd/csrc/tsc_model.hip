@@ -1935,6 +1935,248 @@ __global__ void dx1w1_reduce2_kernel(const float *__restrict__ ws, int G, int S,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// FcACPolicy (agents/policies.py:214-256; BASELINE configs[1]): both layers' weight gradients of one tower in ONE pass over
+// the n-step batch.  The second layer is fc(H -> 64) + relu, so its pre-activation gradient dZ [N][64] is what head_bwd2
+// leaves in dH (relu' of the 64 units folded in); then
+//   dWfc = X1^T dZ,  dbfc = colsum(dZ),
+//   dX1  = (dZ Wfc^T) * relu'(X1)     (16 x 16 tiles, never leaves the registers)
+//   dW1  = obs^T dX1,  db1 = colsum(dX1)
+// -- dx1w1_kernel2 with a 64-deep contraction (16 stationary registers per column unit instead of 64) plus the X1 chunk in
+// LDS, which serves the relu mask (from HBM per lane before) and is the A operand of the dWfc tiles: H/16 x 4 tiles of
+// 16 x 16, wave w owns unit column w & 3 and every second hidden unit from w >> 2 (5 tiles at H = 160, K = the chunk's 32
+// rows).  Replaces three grouped GEMMs (dWfc, dX1 with its 1-GB round trip through HBM, dW1 at a quarter-empty tile).
+// Deterministic like its model: fixed row splits, partial sums folded in split order by fc_bwd_reduce_kernel.
+// ------------------------------------------------------------------------------------------------
+constexpr int kFbLdz = kL + 4;   // dZ chunk [32 rows][64 k + 4]: row-major like HBM, read as 16-byte A-operand quads
+
+template <int NCU>   // H / 16
+__global__ void __launch_bounds__(512, 1)
+fc_bwd_kernel(const float *__restrict__ dZ, const float *__restrict__ X1, const float *__restrict__ WxT,
+              const float *__restrict__ obs, long long N, int G, int S, long long rows_per_split, int A, int SMAX,
+              float *__restrict__ ws, const int *__restrict__ ftm) {
+    constexpr int H = 16 * NCU, NHU = 2 * NCU;                  // half units (column unit x row tile) per chunk
+    constexpr int CHI = (NHU + 7) / 8, CLO = NHU / 8;           // tiles of waves 0..3 / 4..7
+    static_assert(NHU % 8 == 0 || NHU % 8 == 4, "H must be a multiple of 32");
+    constexpr int LDX = H + 16;                                 // X1 chunk rows: (LDX % 32) == 16 -> the four k rows of an MFMA step sit on two bank halves
+    constexpr int NF = NCU / 2;                                 // dWfc tiles per wave
+    constexpr int XQ = H / 4, NXQ = 32 * XQ, NXL = (NXQ + 511) / 512;
+    static_assert(NXL <= 3, "X1 staging slots");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *Az = (float *)smem_raw;                              // [2][32][kFbLdz]
+    float *Ob = Az + 2 * 32 * kFbLdz;                           // [2][32][kObLd]
+    float *Xs = Ob + 2 * 32 * kObLd;                            // [2][32][LDX]
+    const int g = blockIdx.x % G, sp = blockIdx.x / G, a = g >> 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 15, kq = lane >> 4;
+    const long long n0 = (long long)sp * rows_per_split;
+    long long n1 = n0 + rows_per_split;
+    if (n1 > N) n1 = N;
+    const float *dz = dZ + (long long)g * N * kL, *x1 = X1 + (long long)g * N * H;
+    const long long AS = (long long)A * SMAX;
+    const int sq = SMAX >> 2;
+    constexpr long long kPer1 = (long long)65 * H, kPerF = (long long)(H + 1) * kL;
+    float *w = ws + ((long long)sp * G + g) * (2 * kPer1 + kPerF);
+    float *wF = w + 2 * kPer1;
+    // ---- first layer: this wave's half units [st, st + cnt): unit = h >> 1, row tile = h & 1 (as in dx1w1_kernel2)
+    const int st = wave < 4 ? wave * CHI : 4 * CHI + (wave - 4) * CLO, cnt = wave < 4 ? CHI : CLO;
+    const int U0 = st >> 1;
+    const bool a00 = 2 * U0 >= st, a01 = 2 * U0 + 1 < st + cnt, a10 = 2 * U0 + 2 < st + cnt, a11 = 2 * U0 + 3 < st + cnt;
+    const int U1 = U0 + 1 < NCU ? U0 + 1 : NCU - 1;
+    const int col0 = 16 * U0 + n, col1 = 16 * U1 + n;
+    const int fm0 = ftm[a * NCU + U0], fm1 = ftm[a * NCU + U1];
+    // stationary B operands: bwX[4 j + c] = Wfc^T[k = 16 j + 4 kq + c][col]
+    float bw0[16], bw1[16];
+    {
+        const float *src = WxT + (long long)g * kL * H + (long long)(4 * kq) * H;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bw0[4 * j + c] = src[(long long)(16 * j + c) * H + col0];
+                bw1[4 * j + c] = src[(long long)(16 * j + c) * H + col1];
+            }
+    }
+    f32x4 accW[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) accW[u][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum0 = 0.f, bsum1 = 0.f;
+    // ---- second layer: dWfc tiles (hidden unit hu0 + 2 j, unit column c2), dbfc from the waves with hu0 == 0
+    const int c2 = wave & 3, hu0 = wave >> 2;
+    f32x4 accF[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) accF[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsumF = 0.f;
+    // ---- staging: thread -> one dZ float4 (row tid >> 4, 16-byte column tid & 15), one obs float4, up to three X1 float4s.
+    // Rows past the split are stored as ZERO dZ rows: they then contribute nothing to either layer.
+    const int zr = tid >> 4, zc = tid & 15;
+    struct XSlot { int row, col; bool ok; };
+    auto xslot = [&](int q) {
+        XSlot o;
+        int idx = tid + 512 * q;
+        o.ok = idx < NXQ;
+        if (!o.ok) idx = NXQ - 1;
+        o.row = idx / XQ; o.col = 4 * (idx % XQ);
+        return o;
+    };
+    const XSlot x0 = xslot(0), x1s = xslot(1), x2s = xslot(2);
+    float4 sz, so, sx0, sx1, sx2;
+    auto fetch = [&](long long row0) {
+        auto rowc = [&](long long r) { return r < n1 ? r : n1 - 1; };
+        const float4 z = *reinterpret_cast<const float4 *>(dz + rowc(row0 + zr) * kL + 4 * zc);
+        sz = row0 + zr < n1 ? z : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 o = *reinterpret_cast<const float4 *>(obs + rowc(row0 + zr) * AS + (long long)a * SMAX + 4 * (zc < sq ? zc : 0));
+        so = zc < sq ? o : make_float4(0.f, 0.f, 0.f, 0.f);
+        sx0 = *reinterpret_cast<const float4 *>(x1 + rowc(row0 + x0.row) * H + x0.col);
+        if (NXL > 1) sx1 = *reinterpret_cast<const float4 *>(x1 + rowc(row0 + x1s.row) * H + x1s.col);
+        if (NXL > 2) sx2 = *reinterpret_cast<const float4 *>(x1 + rowc(row0 + x2s.row) * H + x2s.col);
+    };
+    auto put = [&](int buf) {
+        *reinterpret_cast<float4 *>(Az + ((long long)buf * 32 + zr) * kFbLdz + 4 * zc) = sz;
+        *reinterpret_cast<float4 *>(Ob + ((long long)buf * 32 + zr) * kObLd + 4 * zc) = so;
+        float *xb = Xs + (long long)buf * 32 * LDX;
+        if (x0.ok) *reinterpret_cast<float4 *>(xb + x0.row * LDX + x0.col) = sx0;
+        if (NXL > 1 && x1s.ok) *reinterpret_cast<float4 *>(xb + x1s.row * LDX + x1s.col) = sx1;
+        if (NXL > 2 && x2s.ok) *reinterpret_cast<float4 *>(xb + x2s.row * LDX + x2s.col) = sx2;
+    };
+    // one column unit of the chunk in LDS buffer `buf`: both / one of its row tiles
+    auto unit = [&](int buf, long long row, const float (&bw)[16], int col, bool r0, bool r1, f32x4 (&aw)[4], float &bs, int fm) {
+        f32x4 c0 = f32x4{0.f, 0.f, 0.f, 0.f}, c1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float4 *A0 = reinterpret_cast<const float4 *>(Az + ((long long)buf * 32 + n) * kFbLdz + 4 * kq);
+        const float4 *A1 = reinterpret_cast<const float4 *>(Az + ((long long)buf * 32 + 16 + n) * kFbLdz + 4 * kq);
+        // relu mask rows 16 r + 4 kq + i of column col, from the X1 chunk
+        const float *Xc = Xs + ((long long)buf * 32 + 4 * kq) * LDX + col;
+        float xm0[4], xm1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { xm0[i] = Xc[i * LDX]; xm1[i] = Xc[(16 + i) * LDX]; }
+        if (r0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 p = A0[4 * j];
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p.x, bw[4 * j], c0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p.y, bw[4 * j + 1], c0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p.z, bw[4 * j + 2], c0, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(p.w, bw[4 * j + 3], c0, 0, 0, 0);
+            }
+        }
+        if (r1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 q = A1[4 * j];
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.x, bw[4 * j], c1, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.y, bw[4 * j + 1], c1, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.z, bw[4 * j + 2], c1, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(q.w, bw[4 * j + 3], c1, 0, 0, 0);
+            }
+        }
+        // dW1 += obs^T dX1 : contraction step i takes rows 16 r + 4 kq + i = the accumulator's own rows
+        auto tail = [&](int r, const f32x4 &c, const float (&xm)[4]) {
+            const float *Os = Ob + ((long long)buf * 32 + 16 * r + 4 * kq) * kObLd + n;
+            float d[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d[i] = xm[i] > 0.f ? c[i] : 0.f;               // rows past the split: c is exactly zero (zero dZ rows)
+                bs += d[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft)
+                    if ((fm >> ft) & 1)                                 // wave-uniform
+                        aw[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(Os[i * kObLd + 16 * ft], d[i], aw[ft], 0, 0, 0);
+        };
+        if (r0) tail(0, c0, xm0);
+        if (r1) tail(1, c1, xm1);
+    };
+    if (n0 < n1) {
+        fetch(n0);
+        put(0);
+        __syncthreads();
+        int buf = 0;
+        for (long long row = n0; row < n1; row += 32, buf ^= 1) {
+            fetch(row + 32);                                    // lands while this chunk computes
+            {   // dWfc += X1^T dZ: A[m = hidden][k = row] from the X1 chunk, B[k = row][n = unit] from the dZ chunk
+                const float *Bz = Az + ((long long)buf * 32 + kq) * kFbLdz + 16 * c2 + n;
+                const float *Ax = Xs + ((long long)buf * 32 + kq) * LDX + 16 * hu0 + n;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const float b = Bz[4 * s * kFbLdz];
+                    bsumF += b;
+#pragma unroll
+                    for (int j = 0; j < NF; ++j)
+                        accF[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ax[4 * s * LDX + 32 * j], b, accF[j], 0, 0, 0);
+                }
+            }
+            if (a00 || a01) unit(buf, row, bw0, col0, a00, a01, accW[0], bsum0, fm0);
+            if (a10 || a11) unit(buf, row, bw1, col1, a10, a11, accW[1], bsum1, fm1);
+            put(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // partial results of the first layer: slot 0 = row tile 0 (or both tiles of a unit owned by one wave), slot 1 = row tile 1 alone
+    auto flush = [&](const f32x4 (&aw)[4], float bs, int col, bool r0, bool r1) {
+        float *w0 = w + (long long)((r0 ? 0 : 1) * 65) * H;
+        float *wz = w + (long long)65 * H;                      // slot 1, zeroed by the owner of both tiles
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = 16 * ft + 4 * kq + i;
+                w0[(long long)f * H + col] = aw[ft][i];
+                if (r0 && r1) wz[(long long)f * H + col] = 0.f;
+            }
+        bs += __shfl_xor(bs, 16, 64);
+        bs += __shfl_xor(bs, 32, 64);
+        if (kq == 0) {
+            w0[(long long)64 * H + col] = bs;
+            if (r0 && r1) wz[(long long)64 * H + col] = 0.f;
+        }
+    };
+    if (a00 || a01) flush(accW[0], bsum0, col0, a00, a01);
+    if (a10 || a11) flush(accW[1], bsum1, col1, a10, a11);
+    // second layer: accF[j][i] = dWfc[hidden 16 (hu0 + 2 j) + 4 kq + i][unit 16 c2 + n]
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            wF[(long long)(16 * (hu0 + 2 * j) + 4 * kq + i) * kL + 16 * c2 + n] = accF[j][i];
+    bsumF += __shfl_xor(bsumF, 16, 64);
+    bsumF += __shfl_xor(bsumF, 32, 64);
+    if (kq == 0 && hu0 == 0) wF[(long long)H * kL + 16 * c2 + n] = bsumF;
+}
+
+// grads[g]: W1 | b1 (sum over (split, row-tile slot), structural zeros of W1 applied) and Wfc | bfc (sum over splits), in order
+__global__ void fc_bwd_reduce_kernel(const float *__restrict__ ws, int G, int S, int H, int SMAX, const int16_t *__restrict__ rr,
+                                     float *__restrict__ grads, long long stride, long long oW1, long long ob1, long long oWx) {
+    const long long per1 = (long long)65 * H, perF = (long long)(H + 1) * kL, per = 2 * per1 + perF;
+    const long long out1 = (long long)(SMAX + 1) * H, out = out1 + perF;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= out * G) return;
+    const long long g = i / out, j = i % out;
+    float acc = 0.f;
+    if (j < out1) {
+        const int f = (int)(j / H), n = (int)(j % H);
+        const long long src = f < SMAX ? j : (long long)64 * H + n;
+        for (int s = 0; s < S; ++s) {
+            const float *b = ws + ((long long)s * G + g) * per;
+            acc += b[src];
+            acc += b[per1 + src];
+        }
+        if (f < SMAX) {
+            const int16_t *q = rr + ((g >> 1) * SMAX + f) * 2;
+            if (n < q[0] || n >= q[1]) acc = 0.f;
+            grads[g * stride + oW1 + j] = acc;
+        } else {
+            grads[g * stride + ob1 + n] = acc;
+        }
+    } else {
+        const long long jj = j - out1;                         // Wfc [H][64] | bfc [64] are contiguous in the layout
+        for (int s = 0; s < S; ++s) acc += ws[((long long)s * G + g) * per + 2 * per1 + jj];
+        grads[g * stride + oWx + jj] = acc;
+    }
+}
+
 struct tsc_model {
     Layout lay;
     int E, T, device;
@@ -1964,6 +2206,7 @@ struct tsc_model {
     int fused_dw;               // dWx | dWh | dbl in one pass (dwxh_kernel)
     int fc_mfma;                // FcACPolicy rollout forward on the matrix cores (TSC_FC_MFMA=0: the per-thread kernel)
     int fused_dx;               // dX1 in registers, dW1 | db1 in the same pass (dx1w1_kernel2)
+    int fused_fc;               // FcACPolicy: dWfc | dbfc | dW1 | db1 in one pass, dX1 in registers (fc_bwd_kernel)
     int inplace;                // the running rollout is written straight into the buffer's slots (tsc_model_rollout_slot): slot T -> 0 carry
     int cached_next;            // next rollout slot whose activations the fused forward will cache; T = all cached
     long long *dbg;
@@ -2108,6 +2351,13 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     if (const char *ev = getenv("TSC_UNFUSED_DW")) if (atoi(ev)) m->fused_dw = 0;
     m->fused_dx = !L.fc && (L.H == 224 || L.H == 160 || L.H == 192 || L.H == 128) && L.SMAX <= 64 && L.SMAX % 4 == 0;
     if (const char *ev = getenv("TSC_UNFUSED_DX")) if (atoi(ev)) m->fused_dx = 0;
+    m->fused_fc = L.fc && (L.H == 160 || L.H == 128) && L.SMAX <= 64 && L.SMAX % 4 == 0;
+    if (const char *ev = getenv("TSC_UNFUSED_DX")) if (atoi(ev)) m->fused_fc = 0;
+    if (m->fused_fc) {
+        const int lds = (int)(sizeof(float) * (2 * 32 * kFbLdz + 2 * 32 * kObLd + 2 * 32 * (L.H + 16)));
+        TSC_HIP(hipFuncSetAttribute((const void *)fc_bwd_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        TSC_HIP(hipFuncSetAttribute((const void *)fc_bwd_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
     if (m->fused_dx) {
         const int lds = (int)(sizeof(float) * (2 * 32 * kD1Ld + 2 * 32 * kObLd));
         TSC_HIP(hipFuncSetAttribute((const void *)dx1w1_kernel2<14>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -2418,6 +2668,31 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
         hipLaunchKernelGGL(transpose_wx_kernel, dim3((unsigned)((G * L.H * L.NZ + 255) / 256)), dim3(256), 0, st, m->params, L, m->WxT);
         ps9.stop();
         TSC_HIP(hipGetLastError());
+        int S = 256 / (int)G;                       // ~ one workgroup per CU
+        if (S < 1) S = 1;
+        const long long perfc = (long long)2 * 65 * L.H + (long long)(L.H + 1) * kL;
+        if (m->fused_fc && (size_t)((long long)S * G * perfc) <= m->ws_floats && L.ob1 == L.oW1 + (long long)L.SMAX * L.H &&
+            L.obl == L.oWx + (long long)L.H * kL) {
+            // both layers' weight gradients in one pass, dX1 never leaves the registers (fc_bwd_kernel)
+            long long rps = (N + S - 1) / S;
+            rps = (rps + 31) / 32 * 32;                  // whole 32-row chunks
+            const size_t lds = sizeof(float) * (2 * 32 * kFbLdz + 2 * 32 * kObLd + 2 * 32 * (L.H + 16));
+            {
+                tsc::ProfScope ps(tsc::KID_DX1_GEMM, m->stream);
+#define TSC_FCB(NCU) hipLaunchKernelGGL(fc_bwd_kernel<NCU>, dim3((unsigned)(S * G)), dim3(512), lds, st, m->dHh, m->X1, m->WxT, m->r_obs, N, (int)G, S, rps, (int)A, L.SMAX, m->ws, m->ftmask)
+                if (L.H == 160) TSC_FCB(10); else TSC_FCB(8);
+#undef TSC_FCB
+            }
+            {
+                tsc::ProfScope ps(tsc::KID_DW1_GEMM, m->stream);
+                const long long tot = ((long long)(L.SMAX + 1) * L.H + (long long)(L.H + 1) * kL) * G;
+                hipLaunchKernelGGL(fc_bwd_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, m->ws, (int)G, S, L.H, L.SMAX,
+                                   m->rowrange, g, L.stride, L.oW1, L.ob1, L.oWx);
+            }
+            TSC_HIP(hipGetLastError());
+            m->cached_next = 0;
+            return 0;
+        }
         if (gemm(m, tsc::KID_DWX_GEMM, true, tsc::EPI_NONE, (int)G, L.H, kL, (int)N, m->X1, N * L.H, L.H, 1, m->dHh, N * kL, kL, g + L.oWx,
                  L.stride, kL, nullptr, 0, nullptr, 0, 0, nullptr, 0, g + L.obl, L.stride)) return tsc::fail("gemm failed");
         if (gemm(m, tsc::KID_DX1_GEMM, false, tsc::EPI_MASK_POS, (int)G, (int)N, L.H, kL, m->dHh, N * kL, kL, 1, m->WxT, (long long)L.H * kL, L.H,

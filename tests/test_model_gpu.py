@@ -312,10 +312,12 @@ def test_forward_sample_equals_forward_then_sample():
     m.close()
 
 
-@pytest.mark.parametrize('agent,knob', [('ma2c', 'TSC_UNFUSED_DW'), ('ia2c', 'TSC_UNFUSED_DW'),
-                                        ('ma2c', 'TSC_UNFUSED_DX'), ('ia2c', 'TSC_UNFUSED_DX')])
-def test_fused_update_kernels_equal_grouped_gemms(agent, knob, monkeypatch):
-    """dwxh_kernel (dWx | dWh | dbl in one pass, whole tower output in accumulators) and dx1w1_kernel2 (dX1 kept in
+@pytest.mark.parametrize('agent,knob,policy', [('ma2c', 'TSC_UNFUSED_DW', 'lstm'), ('ia2c', 'TSC_UNFUSED_DW', 'lstm'),
+                                               ('ma2c', 'TSC_UNFUSED_DX', 'lstm'), ('ia2c', 'TSC_UNFUSED_DX', 'lstm'),
+                                               ('ia2c', 'TSC_UNFUSED_DX', 'fc')])
+def test_fused_update_kernels_equal_grouped_gemms(agent, knob, policy, monkeypatch):
+    """(policy 'fc': fc_bwd_kernel -- dWfc | dbfc | dW1 | db1 of the FcACPolicy in one pass -- against its three grouped GEMMs.)
+    dwxh_kernel (dWx | dWh | dbl in one pass, whole tower output in accumulators) and dx1w1_kernel2 (dX1 kept in
     registers, dW1 | db1 from the same pass, only the structurally non-zero feature tiles of W1) against the grouped GEMMs
     they replace: same gradient up to fp32 summation order, structural zeros of W1 exactly zero."""
     E, T = 40, 9
@@ -323,7 +325,7 @@ def test_fused_update_kernels_equal_grouped_gemms(agent, knob, monkeypatch):
     grads = []
     for unfused in ('0', '1'):
         monkeypatch.setenv(knob, unfused)
-        scn, m, o = _make(agent, E, T, seed=5)
+        scn, m, o = _make(agent, E, T, seed=5, policy=policy)
         m.reset(); o.reset()
         r2 = np.random.RandomState(123)
         obs, done = _fill(scn, m, o, E, T, r2, terminal=False, use_cache=True)
@@ -504,17 +506,19 @@ def test_update_bench_shape_T120():
     m.close()
 
 
-@pytest.mark.parametrize('agent', ['ma2c', 'ia2c'])
-def test_update_benchmarked_batch_E1024_T120(agent):
+@pytest.mark.parametrize('agent,policy,E', [('ma2c', 'lstm', 1024), ('ia2c', 'lstm', 1024), ('ia2c', 'fc', 256)])
+def test_update_benchmarked_batch_E1024_T120(agent, policy, E):
     """The update AT the benchmarked batch -- E = 1024 distinct instances, T = 120: 122 880 rows per agent-tower, the five
     row splits of dwxh / dx1w1 cover 24 576 rows each, lstm_bwd runs its full grid -- through the rollout path the
     benchmark uses (fused forward, activation cache), for MA2C (H = 224) and IA2C (H = 160: the dwxh<7> / dx1w1<5>
     instantiations).  The float64 oracle evaluates the first, a four-neighbour and the last agent (six towers: all the
-    CPU can do in seconds); their gradient slices, returns, losses, norms and updated parameters are compared."""
+    CPU can do in seconds); their gradient slices, returns, losses, norms and updated parameters are compared.
+    ('ia2c', 'fc', 256): BASELINE configs[1] -- FcACPolicy (agents/policies.py:214-256), 256 instances x 120 steps = 30 720
+    rows per agent-tower through the training-shape forward and the one-pass first / second layer backward (fc_bwd_kernel)."""
     from deeprl_signal_control_amd import _lib
     from oracle.nets_oracle import OracleA2C
-    E, T = 1024, 120
-    scn, m, _ = _make(agent, E, T, seed=5)
+    T = 120
+    scn, m, _ = _make(agent, E, T, seed=5, policy=policy)
     A = scn.n_agent
     sel = [0, 3, A - 1]
     tw = m.get_tower_params()
@@ -564,7 +568,7 @@ def test_update_benchmarked_batch_E1024_T120(agent):
         for k2 in (0, 1):
             for k in op[2 * i + k2]:
                 np.testing.assert_allclose(p[2 * a + k2][k], op[2 * i + k2][k], atol=3e-5, err_msg='param agent=%d %s' % (a, k))
-    print('E=1024 T=120 %s worst |dg| / max|g|:' % agent, {k: '%.1e' % v for k, v in worst.items()})
+    print('E=%d T=120 %s %s worst |dg| / max|g|:' % (E, agent, policy), {k: '%.1e' % v for k, v in worst.items()})
     m.close()
 
 
