@@ -30,7 +30,8 @@ def stale():
 def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
-    cmd = [HIPCC] + FLAGS + ['-I', os.path.join(HERE, '..', 'include'), '-o', LIB] + sources()
+    extra = os.environ.get('TSC_BUILD_DEFS', '').split()          # measurement builds, e.g. TSC_BUILD_DEFS=-DTSC_STREAM_SC1=1
+    cmd = [HIPCC] + FLAGS + extra + ['-I', os.path.join(HERE, '..', 'include'), '-o', LIB] + sources()
     if verbose:
         print(' '.join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -92,3 +92,4 @@ template <class T> __device__ __forceinline__ T ldg(const T *base, unsigned byte
 template <class T> __device__ __forceinline__ void stg(T *base, unsigned byte_off, T v) {
     *(T *)((char *)base + byte_off) = v;
 }
+

@@ -295,7 +295,7 @@ __global__ void fingerprint_kernel(EnvDev P, const float *pi) {
 // SPEC 1: the table dimensions of the reference's large_grid are compile-time constants (LDS offsets and index products
 // fold into immediates: the kernel holds > 100 scalar values otherwise and reloads the spilled ones with v_readlane)
 template <int MAXT, bool HELP, bool REC = false, int KF = 4, int SPEC = 0>      // REC: evaluation recording (plain walk only); KF: vehicles per thread and super-round of the flat phase
-__global__ void __launch_bounds__(MAXT, MAXT == 256 ? 4 : 1)
+__global__ void __launch_bounds__(MAXT, MAXT <= 512 ? 4 : 1)      // (HIP: the second figure is wavefronts per SIMD) 128 VGPRs whatever the workgroup size
 step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, double *__restrict__ reward,
             double *__restrict__ greward, uint8_t *__restrict__ done, int train_mode) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1308,16 +1308,30 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     h->kf = h->spec == 1 ? 2 : 1;                            // (Monaco, spec 2: 330 M env-steps/s with 1, 323 M with 2)
     if (const char *ev = getenv("TSC_ENV_KF")) { const int kv = atoi(ev); h->kf = (kv == 2 || kv == 4) ? kv : 1; }
     if (h->spec && h->kf == 4) h->spec = 0;                  // (no specialised instantiation of the 4-wide variant)
-    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
-    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
-    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
-    TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
+#define TSC_ATTR(MT, KF, SP) TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<MT, true, false, KF, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem))
+    TSC_ATTR(256, 1, 1); TSC_ATTR(256, 2, 1); TSC_ATTR(256, 1, 2); TSC_ATTR(256, 2, 2);
+    TSC_ATTR(512, 1, 1); TSC_ATTR(512, 2, 1); TSC_ATTR(512, 1, 2); TSC_ATTR(512, 2, 2);
+    TSC_ATTR(1024, 1, 1); TSC_ATTR(1024, 2, 1); TSC_ATTR(1024, 1, 2); TSC_ATTR(1024, 2, 2);
+#undef TSC_ATTR
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
-    if (const char *ev = getenv("TSC_ENV_THREADS")) {       // measurement knob: extra helper wavefronts
+    // Workgroup size of the specialised kernels: a CU holds 16 wavefronts of this kernel (128 VGPRs), i.e. four workgroups of 256
+    // threads.  With fewer instances than that the flat phase -- a latency chain per wavefront -- is spread over more wavefronts of
+    // the same instance instead of leaving the slots idle (sim only, saturated large_grid: E = 256: 63.0 -> 52.5 us per control
+    // step with 1024 threads, E = 512: 70.9 -> 64.8 us with 512; Monaco 69.6 -> 59.9 / 77.9 -> 71.5; E = 1024 wants 256).
+    // TSC_ENV_THREADS overrides (parity tests run every size).
+    if (h->spec && P.help && h->threads == 256) {
+        int dev_cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) dev_cus = prop.multiProcessorCount;
+        if (n_env <= dev_cus) { h->threads = 1024; h->kf = 1; }
+        else if (n_env <= 2 * dev_cus) h->threads = 512;
+    }
+    if (const char *ev = getenv("TSC_ENV_THREADS")) {       // measurement / test knob
         const int tv = atoi(ev);
         if (tv >= P.NLA && tv <= 1024 && tv % 64 == 0) h->threads = tv;
     }
+    if (const char *ev = getenv("TSC_ENV_KF")) { const int kv = atoi(ev); h->kf = (kv == 2 || kv == 4) ? kv : 1; }
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
@@ -1483,13 +1497,23 @@ int tsc_env_step(tsc_env *h, const int32_t *action_dev, float *obs_dev, double *
 #define TSC_STEP_KF(KF)                                                                                           \
     hipLaunchKernelGGL((step_kernel<256, true, false, KF>), dim3(h->P.E), dim3(h->threads), h->smem, h->stream, h->P, action_dev, \
                        obs_dev, reward_dev, global_reward_dev, done_dev, (int)train_mode)
-#define TSC_STEP_SPEC(KF, SP)                                                                                       \
-    hipLaunchKernelGGL((step_kernel<256, true, false, KF, SP>), dim3(h->P.E), dim3(h->threads), h->smem, h->stream, h->P, action_dev, \
+#define TSC_STEP_SPEC(MT, KF, SP)                                                                                   \
+    hipLaunchKernelGGL((step_kernel<MT, true, false, KF, SP>), dim3(h->P.E), dim3(h->threads), h->smem, h->stream, h->P, action_dev, \
                        obs_dev, reward_dev, global_reward_dev, done_dev, (int)train_mode)
-    else if (h->threads <= 256 && h->P.help && h->kf == 1 && h->spec == 1) TSC_STEP_SPEC(1, 1);
-    else if (h->threads <= 256 && h->P.help && h->kf == 2 && h->spec == 1) TSC_STEP_SPEC(2, 1);
-    else if (h->threads <= 256 && h->P.help && h->kf == 1 && h->spec == 2) TSC_STEP_SPEC(1, 2);
-    else if (h->threads <= 256 && h->P.help && h->kf == 2 && h->spec == 2) TSC_STEP_SPEC(2, 2);
+    // specialised instantiations: workgroup size 256 (four workgroups per CU: E > 512), 512 or 1024 (fewer instances than
+    // workgroup slots: the flat phase spreads over more wavefronts instead of leaving the CU idle)
+    else if (h->P.help && h->spec && (h->kf == 1 || h->kf == 2) && (h->threads == 256 || h->threads == 512 || h->threads == 1024)) {
+        const int key = h->threads * 100 + h->kf * 10 + h->spec;
+        switch (key) {
+            case 25611: TSC_STEP_SPEC(256, 1, 1); break;   case 25621: TSC_STEP_SPEC(256, 2, 1); break;
+            case 25612: TSC_STEP_SPEC(256, 1, 2); break;   case 25622: TSC_STEP_SPEC(256, 2, 2); break;
+            case 51211: TSC_STEP_SPEC(512, 1, 1); break;   case 51221: TSC_STEP_SPEC(512, 2, 1); break;
+            case 51212: TSC_STEP_SPEC(512, 1, 2); break;   case 51222: TSC_STEP_SPEC(512, 2, 2); break;
+            case 102411: TSC_STEP_SPEC(1024, 1, 1); break; case 102421: TSC_STEP_SPEC(1024, 2, 1); break;
+            case 102412: TSC_STEP_SPEC(1024, 1, 2); break; case 102422: TSC_STEP_SPEC(1024, 2, 2); break;
+            default: return tsc::fail("tsc_env_step: no instantiation for %d threads, kf %d, spec %d", h->threads, h->kf, h->spec);
+        }
+    }
 #undef TSC_STEP_SPEC
     else if (h->threads <= 256 && h->P.help && h->kf == 1) TSC_STEP_KF(1);
     else if (h->threads <= 256 && h->P.help && h->kf == 2) TSC_STEP_KF(2);

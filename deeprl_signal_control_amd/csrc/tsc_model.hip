@@ -58,6 +58,20 @@ __device__ __forceinline__ float tanhf_(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
 
+// The activation cache is written once per control step and not read before the update: streaming stores keep its 160 MB
+// per launch from evicting the simulator's vehicle state out of L2 / the infinity cache between two tsc_env_step launches.
+// Round 4, measured and rejected: `sc1` instead of `nt` on the 16-byte stores (__builtin_amdgcn_raw_buffer_store_b128 with aux
+// bit 4 over a per-tower descriptor: the lines then leave the XCD's L2 at once instead of staying dirty until the kernel ends)
+// -- forward 99.2 -> 98.5 us, simulator step behind it 88.0 -> 89.9 us, iteration 42.25 -> 42.5 ms at equal traffic (two runs
+// each).  (An inline-asm `global_store_dwordx4 ... sc1` is NOT an option: the hazard recogniser does not see a wide store in it
+// and lets the next VALU instruction overwrite the data registers -- 7 % of the cached rows came out as garbage.)
+__device__ __forceinline__ void st_stream(float *p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void st_stream4(float *p, const float4 &v) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f4 *>(p));
+}
+
 // ------------------------------------------------------------------------------------------------
 // LSTM forward (agents/utils.py:88-116), T steps, one workgroup per (group, 64-env tile).
 //   Z     [G][T*E][256]  in: x*Wx + b   out (if store): post-activation gates i|f|o|u
@@ -733,7 +747,8 @@ template <int NCT>               // H / 32
 __global__ void __launch_bounds__(512, 1)
 policy_fwd_fc_mfma_kernel(const float *__restrict__ params, Layout lay, const int *__restrict__ n_act,
                           const float *__restrict__ obs, int E, float *__restrict__ pi_out, float *__restrict__ v_out,
-                          int *action_out, unsigned long long seed, unsigned long long step) {
+                          int *action_out, unsigned long long seed, unsigned long long step, int tslot, long long Ntot,
+                          float *__restrict__ X1c, float *__restrict__ Hhc) {
     constexpr int H = 32 * NCT, LDX = H + 1, NS2 = H / 4, NU = 2 * NCT;
     static_assert(NU <= 16, "two layer-1 units per wave at most");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -811,6 +826,26 @@ policy_fwd_fc_mfma_kernel(const float *__restrict__ params, Layout lay, const in
         X2s[(t * 32 + row) * kFcLdo + j] = fmaxf(v, 0.f);
     }
     __syncthreads();
+    if (tslot >= 0) {
+        // activation cache (like the LSTM rollout forward's): this step's X1 and relu(X1 Wfc + bfc) rows of both towers go to
+        // rows [tslot E, (tslot + 1) E) of the training buffers, so the update does not evaluate the forward a second time
+        // (the reference builds the graph twice, agents/policies.py:94-96).  Written once, read by the update only: streaming stores.
+        constexpr int XQ = H / 4;
+        for (int i = tid; i < 2 * 32 * XQ; i += 512) {
+            const int t = i / (32 * XQ), row = (i / XQ) % 32, q = i % XQ;
+            if (e0 + row < E) {
+                const float *src = X1s + (t * 32 + row) * LDX + 4 * q;
+                st_stream4(X1c + ((long long)(2 * a + t) * Ntot + (long long)tslot * E + e0 + row) * H + 4 * q, make_float4(src[0], src[1], src[2], src[3]));
+            }
+        }
+        for (int i = tid; i < 2 * 32 * (kL / 4); i += 512) {
+            const int t = i / (32 * (kL / 4)), row = (i / (kL / 4)) % 32, q = i % (kL / 4);
+            if (e0 + row < E) {
+                const float *src = X2s + (t * 32 + row) * kFcLdo + 4 * q;
+                st_stream4(Hhc + ((long long)(2 * a + t) * Ntot + (long long)tslot * E + e0 + row) * kL + 4 * q, make_float4(src[0], src[1], src[2], src[3]));
+            }
+        }
+    }
     if (tid < 32 && e0 + tid < E) {                     // heads + sampling, one instance per thread
         float pi[kOut], v;
         const int na = n_act[a];
@@ -833,15 +868,6 @@ policy_fwd_fc_mfma_kernel(const float *__restrict__ params, Layout lay, const in
 // ahead.  Blocks are numbered so that all tiles of a tower run on the same XCD (block b -> XCD b%8)
 // and reuse its L2-resident weights.
 // ------------------------------------------------------------------------------------------------
-// The activation cache is written once per control step and not read before the update: streaming (non-temporal) stores
-// keep its 160 MB per launch from evicting the simulator's vehicle state out of L2 / the infinity cache between two
-// tsc_env_step launches (measured in bench.py: env_step 112 -> ... us in the training loop).
-__device__ __forceinline__ void st_stream(float *p, float v) { __builtin_nontemporal_store(v, p); }
-__device__ __forceinline__ void st_stream4(float *p, const float4 &v) {
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    f4 t = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(t, reinterpret_cast<f4 *>(p));
-}
 constexpr int kXLd = 68;
 
 __global__ void __launch_bounds__(256, 2)
@@ -2456,7 +2482,8 @@ static int model_forward(tsc_model *m, const float *obs, const uint8_t *done, fl
     // activation cache: valid only if slots 0..T-1 are filled in order by advancing forwards
     if (advance) {
         if (tslot == 0) m->cached_next = 0;         // slot 0 opens a rollout: whatever invalidated the cache before is history
-        if (m->fused_fwd && tslot >= 0 && tslot == m->cached_next && tslot < m->T) m->cached_next = tslot + 1;
+        const bool fc_cache = L.fc && (L.H == 160 || L.H == 128) && L.SMAX <= 64 && L.AMAX <= kOut && m->fc_mfma;   // policy_fwd_fc_mfma_kernel
+        if ((m->fused_fwd || fc_cache) && tslot >= 0 && tslot == m->cached_next && tslot < m->T) m->cached_next = tslot + 1;
         else { m->cached_next = -1; tslot = -1; }
     } else {
         tslot = -1;
@@ -2529,7 +2556,7 @@ static int model_forward(tsc_model *m, const float *obs, const uint8_t *done, fl
         }
         tsc::ProfScope ps(tsc::KID_FUSED_FWD, m->stream);
 #define TSC_FCM(NCT) hipLaunchKernelGGL(policy_fwd_fc_mfma_kernel<NCT>, dim3((unsigned)((E + 31) / 32), (unsigned)L.A), dim3(512), lds, m->stream, m->params, L, \
-                                        m->n_act, obs, E, pi, v, action, (unsigned long long)seed, (unsigned long long)step)
+                                        m->n_act, obs, E, pi, v, action, (unsigned long long)seed, (unsigned long long)step, (int)tslot, (long long)m->T * E, m->X1, m->Hh)
         if (L.H == 128) TSC_FCM(4); else TSC_FCM(5);
 #undef TSC_FCM
         ps.stop();
@@ -2662,7 +2689,8 @@ int tsc_model_compute_grads(tsc_model *m, const float *R_boot, double beta) {
     float *g = m->grads;
     if (L.fc) {
         // FcACPolicy (agents/policies.py:214-256): Hh = relu(X1 Wfc + bfc); dZ = dH * (Hh > 0) comes out of head_bwd
-        if (dense_forward(m, m->r_obs, N, m->X1, m->Hh)) return tsc::fail("gemm launch failed");
+        // (skipped when the rollout forward cached X1 / Hh of all n_step slots under these very parameters)
+        if (m->cached_next != (int)T && dense_forward(m, m->r_obs, N, m->X1, m->Hh)) return tsc::fail("gemm launch failed");
         if (launch_head_bwd(m, N, beta)) return tsc::fail("head_bwd failed");       // + dWo, dbo
         tsc::ProfScope ps9(tsc::KID_TRANSPOSE, m->stream);
         hipLaunchKernelGGL(transpose_wx_kernel, dim3((unsigned)((G * L.H * L.NZ + 255) / 256)), dim3(256), 0, st, m->params, L, m->WxT);

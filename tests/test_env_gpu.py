@@ -27,8 +27,12 @@ def _replay(env, g, prefix='', test_ind=None):
         assert bool(done) == bool(g[prefix + 'done'][t])
 
 
-def test_golden_ma2c_full_episode(golden_dir):
+@pytest.mark.parametrize('threads', ['256', '512', '1024'])
+def test_golden_ma2c_full_episode(golden_dir, threads, monkeypatch):
+    """Every workgroup size of the specialised step kernel (csrc/tsc_env.hip picks 1024 / 512 / 256 threads per instance for
+    E <= 256 / <= 512 / more; 256 is what the benchmarked 1024 instances run) replays the reference's episode bit-exactly."""
     from deeprl_signal_control_amd.env import TrafficEnv
+    monkeypatch.setenv('TSC_ENV_THREADS', threads)
     g = np.load(os.path.join(golden_dir, 'large_grid_ma2c.npz'))
     env = TrafficEnv(build_large_grid('ma2c'), seed=12)
     _replay(env, g, 'ep1_')
@@ -84,12 +88,16 @@ def test_golden_test_mode_and_greedy(golden_dir):
     env.close()
 
 
-@pytest.mark.parametrize('E,steps,p_random', [(48, 150, 0.7), (8, 720, 1.0)])
-def test_batched_vs_oracle_state(E, steps, p_random):
+@pytest.mark.parametrize('E,steps,p_random,threads', [(48, 150, 0.7, '256'), (48, 150, 0.7, '512'), (48, 150, 0.7, '1024'),
+                                                      (8, 720, 1.0, '256'), (8, 720, 1.0, '')])
+def test_batched_vs_oracle_state(E, steps, p_random, threads, monkeypatch):
     """E env instances with different seeds vs E independent oracle instances: obs, rewards and
-    the full vehicle state (positions, speeds, waits, routes) must be identical."""
+    the full vehicle state (positions, speeds, waits, routes) must be identical -- for every workgroup size of the step
+    kernel ('' = the library's own choice for this E)."""
     from deeprl_signal_control_amd.env import VecTrafficEnv
     from oracle.env_oracle import OracleEnv, greedy_large_grid
+    if threads:
+        monkeypatch.setenv('TSC_ENV_THREADS', threads)
     scn = build_large_grid('ma2c')
     env = VecTrafficEnv(scn, E, seed=100)
     orc = [OracleEnv(scn, seed=100 + e) for e in range(E)]
@@ -173,8 +181,9 @@ def test_helper_threads_equal_plain_walk(monkeypatch):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize('kf,spec', [('1', '1'), ('2', '1'), ('4', '1'), ('1', '0'), ('2', '0')])
-def test_flat_phase_super_rounds_at_saturation(kf, spec, monkeypatch):
+@pytest.mark.parametrize('kf,spec,threads', [('1', '1', '256'), ('2', '1', '256'), ('4', '1', '256'), ('1', '0', '256'), ('2', '0', '256'),
+                                             ('1', '1', '512'), ('2', '1', '512'), ('1', '1', '1024'), ('2', '1', '1024')])
+def test_flat_phase_super_rounds_at_saturation(kf, spec, threads, monkeypatch):
     """More queued vehicles than one super-round of the flat phase holds (kF x 256 per round): tripled demand and random
     phases fill most lanes to capacity.  The chain scan then crosses wavefronts and super-rounds (LDS carries, the saved
     old state of the previous round's last vehicle); obs, rewards and the full vehicle state stay bit-identical to the
@@ -184,6 +193,7 @@ def test_flat_phase_super_rounds_at_saturation(kf, spec, monkeypatch):
     from oracle.env_oracle import OracleEnv
     monkeypatch.setenv('TSC_ENV_KF', kf)
     monkeypatch.setenv('TSC_ENV_SPEC', spec)
+    monkeypatch.setenv('TSC_ENV_THREADS', threads)          # super-rounds of kF x threads vehicles; 256 = the benchmarked kernel
     scn = build_large_grid('ma2c', peak_flow1=3300, peak_flow2=2800)
     E = 6
     env = VecTrafficEnv(scn, E, seed=9)
@@ -203,7 +213,7 @@ def test_flat_phase_super_rounds_at_saturation(kf, spec, monkeypatch):
                 np.testing.assert_array_equal(o[e, a, :scn.n_s_ls[a]], oo[a].astype(np.float32), err_msg='t=%d e=%d a=%d' % (t, e, a))
             np.testing.assert_array_equal(r[e], orr, err_msg='t=%d e=%d' % (t, e))
         peak = max(peak, env.mean_live_vehicles())
-    assert peak > 600, peak                      # 3 super-rounds at kF = 1, 2 at kF = 2 (entry lanes cap the inflow)
+    assert peak > 600, peak                      # 256 threads: 3 super-rounds at kF = 1, 2 at kF = 2 (entry lanes cap the inflow)
     for e in range(E):
         st, sn = env.get_state(e), orc[e].ms.snapshot()
         for k in ('n', 'x', 'v', 'sf', 'w', 'r'):

@@ -89,8 +89,10 @@ def test_gpu_golden_monaco(golden_dir):
 
 
 @pytest.mark.gpu
-def test_gpu_batched_vs_oracle_monaco():
+@pytest.mark.parametrize('threads', ['256', '512', '1024'])
+def test_gpu_batched_vs_oracle_monaco(threads, monkeypatch):
     import torch
+    monkeypatch.setenv('TSC_ENV_THREADS', threads)           # every workgroup size of the Monaco instantiation (spec 2)
     from deeprl_signal_control_amd.env import VecTrafficEnv
     from oracle.env_oracle import OracleEnv
     scn = build_real_net('ma2c')
