@@ -107,6 +107,39 @@ __device__ __forceinline__ uint32_t hash32(uint32_t seed, uint32_t route, uint32
 }
 __device__ __forceinline__ float u01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
 
+// Wavefront scans on the DPP data path (gfx9: row_shr within the four 16-lane rows, then row_bcast:15 into rows 1 / 3 and
+// row_bcast:31 into rows 2 / 3): a cross-lane step is one VALU move instead of a ds_bpermute_b32 with its address arithmetic
+// (~5 instructions and an LDS round trip each; the flat phase ran 14 of them per super-round).  Lanes without a source lane
+// keep `ident`, the identity of the operator, so no lane test is needed.
+#define TSC_DPP_I(ident, v, ctrl, rows) __builtin_amdgcn_update_dpp((ident), (v), (ctrl), (rows), 0xF, false)
+#define TSC_DPP_F(ident, v, ctrl, rows) __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(v), (ctrl), (rows), 0xF, false))
+constexpr int kDppShr1 = 0x111, kDppShr2 = 0x112, kDppShr4 = 0x114, kDppShr8 = 0x118, kDppBcast15 = 0x142, kDppBcast31 = 0x143,
+              kDppWaveShr1 = 0x138;
+// inclusive prefix sum over the wavefront
+__device__ __forceinline__ int wave_scan_add(int v) {
+    v += TSC_DPP_I(0, v, kDppShr1, 0xF); v += TSC_DPP_I(0, v, kDppShr2, 0xF);
+    v += TSC_DPP_I(0, v, kDppShr4, 0xF); v += TSC_DPP_I(0, v, kDppShr8, 0xF);
+    v += TSC_DPP_I(0, v, kDppBcast15, 0xA); v += TSC_DPP_I(0, v, kDppBcast31, 0xC);
+    return v;
+}
+// inclusive prefix maximum over the wavefront (values >= 0)
+__device__ __forceinline__ int wave_scan_max(int v) {
+    v = max(v, TSC_DPP_I(0, v, kDppShr1, 0xF)); v = max(v, TSC_DPP_I(0, v, kDppShr2, 0xF));
+    v = max(v, TSC_DPP_I(0, v, kDppShr4, 0xF)); v = max(v, TSC_DPP_I(0, v, kDppShr8, 0xF));
+    v = max(v, TSC_DPP_I(0, v, kDppBcast15, 0xA)); v = max(v, TSC_DPP_I(0, v, kDppBcast31, 0xC));
+    return v;
+}
+// segmented inclusive min-scan: (v, f) <- (f ? v : min(v, v_prev), f | f_prev); f = 1 marks the first lane of a segment
+__device__ __forceinline__ void wave_seg_scan_min(float &v, int &f) {
+#define TSC_SEG_STEP(ctrl, rows) do {                                     \
+        const float ov = TSC_DPP_F(INFINITY, v, ctrl, rows);              \
+        const int of = TSC_DPP_I(0, f, ctrl, rows);                       \
+        v = f ? v : fminf(v, ov); f |= of; } while (0)
+    TSC_SEG_STEP(kDppShr1, 0xF); TSC_SEG_STEP(kDppShr2, 0xF); TSC_SEG_STEP(kDppShr4, 0xF); TSC_SEG_STEP(kDppShr8, 0xF);
+    TSC_SEG_STEP(kDppBcast15, 0xA); TSC_SEG_STEP(kDppBcast31, 0xC);
+#undef TSC_SEG_STEP
+}
+
 // one car-following evaluation against one leader (DESIGN.md "follow")
 __device__ __forceinline__ float follow(float v, float v0, bool has_lead, float g, float vl, float s0gap) {
     float ratio = v / v0;
@@ -166,7 +199,10 @@ struct Smem {
     int *pend, *ser; uint8_t *emit;             // per-stream insertion state [NS], emissions [NS*8]
     uint8_t *zip;                               // [NU*NR]
     uint32_t *up4;                              // [NLA] the lane's feeders, a byte each (0xFF = none): merge arbitration
-    int *pre, *wtot;                            // wave-local inclusive scan of queued vehicles [NLA], wave totals [16]
+    int *pre, *wtot;                            // wave-local inclusive scan of queued vehicles [NLA] (from phase H on: the lane's
+                                                // first flat index), wave totals [16]
+    uint8_t *mark; uint16_t *bound;             // flat phase: mark[k] = (lane & 63) + 1 where a lane's queued vehicles start at flat index
+                                                // k (else 0) [NLA * (kCap - 1)]; bound[j] = lane + 1 of the owner of flat index 64 j
     int *nc; float *seed;                       // per lane: vehicles ahead of the first one that stays; its chain key [NLA]
     float *wtail, *hz;                          // wave tails of the chain scan [2][16]; old (x, v) across super-rounds [2]
     uint32_t *or0, *or1;                        // outbox of the trip records [kMaxCross*NLA]      (recording only)
@@ -191,6 +227,7 @@ __host__ __device__ __forceinline__ void smem_layout(Smem &s, const EnvDev &P, T
     s.zip = (uint8_t *)take((P.NU * P.NR + 3) / 4 * 4);
     s.up4 = (uint32_t *)take(4 * P.NLA);
     s.pre = (int *)take(4 * P.NLA); s.wtot = (int *)take(4 * 16);
+    s.mark = (uint8_t *)take((size_t)P.NLA * (kCap - 1) + 8); s.bound = (uint16_t *)take(2 * ((size_t)P.NLA * (kCap - 1) / 64 + 8));
     s.nc = (int *)take(4 * P.NLA); s.seed = (float *)take(4 * P.NLA); s.wtail = (float *)take(4 * 32); s.hz = (float *)take(4 * 4);
     if (P.rec) {
         s.or0 = (uint32_t *)take(4 * kMaxCross * P.NLA); s.or1 = (uint32_t *)take(4 * kMaxCross * P.NLA);
@@ -391,18 +428,17 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         s.len[q] = in ? P.lane_len[q] : 1.0f; s.node[q] = in ? P.lane_node[q] : -1; s.vmax[q] = in ? P.lane_vmax[q] : 1.0f;
     }
     for (int q = l; q < NLP; q += blockDim.x) { s.wave[q] = 0; s.halt[q] = 0; s.hwait[q] = 0; }
+    if constexpr (HELP) {                           // flat-phase marks: all clear (a second sets and clears its own)
+        uint32_t *mk = (uint32_t *)s.mark;
+        for (int q = l; q < (NLA * (kCap - 1) + 8) / 4; q += blockDim.x) mk[q] = 0u;
+    }
     // publishes a lane's summary for the next second; with HELP also the wave-local inclusive scan of the number
     // of queued vehicles (slots >= 1) that phase A1 distributes over the workgroup
     auto publish = [&]() {
         if (!lthr) return;
         s.n[l] = n; s.hx[l] = hx; s.hv[l] = hv; s.hm[l] = hm; s.tx[l] = tx; s.tv[l] = tv;
         if constexpr (HELP) {
-            int inc = n > 1 ? n - 1 : 0;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int up = __shfl_up(inc, d, 64);
-                if ((l & 63) >= d) inc += up;
-            }
+            const int inc = wave_scan_add(n > 1 ? n - 1 : 0);
             s.pre[l] = inc;
             if ((l & 63) == 63) s.wtot[l >> 6] = inc;
         }
@@ -439,6 +475,24 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 if (vn < kHalt && xn >= origin) ++rq_halt;
             }
         };
+        if constexpr (HELP) {
+            // flat order of the queued vehicles (slots >= 1) of the instance, lane after lane: this lane's first flat index P0
+            // (wave-local inclusive scan from publish() + the totals of the lane wavefronts before mine), a mark at P0 and the
+            // owner of the one multiple of 64 its <= 27 vehicles can cover -- what the flat phase needs to turn a flat index
+            // into (lane, slot) with one LDS read, a wavefront max-scan and one more read (a 6-step binary search per vehicle
+            // before round 4)
+            if (lthr) {
+                const int c = n > 1 ? n - 1 : 0;
+                int P0 = s.pre[l] - c;
+                for (int w = 0; w < (l >> 6); ++w) P0 += s.wtot[w];
+                s.pre[l] = P0;
+                if (c > 0) {
+                    s.mark[P0] = (uint8_t)((l & 63) + 1);
+                    const int m64 = (P0 + c - 1) & ~63;
+                    if (m64 >= P0) s.bound[m64 >> 6] = (uint16_t)(l + 1);
+                }
+            }
+        }
         if (lane) {
             int ncross = 0;
             bool all_crossed = true;
@@ -670,22 +724,35 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     vn[u] = a[u] = 0.0f; key[u] = loc[u] = INFINITY; run0[u] = true;
                 }
                 if (wave_on) {
+                    // flat index -> (lane, slot): the owner of index k is the last lane whose mark lies at or before k.  Marks hold
+                    // the lane's index within its wavefront (a byte); the wavefront comes from the segment the index falls into, so
+                    // the owners are increasing along the flat order and a prefix maximum finds them.
+                    int kks[kF], val[kF];
     #pragma unroll
                     for (int u = 0; u < kF; ++u) {
                         const int k = base + kF * l + u;
                         act[u] = k < total;
-                        int w = 0, kk = act[u] ? k : total - 1;       // clamped: locate and load unconditionally
+                        const int kk = act[u] ? k : total - 1;        // clamped: locate and load unconditionally
+                        kks[u] = kk;
+                        int w = 0, kr = kk;
                         for (; w < nseg - 1; ++w) {
                             const int c = s.wtot[w];
-                            if (kk < c) break;
-                            kk -= c;
+                            if (kr < c) break;
+                            kr -= c;
                         }
-                        const int *pre = s.pre + (w << 6);
-                        int lo = 0;                                   // smallest j with pre[j] > kk
+                        const int m = (int)s.mark[kk];
+                        val[u] = m ? (w << 6) + m : 0;
+                    }
+                    int lmax[kF], rmax = 0;
     #pragma unroll
-                        for (int st = 32; st; st >>= 1) if (pre[lo + st - 1] <= kk) lo += st;
-                        const int q = (w << 6) + lo;
-                        const int i = kk - (lo ? pre[lo - 1] : 0) + 1;
+                    for (int u = 0; u < kF; ++u) { rmax = max(rmax, val[u]); lmax[u] = rmax; }
+                    const int incl = wave_scan_max(rmax);
+                    int excl = TSC_DPP_I(0, incl, kDppWaveShr1, 0xF);                      // lanes before me; lane 0: none
+                    excl = max(excl, (int)s.bound[(base >> 6) + kF * (l >> 6)]);            // owner of this wavefront's first index
+    #pragma unroll
+                    for (int u = 0; u < kF; ++u) {
+                        const int q = max(lmax[u], excl) - 1;
+                        const int i = kks[u] - s.pre[q] + 1;
                         eq[u] = q; ei[u] = i;
                         const unsigned ob = (unsigned)(i * NLP + q) * 4u, pb = ob - (unsigned)NLP * 4u;
                         x[u] = ldg(X, ob); v[u] = ldg(V, ob); sf[u] = ldg(SF, ob); m[u] = ldg(M, ob);
@@ -720,14 +787,9 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     // segmented inclusive min-scan of the threads' last runs over the wavefront
                     float sv = run;
                     int sfl = (!first_run || ei[0] == 1) ? 1 : 0;
-    #pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        const float ov = __shfl_up(sv, d, 64);
-                        const int of = __shfl_up(sfl, d, 64);
-                        if (wl >= d && !sfl) { sv = fminf(sv, ov); sfl |= of; }
-                    }
-                    pvs = __shfl_up(sv, 1, 64);
-                    pfs = __shfl_up(sfl, 1, 64);
+                    wave_seg_scan_min(sv, sfl);
+                    pvs = TSC_DPP_F(sv, sv, kDppWaveShr1, 0xF);       // lane 0 keeps its own value (not read: its carry is the
+                    pfs = TSC_DPP_I(sfl, sfl, kDppWaveShr1, 0xF);     // previous wavefront's tail)
                     if (wl == 63) s.wtail[(round & 1) * 16 + wv] = sv;
                 }
                 if (l == (int)blockDim.x - 1) { s.hz[2] = x[kF - 1]; s.hz[3] = v[kF - 1]; }
@@ -760,6 +822,10 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             TSC_STAMP();
             __syncthreads();
             TSC_STAMP();
+            {   // this second's marks all lie below `total`: clear them for the next one (which sets its own after the next barrier)
+                uint32_t *mk = (uint32_t *)s.mark;
+                for (int q = l; q < (total + 3) / 4; q += blockDim.x) mk[q] = 0u;
+            }
         }
         // ================= phase B (K3): gather hand-offs from feeder lanes, then demand =========
         if (lane) {
