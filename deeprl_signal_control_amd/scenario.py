@@ -99,6 +99,8 @@ class Scenario:
     reward_scale_realnet: bool = False
     teleport_sec: int = 600          # --time-to-teleport (env.py:281-284)
     extra: Dict = field(default_factory=dict)
+    link_foes: np.ndarray = None     # u32 [A, KMAX] bit k2 of row (a, k): the path of signal link k2 crosses or joins the path of link k
+                                     # inside the junction (junction interiors, DESIGN.md 3 rule 10); None = no junction has foes
     lane_origin: np.ndarray = None   # f32 [NL] where the SUMO lane of that name begins inside the compiled lane (0 unless
                                      # contract_chains merged upstream pieces into it): `lane.*` TraCI getters count from here
 
@@ -113,6 +115,8 @@ class Scenario:
     def __post_init__(self):
         if self.lane_origin is None:
             self.lane_origin = np.zeros(len(self.lane_names), np.float32)
+        if self.link_foes is None:
+            self.link_foes = np.zeros(np.asarray(self.link_lane).shape, np.uint32)
 
     @property
     def n_stream(self) -> int:
@@ -317,6 +321,32 @@ def _signal_tables(phases_per_agent, kmax):
 # ---------------------------------------------------------------------------
 _APPROACH = ('N', 'E', 'S', 'W')          # SUMO link order: incoming edges clockwise from north
 _RIGHT, _THROUGH, _LEFT = 0, 1, 2
+
+
+def four_leg_foes():
+    """Foe links of a four-leg junction whose 12 signal links are ordered like netconvert orders them (and like
+    LARGE_GRID_PHASES reads, envs/large_grid_env.py:40-41): legs clockwise from north, per leg right / through / left.
+    Put every leg's incoming and outgoing side on a circle (clockwise: in, out; right-hand traffic): a movement is the
+    chord from its leg's `in` to its target leg's `out`; two movements from different legs are foes when their chords cross
+    or end on the same leg.  -> u32 [12] bit masks."""
+    def chord(k):
+        leg, turn = divmod(k, 3)
+        out = (leg + (3, 2, 1)[turn]) % 4                # right / through / left
+        return leg, out
+    def between(a, b, x):                                # x strictly inside the clockwise arc a -> b
+        return 0 < (x - a) % 8 < (b - a) % 8
+    foes = np.zeros(12, np.uint32)
+    for k in range(12):
+        li, lo = chord(k)
+        a, b = 2 * li, 2 * lo + 1
+        for k2 in range(12):
+            mi, mo = chord(k2)
+            if mi == li:
+                continue
+            c, d = 2 * mi, 2 * mo + 1
+            if mo == lo or (between(a, b, c) != between(a, b, d)):
+                foes[k] |= np.uint32(1 << k2)
+    return foes
 
 
 def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: int = 925,
@@ -585,7 +615,7 @@ def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: in
         route_names=route_names,
         agent_lanes=agent_lanes, agent_nlane=np.array(nlane, np.int32),
         agent_nlink=np.full(N * N, 12, np.int32), agent_nphase=np.array(n_a_ls, np.int32),
-        link_lane=link_lane, phases=[LARGE_GRID_PHASES] * (N * N),
+        link_lane=link_lane, phases=[LARGE_GRID_PHASES] * (N * N), link_foes=np.tile(four_leg_foes(), (N * N, 1)),
         green_tab=green, yellow_tab=yellow,
         neighbors=neighbors, n_s_ls=n_s, n_w_ls=n_w, n_f_ls=n_f, n_a_ls=n_a_ls,
         obs_kind=obs_kind, obs_src=obs_src, flows=flows, obs_len=lens,
@@ -747,6 +777,11 @@ def build_real_net(agent: str = 'ma2c', flow_rate: int = 325, sort_lanes: bool =
     if agent not in ('greedy', 'a2c'):
         assert lens == n_s
     green, yellow = _signal_tables(phases, kmax)
+    link_foes = np.zeros((A, kmax), np.uint32)              # the junctions' own right-of-way matrices (tools/compile_real_net.py)
+    for a, n in enumerate(node_names):
+        for k, fo in d.get('foes', {}).get(n, {}).items():
+            for k2 in fo:
+                link_foes[a, int(k)] |= np.uint32(1 << int(k2))
     flows = np.array([[b, e, flow_rate, r] for r, b, e in d['flows']], np.int32)
     kw = dict(objective='queue', coef_wait=0.0, norm_wait=30.0, has_wait_state=False, queue_cap=10,
               reward_scale_realnet=True, teleport_sec=300)
@@ -760,7 +795,7 @@ def build_real_net(agent: str = 'ma2c', flow_rate: int = 325, sort_lanes: bool =
         route_names=[(p[0], p[-1]) for p in routes],
         agent_lanes=agent_lanes, agent_nlane=np.array(nlane, np.int32),
         agent_nlink=np.array([len(p[0]) for p in phases], np.int32), agent_nphase=np.array(n_a_ls, np.int32),
-        link_lane=link_lane, phases=phases, green_tab=green, yellow_tab=yellow,
+        link_lane=link_lane, phases=phases, green_tab=green, yellow_tab=yellow, link_foes=link_foes,
         neighbors=neighbors, n_s_ls=n_s, n_w_ls=n_w, n_f_ls=n_f, n_a_ls=n_a_ls,
         obs_kind=obs_kind, obs_src=obs_src, flows=flows, obs_len=lens,
         extra={'flow_rate': flow_rate, 'routes': routes}, **kw)

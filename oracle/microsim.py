@@ -43,6 +43,9 @@ def lib():
         L.ms_network_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
         L.ms_set_streams.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, ip, fp, fp, ip, ip]
         L.ms_set_stream_routes.argtypes = [C.c_void_p, ip]
+        L.ms_set_box.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_double]
+        L.ms_box_count.argtypes = [C.c_void_p]
+        L.ms_box_count.restype = C.c_int64
         _LIB = L
     return _LIB
 
@@ -91,6 +94,13 @@ class MicroSim:
             r = _i(stream_routes)
             self.L.ms_set_stream_routes(self.h, r.ctypes.data_as(C.POINTER(C.c_int32)))
         self.L.ms_reset(self.h, int(seed) & 0xFFFFFFFF)
+
+    def set_box(self, p):
+        """EXPERIMENT (not the spec): a head with an open signal and a full target lane stands in the junction
+        (with probability p, drawn per vehicle) and blocks its foe links (Scenario.link_foes); 0 switches it off."""
+        foes = np.ascontiguousarray(self.scn.link_foes, np.uint32)
+        assert foes.shape == (self.scn.n_agent, self.kmax)
+        self.L.ms_set_box(self.h, foes.ctypes.data_as(C.POINTER(C.c_uint32)), float(p))
 
     def set_links(self, agent, chars):
         if isinstance(chars, str):

@@ -116,6 +116,25 @@ def main():
     for node, link, lane, _ in all_tl:                    # signal link -> incoming lane (getControlledLanes)
         if node in nodes:
             out['tl_links'][node][str(link)] = lane
+    # foes (round 4, junction interiors): signal link k of a node -> the links whose paths cross or join its path inside the
+    # junction, from the junction's own right-of-way matrix (<request index foes>); the request index of a connection is the
+    # position of its internal `via` lane in the junction's intLanes list
+    junc = {}
+    for j in root:
+        if j.tag == 'junction' and j.get('intLanes'):
+            junc[j.get('id')] = dict(int_lanes=j.get('intLanes').split(),
+                                     foes={int(r.get('index')): r.get('foes') for r in j if r.tag == 'request'})
+    via_of = {}                                            # (tl node, link) -> (junction, request index)
+    for c in root:
+        if c.tag == 'connection' and c.get('tl') in nodes and c.get('via'):
+            jid = c.get('via')[1:].rsplit('_', 2)[0]
+            if jid in junc and c.get('via') in junc[jid]['int_lanes']:
+                via_of[(c.get('tl'), int(c.get('linkIndex')))] = (jid, junc[jid]['int_lanes'].index(c.get('via')))
+    out['foes'] = {n: {} for n in nodes}
+    for (node, link), (jid, q) in sorted(via_of.items()):
+        bits = junc[jid]['foes'].get(q, '')
+        foe_req = {i for i, ch in enumerate(reversed(bits)) if ch == '1'}
+        out['foes'][node][str(link)] = sorted(k2 for (n2, k2), (j2, q2) in via_of.items() if n2 == node and j2 == jid and q2 in foe_req and k2 != link)
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     with open(OUT, 'w') as fh:
         json.dump(out, fh, separators=(',', ':'))
