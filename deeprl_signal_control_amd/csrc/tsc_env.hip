@@ -492,6 +492,10 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     if (m64 >= P0) s.bound[m64 >> 6] = (uint16_t)(l + 1);
                 }
             }
+            // From here on the lane wavefronts walk their heads (phase H) while every other wavefront already starts the flat
+            // phase's first half (locate, load, car-following: old state only) -- the two only meet at the barrier in front of
+            // the chain keys (round 4; before, all helper wavefronts idled through phase H).
+            __syncthreads();
         }
         if (lane) {
             int ncross = 0;
@@ -685,7 +689,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             s.nout[l] = nsent;
         }
         TSC_STAMP();
-        __syncthreads();
+        if constexpr (!HELP) __syncthreads();          // (HELP: the barrier sits inside the flat phase, behind its first half)
         TSC_STAMP();
         // ================= phase F (K2, HELP): every vehicle behind the first stayer, one per thread slot =============
         // Nobody behind a vehicle that stays can cross, so such a vehicle's new speed depends only on OLD state (itself, the
@@ -701,7 +705,9 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             int total = 0;
             for (int w = 0; w < nseg; ++w) total += s.wtot[w];
             constexpr int kF = KF;
-            const int wv = l >> 6, wl = l & 63, nwv = (int)blockDim.x >> 6;
+            // flat-phase thread index: rotated so that the lane wavefronts (busy with phase H first) own the LAST flat indices
+            const int lf = (int)blockDim.x > NLA ? (l >= NLA ? l - NLA : l + ((int)blockDim.x - NLA)) : l;
+            const int wv = lf >> 6, wl = lf & 63, nwv = (int)blockDim.x >> 6;
             int round = 0;
             for (int base = 0; base < total; base += kF * (int)blockDim.x, ++round) {
                 const float carry_round = round > 0 ? s.wtail[((round - 1) & 1) * 16 + nwv - 1] : INFINITY;
@@ -709,7 +715,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 // keeps the barrier.  The kernel is VALU-issue bound and the four workgroups of a CU share its SIMDs, so the
                 // ~600 instructions such a wave would run on clamped indices are real time for the others (on average half a
                 // super-round: 17-25 % of the phase at 2-3 super-rounds).
-                const bool wave_on = base + kF * (int)((unsigned)l & ~63u) < total;
+                const bool wave_on = base + kF * (int)((unsigned)lf & ~63u) < total;
                 int eq[kF], ei[kF];
                 float x[kF], v[kF], sf[kF], px[kF], pv[kF];
                 uint32_t m[kF];
@@ -730,7 +736,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     int kks[kF], val[kF];
     #pragma unroll
                     for (int u = 0; u < kF; ++u) {
-                        const int k = base + kF * l + u;
+                        const int k = base + kF * lf + u;
                         act[u] = k < total;
                         const int kk = act[u] ? k : total - 1;        // clamped: locate and load unconditionally
                         kks[u] = kk;
@@ -748,7 +754,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     for (int u = 0; u < kF; ++u) { rmax = max(rmax, val[u]); lmax[u] = rmax; }
                     const int incl = wave_scan_max(rmax);
                     int excl = TSC_DPP_I(0, incl, kDppWaveShr1, 0xF);                      // lanes before me; lane 0: none
-                    excl = max(excl, (int)s.bound[(base >> 6) + kF * (l >> 6)]);            // owner of this wavefront's first index
+                    excl = max(excl, (int)s.bound[(base >> 6) + kF * (lf >> 6)]);           // owner of this wavefront's first index
     #pragma unroll
                     for (int u = 0; u < kF; ++u) {
                         const int q = max(lmax[u], excl) - 1;
@@ -758,9 +764,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                         x[u] = ldg(X, ob); v[u] = ldg(V, ob); sf[u] = ldg(SF, ob); m[u] = ldg(M, ob);
                         px[u] = ldg(X, pb); pv[u] = ldg(V, pb);
                     }
-                    if (round > 0 && l == 0 && ei[0] > 1) { px[0] = s.hz[0]; pv[0] = s.hz[1]; }   // overwritten by the previous super-round
-                    float run = INFINITY;
-                    bool first_run = true;
+                    if (round > 0 && lf == 0 && ei[0] > 1) { px[0] = s.hz[0]; pv[0] = s.hz[1]; }   // overwritten by the previous super-round
     #pragma unroll
                     for (int u = 0; u < kF; ++u) {
                         const int q = eq[u];
@@ -777,6 +781,17 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                         float aa = x[u] + vv;
                         if (aa > Lq) aa = Lq;
                         a[u] = aa;
+                    }
+                }
+                // ---- everything above used OLD state only; what follows needs phase H's results (nc, seed) of this second
+                if (round == 0) __syncthreads();
+                if (wave_on) {
+                    float run = INFINITY;
+                    bool first_run = true;
+    #pragma unroll
+                    for (int u = 0; u < kF; ++u) {
+                        const int q = eq[u];
+                        const float aa = a[u];
                         const bool live = act[u] && ei[u] > s.nc[q];
                         act[u] = live;
                         key[u] = live ? aa + (float)(5 * ei[u]) : INFINITY;
@@ -792,9 +807,9 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     pfs = TSC_DPP_I(sfl, sfl, kDppWaveShr1, 0xF);     // previous wavefront's tail)
                     if (wl == 63) s.wtail[(round & 1) * 16 + wv] = sv;
                 }
-                if (l == (int)blockDim.x - 1) { s.hz[2] = x[kF - 1]; s.hz[3] = v[kF - 1]; }
+                if (lf == (int)blockDim.x - 1) { s.hz[2] = x[kF - 1]; s.hz[3] = v[kF - 1]; }
                 __syncthreads();
-                if (l == 0) { s.hz[0] = s.hz[2]; s.hz[1] = s.hz[3]; }       // read by thread 0 after the next barrier only
+                if (lf == 0) { s.hz[0] = s.hz[2]; s.hz[1] = s.hz[3]; }      // read by flat thread 0 after the next barrier only
                 const float prev_tail = wv > 0 ? s.wtail[(round & 1) * 16 + wv - 1] : carry_round;
                 const float carry = ei[0] > 1 ? (wl == 0 ? prev_tail : (pfs ? pvs : fminf(pvs, prev_tail))) : INFINITY;
 #pragma unroll
