@@ -119,5 +119,9 @@ def test_bench_two_ranks_one_gpu():
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     d = json.loads(line)
-    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0
-    assert d['config']['envs_per_gpu'] == 64 and 'RCCL' in d['config']['workload'] or 'all-reduce' in d['config']['workload']
+    assert d['n_gpus'] == 2 and d['scaling'] == 'weak' and d['value'] > 0 and d['steps'] == 1 and d['warmup'] == 1
+    assert d['config']['envs_per_gpu'] == 64 and 'all-reduce' in d['config']['workload']
+    assert d['config']['parallelism'].startswith('env-sharded x2')
+    # whole-job figure: agents x instances of BOTH ranks x simulated seconds / the slower rank's time
+    assert abs(d['value'] - 25 * 64 * 2 * 120 * 5 / (d['ms_per_step'] * 1e-3)) <= 1e-6 * d['value']
+    assert 'cpu_baseline' not in d and 'configs' not in d.get('extra', {})          # N = 1 only

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Bench lines + rocprofv3 kernel traces of the other BASELINE configs (c2: IA2C FC 256 envs, c5: Monaco MA2C 512 envs),
-# on the GPU box (run through gpurun from the repo root):   tools/profile_configs.sh r03
+# on the GPU box (run through gpurun from the repo root):   tools/profile_configs.sh r04
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT

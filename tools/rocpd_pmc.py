@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Fold rocprofv3 --pmc passes (rocpd SQLite databases, one counter set per pass) into the per-kernel
-HBM traffic table bench.py reads (profiles/r01_pmc.json) and, for an SQ pass, a utilisation CSV.
+HBM traffic table bench.py reads (profiles/rNN_pmc.json) and, for an SQ pass, a utilisation CSV.
 
-    python tools/rocpd_pmc.py traffic gpurun_out/pmc_fetch/*.db gpurun_out/pmc_write/*.db profiles/r01_pmc.json
+    python tools/rocpd_pmc.py traffic gpurun_out/pmc_fetch/*.db gpurun_out/pmc_write/*.db profiles/rNN_pmc.json
     python tools/rocpd_pmc.py sq gpurun_out/pmc_sq/*.db profiles/r01_pmc_sq.csv
 
 FETCH_SIZE / WRITE_SIZE are rocprofv3's derived counters (KB per dispatch, from the L2's memory-side request
@@ -13,7 +13,7 @@ import json
 import sqlite3
 import sys
 
-NAMES = [('step_kernel', 'env_step'), ('head_bwd2_reduce', 'dwo_gemm'), ('head_bwd2', 'head_bwd'), ('register_order', 'register_order'),
+NAMES = [('step_kernel', 'env_step'), ('fc_bwd_reduce', 'dw1_gemm'), ('fc_bwd_kernel', 'dx1_gemm'), ('policy_fwd_fc_mfma', 'policy_fwd_fused'), ('head_bwd2_reduce', 'dwo_gemm'), ('head_bwd2', 'head_bwd'), ('register_order', 'register_order'),
          ('grad_norm_fold', 'grad_norm'), ('policy_fwd_fused', 'policy_fwd_fused'), ('policy_fwd_ws', 'policy_fwd_fused'), ('dwxh_kernel', 'dwx_gemm'),
          ('dx1w1_kernel', 'dx1_gemm'), ('lstm_bwd', 'lstm_bwd'), ('lstm_fwd', 'lstm_fwd'), ('head_bwd', 'head_bwd'),
          ('head_fwd', 'head_fwd'), ('add_transition', 'add_transition'), ('dwxh_reduce', 'dwh_gemm'),
