@@ -368,7 +368,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     const int act = action[(size_t)e * P.A + ac];
     const int prev = P.prev_action[(size_t)e * P.A + ac];
     int n = P.N[(size_t)e * NLP + lc];
-    float L = P.lane_len[lc], vmax = P.lane_vmax[lc], det = P.lane_det[lc];
+    float L_ = P.lane_len[lc], vmax_ = P.lane_vmax[lc], det = P.lane_det[lc];
     int my_node = P.lane_node[lc];
     int up0 = P.lane_up[lc * kMaxUp], up1 = P.lane_up[lc * kMaxUp + 1], up2 = P.lane_up[lc * kMaxUp + 2], up3 = P.lane_up[lc * kMaxUp + 3];
     uint32_t myr_lo = P.lane_routes[lc * 2], myr_hi = P.lane_routes[lc * 2 + 1];     // entry routes, a byte each
@@ -377,7 +377,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     const int rc = l < NS ? l : NS - 1;
     const int pend0 = P.pending[(size_t)e * NS + rc], ser0 = P.serial[(size_t)e * NS + rc];
     if (!lane) {
-        n = 0; L = 1.0f; vmax = 1.0f; det = 0.0f; my_node = -1; up0 = up1 = up2 = up3 = -1;
+        n = 0; L_ = 1.0f; vmax_ = 1.0f; det = 0.0f; my_node = -1; up0 = up1 = up2 = up3 = -1;
         myr_lo = myr_hi = 0xFFFFFFFFu;
     }
     // table copies: four (clamped, unconditional) loads in flight per thread and round instead of one
@@ -498,6 +498,8 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             __syncthreads();
         }
         if (lane) {
+            // lane constants from LDS per phase (HELP): two registers less across the flat phase than holding them for the launch
+            const float L = HELP ? s.len[l] : L_, vmax = HELP ? s.vmax[l] : vmax_;
             int ncross = 0;
             bool all_crossed = true;
             float pnx = INFINITY, pox = 0.0f, pov = 0.0f;
@@ -538,7 +540,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 const int tl = mv_tl(mvp), k = mv_k(mvp), y = mv_yield(mvp), z = s.zip[l * NR + r];
                 const float v0 = vmax * sf;
                 const bool sink = tl == -1;
-                const bool open = sig_open(tl, k, my_node, w, x, v, L, link, P.KMAX, P.teleport);
+                const bool open = sig_open(tl, k, HELP ? s.node[l] : my_node, w, x, v, L, link, P.KMAX, P.teleport);
                 bool can_cross = false;
                 if (all_crossed) {
                     can_cross = open;
@@ -856,8 +858,12 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 }
             }
             n = kept;
+            uint32_t ups = 0xFFFFFFFFu;
+            if constexpr (SPEC > 0) ups = s.up4[l];          // the feeders as bytes (0xFF = none): four registers less across the flat phase
             for (int u = 0; u < kMaxUp; ++u) {
-                const int src = u == 0 ? up0 : u == 1 ? up1 : u == 2 ? up2 : up3;
+                int src;
+                if constexpr (SPEC > 0) { src = (int)((ups >> (8 * u)) & 0xFFu); if (src == 0xFF) src = -1; }
+                else src = u == 0 ? up0 : u == 1 ? up1 : u == 2 ? up2 : up3;
                 if (src < 0) continue;
                 const int cnt = s.nout[src];
                 for (int j = 0; j < cnt; ++j) {
@@ -887,6 +893,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 int pend = s.pend[r] + (int)s.emit[r * 8 + sub];
                 int ser = s.ser[r];
                 if (pend > 0 && n < kCap) {
+                    const float L = HELP ? s.len[l] : L_;
                     const float xt = n > 0 ? tx : (L + kLen) + kS0;
                     float xmax = (xt - kLen) - kS0;
                     float xlo = kLen;
