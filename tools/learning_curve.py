@@ -23,7 +23,7 @@ import numpy as np          # noqa: E402
 import torch                # noqa: E402
 
 
-def run(episodes, n_env, scenario='large_grid', agent='ma2c', seed=0, lr=None, log=None):
+def run(episodes, n_env, scenario='large_grid', agent='ma2c', seed=0, lr=None, log=None, policy='lstm'):
     from deeprl_signal_control_amd.agents import VecA2C
     from deeprl_signal_control_amd.env import VecTrafficEnv
     from deeprl_signal_control_amd.scenario import build_scenario
@@ -37,7 +37,7 @@ def run(episodes, n_env, scenario='large_grid', agent='ma2c', seed=0, lr=None, l
         mcfg['lr_init'] = lr
     env = VecTrafficEnv(scn, n_env, device=0, seed=seed0)
     model = VecA2C(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, scn.n_f_ls, n_env, scn.s_max, int(scn.green_tab.shape[1]), mcfg,
-                   device=0, seed=seed, name=agent)
+                   device=0, seed=seed, name=agent, policy=policy)
     tr = VecTrainer(env, model, log_rewards=True)
     rows = []
     T = int(env.T)
@@ -71,11 +71,12 @@ def main():
     ap.add_argument('--scenario', default='large_grid')
     ap.add_argument('--agent', default='ma2c')
     ap.add_argument('--lr', type=float, default=None)
+    ap.add_argument('--policy', default='lstm', choices=['lstm', 'fc'], help='fc = FcACPolicy (ia2c only; BASELINE configs[1])')
     ap.add_argument('--out', default=None)
     args = ap.parse_args()
-    rows = run(args.episodes, args.envs, args.scenario, args.agent, lr=args.lr, log=print)
+    rows = run(args.episodes, args.envs, args.scenario, args.agent, lr=args.lr, log=print, policy=args.policy)
     first, last = np.mean([r['avg_reward'] for r in rows[:5]]), np.mean([r['avg_reward'] for r in rows[-5:]])
-    out = dict(scenario=args.scenario, agent=args.agent, envs=args.envs, episodes=args.episodes,
+    out = dict(scenario=args.scenario, agent=args.agent, policy=args.policy, envs=args.envs, episodes=args.episodes,
                control_steps_per_episode=rows[0]['step'], first5_mean=first, last5_mean=last, rows=rows,
                note='mean over env instances of the per-episode mean global step reward (train_reward.csv avg_reward); '
                     'this repo\'s microsim spec underneath, not SUMO')
