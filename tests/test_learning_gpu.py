@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_ma2c_mean_step_reward_improves():
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import learning_curve
-    rows = learning_curve.run(18, 1024, lr=5e-3)
+    rows, _ = learning_curve.run(18, 1024, lr=5e-3)
     r = np.array([x['avg_reward'] for x in rows])
     assert np.isfinite(r).all() and r[0] < -400                      # an untrained policy is about as good as a random one
     assert r[-4:].mean() > r[:4].mean() + 4.0, r

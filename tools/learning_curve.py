@@ -60,8 +60,13 @@ def run(episodes, n_env, scenario='large_grid', agent='ma2c', seed=0, lr=None, l
         if log:
             log('episode %3d  avg step reward %9.2f  (std over steps %.1f, over instances %.1f)  %.2f s'
                 % (ep, row['avg_reward'], row['std_reward'], row['spread_over_instances'], row['wall_s']))
+    # the reference's evaluation (Trainer.run's test block, utils.py:257-275): every test seed, sampled and argmax policy
+    ev = {pt: tr.evaluate(policy_type=pt) for pt in ('default', 'deterministic')}
+    if log:
+        for pt, rws in ev.items():
+            log('evaluation (%s policy): %s' % (pt, ', '.join('seed %d: %.1f' % (r['test_id'], r['avg_reward']) for r in rws)))
     env.close(); model.close()
-    return rows
+    return rows, ev
 
 
 def main():
@@ -74,10 +79,10 @@ def main():
     ap.add_argument('--policy', default='lstm', choices=['lstm', 'fc'], help='fc = FcACPolicy (ia2c only; BASELINE configs[1])')
     ap.add_argument('--out', default=None)
     args = ap.parse_args()
-    rows = run(args.episodes, args.envs, args.scenario, args.agent, lr=args.lr, log=print, policy=args.policy)
+    rows, ev = run(args.episodes, args.envs, args.scenario, args.agent, lr=args.lr, log=print, policy=args.policy)
     first, last = np.mean([r['avg_reward'] for r in rows[:5]]), np.mean([r['avg_reward'] for r in rows[-5:]])
     out = dict(scenario=args.scenario, agent=args.agent, policy=args.policy, envs=args.envs, episodes=args.episodes,
-               control_steps_per_episode=rows[0]['step'], first5_mean=first, last5_mean=last, rows=rows,
+               control_steps_per_episode=rows[0]['step'], first5_mean=first, last5_mean=last, rows=rows, evaluation=ev,
                note='mean over env instances of the per-episode mean global step reward (train_reward.csv avg_reward); '
                     'this repo\'s microsim spec underneath, not SUMO')
     print('first 5 episodes %.2f -> last 5 episodes %.2f' % (first, last))
