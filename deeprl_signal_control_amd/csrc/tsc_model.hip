@@ -783,10 +783,35 @@ policy_fwd_fc_mfma_kernel(const float *__restrict__ params, Layout lay, const in
         }
         b1v[uu] = P[lay.ob1 + col];
     }
-    for (int i = tid; i < 32 * SMAX; i += 512) {
-        const int r = i / SMAX, c = i % SMAX;
-        const int er = e0 + r < E ? e0 + r : E - 1;
-        Os[c * kFmLd + r] = obs[((long long)er * lay.A + a) * SMAX + c];
+    // heads: thread = (instance tid >> 4, units 4 (tid & 15) .. + 3) -- its slice of Wo (pi tower) and of Wv, requested with the rest
+    const int hc = tid & 15;
+    float hwo[4][kOut], hwv[4], hbo[kOut];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int k = 0; k < kOut; ++k) hwo[u][k] = Pa[lay.oWo + (4 * hc + u) * kOut + k];
+        hwv[u] = Pa[lay.stride + lay.oWo + (4 * hc + u) * kOut];
+    }
+#pragma unroll
+    for (int k = 0; k < kOut; ++k) hbo[k] = Pa[lay.obo + k];
+    const float hbv = Pa[lay.stride + lay.obo];
+    const float b2p = Pa[lay.obl + (tid & 63)], b2v = Pa[lay.stride + lay.obl + (tid & 63)];   // second-layer biases of this thread's column
+    {   // obs tile -> LDS, k-major: all (<= 4, SMAX <= 64) loads of a thread first, then the stores (a load inside the store loop
+        // costs one L2 round trip per iteration)
+        float ovv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + 512 * q, ic = i < 32 * SMAX ? i : 32 * SMAX - 1;
+            const int r = ic / SMAX, c = ic - r * SMAX;
+            const int er = e0 + r < E ? e0 + r : E - 1;
+            ovv[q] = obs[((long long)er * lay.A + a) * SMAX + c];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + 512 * q;
+            const int r = i / SMAX, c = i - r * SMAX;
+            if (i < 32 * SMAX) Os[c * kFmLd + r] = ovv[q];
+        }
     }
     if (SMAX & 1) { if (tid < 32) Os[SMAX * kFmLd + tid] = 0.f; }      // the odd last step multiplies a zero row
     __syncthreads();
@@ -820,9 +845,11 @@ policy_fwd_fc_mfma_kernel(const float *__restrict__ params, Layout lay, const in
         for (int r = 0; r < 16; ++r) P2[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * kFmLd + li] = acc[r];
     }
     __syncthreads();
-    for (int i = tid; i < 2 * 32 * kL; i += 512) {                      // the two K halves + bias, relu
+#pragma unroll
+    for (int q = 0; q < 2 * 32 * kL / 512; ++q) {                       // the two K halves + bias, relu (j = tid & 63 in every iteration)
+        const int i = tid + 512 * q;
         const int t = i >> 11, row = (i >> 6) & 31, j = i & 63, w0 = t * 4 + (j >> 5) * 2, c = j & 31;
-        const float v = (P2[(w0 * 32 + row) * kFmLd + c] + P2[((w0 + 1) * 32 + row) * kFmLd + c]) + Pa[(long long)t * lay.stride + lay.obl + j];
+        const float v = (P2[(w0 * 32 + row) * kFmLd + c] + P2[((w0 + 1) * 32 + row) * kFmLd + c]) + (t ? b2v : b2p);
         X2s[(t * 32 + row) * kFcLdo + j] = fmaxf(v, 0.f);
     }
     __syncthreads();
@@ -846,14 +873,63 @@ policy_fwd_fc_mfma_kernel(const float *__restrict__ params, Layout lay, const in
             }
         }
     }
-    if (tid < 32 && e0 + tid < E) {                     // heads + sampling, one instance per thread
-        float pi[kOut], v;
-        const int na = n_act[a];
-        head_eval(params, lay, a, na, X2s + tid * kFcLdo, X2s + (32 + tid) * kFcLdo, pi, v);
-        const long long idx = (long long)(e0 + tid) * lay.A + a;
-        for (int k = 0; k < lay.AMAX; ++k) pi_out[idx * lay.AMAX + k] = k < kOut ? pi[k] : 0.f;
-        v_out[idx] = v;
-        if (action_out) action_out[idx] = sample_action(pi, na, seed, step, idx);
+    {   // heads + sampling: the 16 lanes of an instance each take four hidden units of both towers, the partial logits meet by
+        // xor-shuffles (one shuffle row of the wavefront per instance), lane 0 of the row finishes (round 4; one thread per
+        // instance walked all 64 units before: a 600-instruction chain on 32 of the 512 threads)
+        const int hr = tid >> 4;
+        const float *xp = X2s + hr * kFcLdo + 4 * hc, *xv = X2s + (32 + hr) * kFcLdo + 4 * hc;
+        float lg[kOut], vv = 0.f;
+#pragma unroll
+        for (int k = 0; k < kOut; ++k) lg[k] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float h = xp[u];
+#pragma unroll
+            for (int k = 0; k < kOut; ++k) lg[k] += h * hwo[u][k];
+            vv += xv[u] * hwv[u];
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+            for (int k = 0; k < kOut; ++k) lg[k] += __shfl_xor(lg[k], o, 64);
+            vv += __shfl_xor(vv, o, 64);
+        }
+        // softmax + np.random.choice, one action per lane of the instance's row (lane k < 8 of the 16): one exp, one division and one
+        // float64 division per lane instead of eight of each on one lane; every sum keeps its sequential order (the row gathers
+        // the eight terms by shuffles and adds them left to right), so pi and the sampled action are what the one-lane code gave
+        const int na = n_act[a], km = hc & 7, row0 = (tid & 63) & ~15;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < kOut; ++k) { lg[k] += hbo[k]; if (k < na && lg[k] > mx) mx = lg[k]; }
+        float lgm = lg[0];
+#pragma unroll
+        for (int k = 1; k < kOut; ++k) lgm = km == k ? lg[k] : lgm;
+        const float pk = km < na ? expf(lgm - mx) : 0.f;
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < kOut; ++k) sum += __shfl(pk, row0 + k, 64);
+        const float pim = pk / sum;
+        double sacc = 0.0, mine = 0.0;                   // cdf = cumsum(p) in float64, left to right (numpy)
+#pragma unroll
+        for (int k = 0; k < kOut; ++k) {
+            const float pj = __shfl(pim, row0 + k, 64);
+            if (k < na) sacc += (double)pj;
+            if (k == km) mine = sacc;
+        }
+        const long long idx = (long long)(e0 + hr) * lay.A + a;
+        const unsigned long long hh = splitmix64(splitmix64(seed ^ (step * 0xD1B54A32D192ED03ull)) + (unsigned long long)idx);
+        const double uu = (double)(hh >> 11) * (1.0 / 9007199254740992.0);
+        const bool below = hc < 8 && km < na && uu < mine / sacc;          // searchsorted(cdf / cdf[-1], u, 'right'): first k with u < cdf_k
+        const unsigned long long bal = __ballot(below);
+        const unsigned rowbits = (unsigned)((bal >> row0) & 0xFFull);
+        const int ans = rowbits ? __ffs((int)rowbits) - 1 : na - 1;
+        if (e0 + hr < E) {
+            if (hc < 8 && km < lay.AMAX) pi_out[idx * lay.AMAX + km] = pim;
+            if (hc == 0) {
+                v_out[idx] = vv + hbv;
+                if (action_out) action_out[idx] = ans;
+            }
+        }
     }
 }
 
