@@ -17,8 +17,10 @@
 // control step (2 yellow + 3 green simulated seconds, detectors, obs, reward) is a single launch.  Per
 // simulated second: phase H (lane threads: the platoon that crosses and the first vehicle that stays), phase F (all
 // threads: every other queued vehicle in a flat, load-balanced order -- car-following from the old state, the queue
-// constraint as a segmented prefix-min scan over the wavefront), phase B (gather + demand) (see step_kernel).  The
-// reference's large_grid and Monaco run instantiations whose table dimensions are compile-time constants (kSpec).
+// constraint as a segmented prefix-min scan on the wavefront's DPP path; its first half runs on the helper wavefronts
+// WHILE the lane wavefronts are in phase H), phase B (gather + demand) (see step_kernel).  The reference's large_grid
+// and Monaco run instantiations whose table dimensions are compile-time constants (kSpec), with 256, 512 or 1024
+// threads per instance depending on how many instances share a CU (tsc_env_create).
 //
 // Arithmetic is fp32 with one rounding per operation (-ffp-contract=off, IEEE div/sqrt) so the
 // vehicle state is bit-identical to the CPU oracle; obs/reward are computed in float64 exactly
@@ -319,7 +321,7 @@ __global__ void fingerprint_kernel(EnvDev P, const float *pi) {
 //   * lane threads (l < NLA) own one lane each: the head walk (phase H), the gather (phase B);
 //   * with HELP, phase F evaluates the car-following law of every queued vehicle behind the first one that stays with
 //     ALL threads of the workgroup, KF vehicles per thread in a flat, load-balanced order (prefix sum over the lane
-//     counts + a 6-step binary search).  A queued vehicle that is not the head of a platoon crossing in this very
+//     counts; the lane of a flat index from byte marks + a wavefront prefix maximum).  A queued vehicle that is not the head of a platoon crossing in this very
 //     second cannot cross, so its new speed depends only on OLD state (itself, the vehicle ahead, the signal):
 //     min(follow(leader), follow(stop line) if the link is closed).  The walk then only applies the clamps and
 //     the bookkeeping (~50 instructions per vehicle instead of ~500); heads and vehicles right behind a vehicle
@@ -697,11 +699,11 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         // Nobody behind a vehicle that stays can cross, so such a vehicle's new speed depends only on OLD state (itself, the
         // vehicle ahead, the signal) and its new position on the chain clamp x'_i = min(a_i, x'_{i-1} - 5), a_i = min(x_i +
         // v'_i, L).  The clamp is an exclusive prefix-min over the keys a_j + 5 j within a lane (DESIGN.md rule 4): all
-        // queued vehicles of the instance are laid out flat over the workgroup (prefix sum of the lane counts + binary
-        // search), kF consecutive ones per thread, and the chain is a segmented min-scan -- in the thread, then over
-        // the wavefront by shuffles, then across wavefronts through one LDS word per wave (a lane's <= 27 queued
-        // vehicles touch at most two wavefronts).  Replaces the A1 scratch round trip through HBM and the 28-deep
-        // sequential lane walk of round 1.
+        // queued vehicles of the instance are laid out flat over the workgroup (prefix sum of the lane counts, lane marks +
+        // a prefix maximum to find a flat index's lane), kF consecutive ones per thread, and the chain is a segmented
+        // min-scan -- in the thread, then over the wavefront on the DPP path, then across wavefronts through one LDS word
+        // per wave (a lane's <= 27 queued vehicles touch at most two wavefronts).  Replaces the A1 scratch round trip
+        // through HBM and the 28-deep sequential lane walk of round 1.
         if constexpr (HELP) {
             const int nseg = NLA >> 6;
             int total = 0;

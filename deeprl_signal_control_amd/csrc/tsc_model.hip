@@ -23,8 +23,9 @@
 //   update .......... head_bwd2 (persistent, loss gradient + dH + dWo | dbo) -> lstm_bwd2 (Wh^T stationary in registers,
 //                     dc in registers / dh through LDS over the n_step time steps, next step's inputs in flight under the
 //                     MFMAs) -> dwxh (dWx | dWh | dbl, whole tower output in accumulators) -> dx1w1_kernel2 (dX1 in
-//                     registers, chained into dW1 | db1) -> grad_norm -> rmsprop; the FC-policy update on the grouped
-//                     split-K GEMM (tsc_gemm.h)
+//                     registers, chained into dW1 | db1) -> grad_norm -> rmsprop; the FcACPolicy update: head_bwd2 ->
+//                     fc_bwd_kernel (dWfc | dbfc | dW1 | db1 in one pass over the X1 / Hh rows its rollout forward cached;
+//                     the grouped split-K GEMMs of tsc_gemm.h behind TSC_UNFUSED_DX and for other shapes)
 #include "tsc_common.h"
 #include "tsc_gemm.h"
 #include "../../include/tsc.h"
