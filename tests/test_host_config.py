@@ -114,3 +114,36 @@ def test_cli_flags_and_disk_helpers(tmp_path):
 def test_replica_sampling_streams_are_distinct():
     seeds = {replica_sample_seed(12, r, b) for r in range(8) for b in range(2)}
     assert len(seeds) == 16 and replica_sample_seed(12) == 12
+
+
+def test_checkpoint_seed_slot_keeps_its_meaning_per_format():
+    """`counters` of a checkpoint hold the BASE seed since format 2 (every rank / replica re-derives its action
+    stream); files written before (no `format` entry) hold the stream seed the saving rank had derived and are used as is."""
+    from deeprl_signal_control_amd.agents import CKPT_FORMAT, replica_sample_seed, resume_sample_seed
+    assert CKPT_FORMAT >= 2
+    base, s0 = resume_sample_seed(7, CKPT_FORMAT, rank=0, replica=0)
+    assert (base, s0) == (7, 7)                                  # rank 0 / replica 0 keeps the base stream
+    base, s3 = resume_sample_seed(7, CKPT_FORMAT, rank=3, replica=1)
+    assert base == 7 and s3 == replica_sample_seed(7, 3, 1) != 7
+    assert resume_sample_seed(123456789, None, rank=3, replica=1) == (None, 123456789)
+
+
+def test_initial_traffic_draw_handles_streams_with_different_candidate_counts():
+    """draw_stream_routes: one vectorised RandomState.choice when every drawn stream has the same number of candidate sinks (the
+    reference's initial traffic: the legacy stream of 120 scalar draws), a per-stream draw otherwise; candidates come from the
+    stream table, not from scenario extras."""
+    import numpy as np
+    from deeprl_signal_control_amd.scenario import build_large_grid, draw_stream_routes
+    scn = build_large_grid('ma2c', init_density=0.2, sort_lanes=False)
+    m2 = np.nonzero(np.asarray(scn.stream_mode) == 2)[0]
+    r = draw_stream_routes(scn, 12)
+    rs = np.random.RandomState(12)
+    cand = scn.stream_choice[m2, 0, :, 0]
+    want = [int(cand[j, int(rs.choice(int((cand[j] >= 0).sum())))]) for j in range(len(m2))]      # 120 scalar draws
+    assert [int(x) for x in r[m2]] == want
+    scn.extra.pop('sink_routes', None)                          # not needed any more
+    assert np.array_equal(draw_stream_routes(scn, 12), r)
+    scn.stream_choice = scn.stream_choice.copy()
+    scn.stream_choice[m2[0], 0, -1, 0] = -1                     # one stream with a candidate less: the per-stream branch
+    r2 = draw_stream_routes(scn, 12)
+    assert r2[m2[0]] in [int(x) for x in scn.stream_choice[m2[0], 0, :, 0] if x >= 0]

@@ -61,3 +61,31 @@ def test_capacity_limits_are_refused_not_truncated():
     scn.lane_len[0] = 400.0
     with pytest.raises(ValueError, match='split them'):
         scn.check_limits()
+
+
+def test_foe_tables_of_the_junction_experiment():
+    """Scenario.link_foes (DESIGN.md 3 "Junction interiors": data of a round-4 experiment on the CPU oracle, not consumed by the
+    device library).  Four-leg grid junctions: chord crossing over netconvert's link order -- symmetric, no link is its own
+    foe, links of one approach are never foes, a right turn only meets the two streams that join its target, the opposing
+    through streams do not conflict, a permissive left crosses the opposing through.  Monaco: the junctions' own
+    right-of-way matrices (<request foes> of most.net.xml, compiled by tools/compile_real_net.py) -- symmetric as well."""
+    from deeprl_signal_control_amd.scenario import build_large_grid, build_real_net, four_leg_foes
+    f = four_leg_foes()
+    name = [leg + turn for leg in 'NESW' for turn in 'RSL']
+    foes = {name[k]: {name[j] for j in range(12) if (int(f[k]) >> j) & 1} for k in range(12)}
+    for k in range(12):
+        assert not (int(f[k]) >> k) & 1
+        for j in range(12):
+            assert ((int(f[k]) >> j) & 1) == ((int(f[j]) >> k) & 1)
+            if j // 3 == k // 3:
+                assert not (int(f[k]) >> j) & 1
+    assert foes['NR'] == {'ES', 'SL'} and 'SS' not in foes['NS'] and 'SS' in foes['NL'] and 'ES' in foes['NS']
+    lg = build_large_grid('ma2c')
+    assert lg.link_foes.shape == (25, 12) and (lg.link_foes == f[None, :]).all()
+    rn = build_real_net('ma2c')
+    assert rn.link_foes.shape == (rn.n_agent, rn.green_tab.shape[2]) and (rn.link_foes != 0).sum() > 150
+    for a in range(rn.n_agent):
+        for k in range(int(rn.agent_nlink[a])):
+            for j in range(int(rn.agent_nlink[a])):
+                assert ((int(rn.link_foes[a, k]) >> j) & 1) == ((int(rn.link_foes[a, j]) >> k) & 1), (a, k, j)
+            assert not (int(rn.link_foes[a, k]) >> k) & 1
