@@ -1151,7 +1151,7 @@ const char *tsc_profile_name(int32_t id) {
     return (id >= 0 && id < tsc::KID_COUNT) ? names[id] : "";
 }
 
-int tsc_version(void) { return 100; }
+int tsc_version(void) { return 104; }      // 1.04: round 4 (tsc_env_counters, negative arrival = truncated trip in tsc_env_read_trips)
 
 #define UP(field, T, src, count)                                                 \
     do {                                                                         \

@@ -92,7 +92,7 @@ typedef struct tsc_scenario {
 typedef struct tsc_env tsc_env;
 
 const char *tsc_last_error(void);
-int tsc_version(void);
+int tsc_version(void);            /* 100 * major + minor; 104: tsc_env_counters, truncated trips flagged in tsc_env_read_trips */
 
 /* Per-kernel timing with HIP events on the launch stream (bench.py's live roofline figure; the
  * reference has no equivalent).  Off by default; read() synchronises the recorded events.
