@@ -390,7 +390,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=None, help='timed iterations (default 10; 20 for the short iterations of c2 / c5)')
-    ap.add_argument('--warmup', type=int, default=None, help='untimed iterations before (default 4; 10 for c2 / c5)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed iterations before (default 10: a cold device needs ~0.3 s of load to reach its clocks)')
     ap.add_argument('--envs', type=int, default=1024, help='env instances per GPU')
     ap.add_argument('--agent', default='ma2c', choices=['ma2c', 'ia2c'])
     ap.add_argument('--scenario', default='large_grid', choices=['large_grid', 'real_net'])
@@ -414,7 +414,7 @@ def main():
     if args.steps is None:
         args.steps = 20 if short else 10
     if args.warmup is None:
-        args.warmup = 10 if short else 4
+        args.warmup = 10              # (4 until round 4: the first timed iterations of a fresh box then ran 1 % below its steady clock)
     if args.config:
         args.scenario, args.agent, args.policy, args.envs = PRESETS[args.config]
     # the plain driver line (no --config / --envs ... given) also carries the other single-GPU configurations of BASELINE.json
