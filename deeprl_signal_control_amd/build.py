@@ -28,13 +28,31 @@ def stale():
 
 
 def build(force=False, verbose=False):
+    """Compiles every .hip source (one hipcc process per file, side by side) and links libtsc.so.  force=True always
+    recompiles from source -- what __graft_entry__.build() does, so that a box that runs the tests provably built what
+    it tests; force=False reuses a library that is newer than every source (the import-time path of _lib.py)."""
     if not force and not stale():
         return LIB
     extra = os.environ.get('TSC_BUILD_DEFS', '').split()          # measurement builds, e.g. TSC_BUILD_DEFS=-DTSC_STREAM_SC1=1
-    cmd = [HIPCC] + FLAGS + extra + ['-I', os.path.join(HERE, '..', 'include'), '-o', LIB] + sources()
+    objdir = os.path.join(HERE, '_obj')
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in FLAGS if f != '-shared'] + extra + ['-I', os.path.join(HERE, '..', 'include')]
+    jobs = []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + '.o')
+        cmd = [HIPCC] + cflags + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd), file=sys.stderr)
+        jobs.append((cmd, obj, subprocess.Popen(cmd)))
+    for cmd, _, p in jobs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    tmp = LIB + '.tmp%d' % os.getpid()
+    link = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + [o for _, o, _ in jobs]
     if verbose:
-        print(' '.join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+        print(' '.join(link), file=sys.stderr)
+    subprocess.check_call(link)
+    os.replace(tmp, LIB)                                         # a concurrent reader never sees a half-written library
     return LIB
 
 

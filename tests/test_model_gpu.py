@@ -506,21 +506,31 @@ def test_update_bench_shape_T120():
     m.close()
 
 
-@pytest.mark.parametrize('agent,policy,E', [('ma2c', 'lstm', 1024), ('ia2c', 'lstm', 1024), ('ia2c', 'fc', 256)])
-def test_update_benchmarked_batch_E1024_T120(agent, policy, E):
+@pytest.mark.parametrize('scenario,agent,policy,E,T,pick', [
+    ('large_grid', 'ma2c', 'lstm', 1024, 120, None),      # BASELINE configs[2]: first, a four-neighbour and the last agent
+    ('large_grid', 'ma2c', 'lstm', 1024, 120, (7, 12, 20)),      # three other agents (interior four-neighbour ones and an edge)
+    ('large_grid', 'ia2c', 'lstm', 1024, 120, (1, 9, 18)),
+    ('large_grid', 'ia2c', 'fc', 256, 120, (4, 13, 22)),         # BASELINE configs[1]
+    ('real_net', 'ma2c', 'lstm', 512, 40, (6, 18, 25)),           # BASELINE configs[4] per GPU: Monaco, H = 192, n_step 40; agents with n_s 6 / n_a 2, n_a 6, n_s 50
+])
+def test_update_benchmarked_batch_E1024_T120(scenario, agent, policy, E, T, pick):
     """The update AT the benchmarked batch -- E = 1024 distinct instances, T = 120: 122 880 rows per agent-tower, the five
     row splits of dwxh / dx1w1 cover 24 576 rows each, lstm_bwd runs its full grid -- through the rollout path the
     benchmark uses (fused forward, activation cache), for MA2C (H = 224) and IA2C (H = 160: the dwxh<7> / dx1w1<5>
-    instantiations).  The float64 oracle evaluates the first, a four-neighbour and the last agent (six towers: all the
-    CPU can do in seconds); their gradient slices, returns, losses, norms and updated parameters are compared.
+    instantiations).  The float64 oracle evaluates three agents (six towers: all the CPU can do in seconds) -- the first,
+    a four-neighbour and the last one, or the three of `pick`, so that the parametrisations cover different agent
+    indices (every index at once: test_update_at_the_benchmarked_batch_equals_the_replicated_small_batch_for_every_agent); their gradient
+    slices, returns, losses, norms and updated parameters are compared.
     ('ia2c', 'fc', 256): BASELINE configs[1] -- FcACPolicy (agents/policies.py:214-256), 256 instances x 120 steps = 30 720
-    rows per agent-tower through the training-shape forward and the one-pass first / second layer backward (fc_bwd_kernel)."""
+    rows per agent-tower through the training-shape forward and the one-pass first / second layer backward (fc_bwd_kernel).
+    ('real_net', 'ma2c', 512, T = 40): what bench.py --config c5 times (config/config_ma2c_real.ini:1-46): 28 agents,
+    policy_fwd_ws_kernel<128> with 16 tiles per tower over 4 workgroups, dwxh_kernel<8> / dx1w1_kernel2<12> at 20 480
+    rows per tower, heterogeneous action counts (masked logits), reward_norm 1."""
     from deeprl_signal_control_amd import _lib
     from oracle.nets_oracle import OracleA2C
-    T = 120
-    scn, m, _ = _make(agent, E, T, seed=5, policy=policy)
+    scn, m, _ = _make(agent, E, T, seed=5, policy=policy, scenario=scenario)
     A = scn.n_agent
-    sel = [0, 3, A - 1]
+    sel = [0, 3, A - 1] if pick is None else list(pick)
     tw = m.get_tower_params()
     o = OracleA2C([tw[2 * a + k] for a in sel for k in (0, 1)], [m.n_wave_ls[a] for a in sel], [m.n_w_ls[a] for a in sel],
                   [m.n_f_ls[a] for a in sel], [m.n_a_ls[a] for a in sel], E, gamma=m.cfg['gamma'],
@@ -568,8 +578,58 @@ def test_update_benchmarked_batch_E1024_T120(agent, policy, E):
         for k2 in (0, 1):
             for k in op[2 * i + k2]:
                 np.testing.assert_allclose(p[2 * a + k2][k], op[2 * i + k2][k], atol=3e-5, err_msg='param agent=%d %s' % (a, k))
-    print('E=%d T=120 %s %s worst |dg| / max|g|:' % (E, agent, policy), {k: '%.1e' % v for k, v in worst.items()})
+    print('%s E=%d T=%d %s %s agents %s worst |dg| / max|g|:' % (scenario, E, T, agent, policy, sel), {k: '%.1e' % v for k, v in worst.items()})
     m.close()
+
+
+@pytest.mark.parametrize('scenario,E,T', [('large_grid', 1024, 120), ('real_net', 512, 40)])
+def test_update_at_the_benchmarked_batch_equals_the_replicated_small_batch_for_every_agent(scenario, E, T):
+    """Every agent index at the benchmarked batch (the float64 oracle above affords three agents of
+    25 / 28).  The loss is a mean over the batch (agents/policies.py:41-61), so a batch that holds eight shuffled copies of
+    a 128-instance (Monaco: 64-instance) rollout has the gradient of that rollout: the small rollout is inside what the
+    all-agent oracle tests cover (E <= 160), the large one runs the benchmark's grid -- 5 (4) workgroups per tower in the
+    forward, the five row splits of dwxh / dx1w1, lstm_bwd's full grid.  An agent-indexed layout slip that only shows at
+    the large batch moves that agent's slice; the copies sit at shuffled instance indices, so an instance-indexed one
+    moves them all.  Tolerance 2e-5 of each tensor's largest entry (float32 summation order is all that differs)."""
+    from deeprl_signal_control_amd import _lib
+    Es = E // 8
+    scn, ms, _ = _make('ma2c', Es, T, seed=5, scenario=scenario)
+    _, mb, _ = _make('ma2c', E, T, seed=5, scenario=scenario)
+    mb.set_tower_params(ms.get_tower_params())
+    A = scn.n_agent
+    rng = np.random.RandomState(E + T)
+    src = rng.permutation(E) % Es                              # instance e of the large batch is a copy of src[e]
+    ms.reset(); mb.reset()
+    obs, done = _rand_obs(scn, Es, rng), np.ones(Es, np.uint8)
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x[src])).cuda()
+    dn = lambda x: torch.from_numpy(x).cuda()
+    for t in range(T):
+        _, vs, _ = ms.forward_sample(dn(obs), dn(done))
+        _, vb, _ = mb.forward_sample(up(obs), up(done))
+        vs = vs.cpu().numpy()
+        np.testing.assert_allclose(vb.cpu().numpy(), vs[src], atol=2e-6)
+        act = np.stack([rng.randint(0, n, Es) for n in scn.n_a_ls], 1).astype(np.int32)
+        rew = -rng.rand(Es, A) * 3.0 * ms.cfg['reward_norm']
+        dpost = (rng.rand(Es) < 0.05).astype(np.uint8)
+        ms.add_transition(dn(obs), dn(done), dn(act), dn(rew), dn(vs), dn(dpost))
+        mb.add_transition(up(obs), up(done), up(act), up(rew), up(vs), up(dpost))
+        obs, done = _rand_obs(scn, Es, rng), dpost
+    Rs_ = ms.forward(dn(obs), False, 'v').clone()
+    Rb_ = mb.forward(up(obs), False, 'v').clone()
+    np.testing.assert_allclose(Rb_.cpu().numpy(), Rs_.cpu().numpy()[src], atol=2e-6)
+    Rb_.copy_(Rs_[torch.from_numpy(src).cuda()])               # the same bootstrap values on both sides
+    _lib.check(ms._L.tsc_model_compute_grads(ms._h, C.c_void_p(Rs_.data_ptr()), 0.01))
+    _lib.check(mb._L.tsc_model_compute_grads(mb._h, C.c_void_p(Rb_.data_ptr()), 0.01))
+    gs, gb = ms.unpack(ms.grad_tensor().cpu().numpy()), mb.unpack(mb.grad_tensor().cpu().numpy())
+    worst = 0.0
+    for g in range(ms.G):
+        for k in gs[g]:
+            scale = max(float(np.abs(gs[g][k]).max()), 1e-7)
+            err = float(np.abs(gb[g][k] - gs[g][k]).max()) / scale
+            worst = max(worst, err)
+            assert err <= 2e-5, 'agent %d tower %d %s: |dg| / max|g| = %.2e' % (g // 2, g % 2, k, err)
+    print('%s E=%d vs 8 x E=%d, T=%d, all %d agents: worst |dg| / max|g| = %.1e' % (scenario, E, Es, T, A, worst))
+    ms.close(); mb.close()
 
 
 @pytest.mark.parametrize('agent,E,T,use_cache', [('ma2c', 70, 40, True), ('ia2c', 40, 40, True), ('ma2c', 33, 10, False)])

@@ -47,7 +47,8 @@ def _obs(fx, i, E, s_max):
 CASES = [('refnet_ma2c_large', 1, 'api'), ('refnet_ma2c_large', 96, 'slots'), ('refnet_ma2c_large', 1024, 'slots'),
          ('refnet_ia2c_large', 1, 'slots'), ('refnet_ia2c_large', 40, 'api'),
          ('refnet_fc_large', 1, 'api'), ('refnet_fc_large', 33, 'api'), ('refnet_fc_large', 256, 'api'),     # 256 x 120 = BASELINE configs[1]'s batch
-         ('refnet_ma2c_real', 1, 'api'), ('refnet_ma2c_real', 64, 'slots')]
+         ('refnet_ma2c_real', 1, 'api'), ('refnet_ma2c_real', 64, 'slots'),
+         ('refnet_ma2c_real', 512, 'slots')]                      # 512 x 40 = the batch bench.py --config c5 times (BASELINE configs[4] per GPU)
 
 
 @pytest.mark.parametrize('name,E,path', CASES)
