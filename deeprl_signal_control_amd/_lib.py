@@ -42,7 +42,7 @@ _LIB = None
 # every symbol include/tsc.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = ['tsc_last_error', 'tsc_version', 'tsc_profile_enable', 'tsc_profile_reset', 'tsc_profile_read',
            'tsc_profile_name', 'tsc_env_create', 'tsc_env_destroy', 'tsc_env_set_stream',
-           'tsc_env_reset', 'tsc_env_set_stream_routes', 'tsc_env_set_fingerprint', 'tsc_env_bind_fingerprint', 'tsc_env_reward_sum', 'tsc_env_step', 'tsc_env_get_state',
+           'tsc_env_reset', 'tsc_env_set_stream_routes', 'tsc_env_set_greedy', 'tsc_env_greedy_actions', 'tsc_env_set_fingerprint', 'tsc_env_bind_fingerprint', 'tsc_env_reward_sum', 'tsc_env_step', 'tsc_env_get_state',
            'tsc_env_live_vehicles', 'tsc_env_counters', 'tsc_env_debug_clock', 'tsc_env_live_sum', 'tsc_env_record', 'tsc_env_read_record', 'tsc_env_read_trips',
            'tsc_model_create', 'tsc_model_destroy', 'tsc_model_set_stream', 'tsc_model_layout',
            'tsc_model_set_params', 'tsc_model_reset_opt_state', 'tsc_model_debug_read', 'tsc_model_get_params', 'tsc_model_get_opt_state', 'tsc_model_set_opt_state',
@@ -77,6 +77,8 @@ def lib():
     L.tsc_env_reset.argtypes = [vp, C.POINTER(C.c_uint32), vp]
     L.tsc_env_set_stream_routes.argtypes = [vp, _ip]
     L.tsc_env_set_fingerprint.argtypes = [vp, vp]
+    L.tsc_env_set_greedy.argtypes = [vp, C.c_int32, C.c_int32, _ip, _ip, _ip]
+    L.tsc_env_greedy_actions.argtypes = [vp, vp, vp]
     L.tsc_env_bind_fingerprint.argtypes = [vp, vp]
     L.tsc_env_reward_sum.argtypes = [vp, C.POINTER(C.c_double), C.c_int32]
     L.tsc_env_step.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int32]

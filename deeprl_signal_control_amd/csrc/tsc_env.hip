@@ -98,6 +98,11 @@ struct EnvDev {
     int *trips;                    // [E][trip_cap][6]: route, serial, depart, arrival, waiting seconds, waiting count
     int *n_trips;                  // [E]
     unsigned long long *live_acc;  // [E] sum over control steps of the vehicles in the network (window-mean V)
+    // ---- greedy controllers (tsc_env_set_greedy / tsc_env_greedy_actions): candidate flows per agent
+    int GC, GT;                    // candidates per agent (padded), terms per candidate (padded)
+    const int *g_ncand;            // [A]
+    const int8_t *g_term;          // [A][GC][GT] observation index of a term, -1 = end
+    const int *g_action;           // [A][GC] action a winning candidate stands for
 };
 
 __device__ __forceinline__ uint32_t hash32(uint32_t seed, uint32_t route, uint32_t serial, uint32_t stream) {
@@ -315,6 +320,40 @@ __global__ void fingerprint_kernel(EnvDev P, const float *pi) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t tot = (size_t)P.E * P.A * P.PMAX;
     if (i < tot) P.fp[i] = pi[i];                                  // pi[:-1] is applied at gather time
+}
+
+// The reference's greedy controllers (LargeGridController envs/large_grid_env.py:45-60, RealNetController
+// envs/real_net_env.py:78-111, SmallGridController envs/small_grid_env.py:40-55) are one rule over different tables: every
+// candidate sums some of the agent's OWN wave entries in a fixed order, float64, starting from 0 -- `ob[0] + ob[3]`, `wave
+// += ob[j]` per green link in link order, `ob[k]` alone -- and np.argmax keeps the FIRST maximum; the winner stands for an
+// action (the phase itself, or small_grid's STATE_PHASE_MAP entry).  One thread per (instance, agent).
+// The controllers see the env's float64 state, this kernel the float32 observation: a wave entry is a vehicle count over
+// norm_wave, clipped (envs/env.py:439-442), so the count is recovered (rint(ob * norm_wave); exact for counts < 2^20) and
+// the float64 value recomputed with the reference's operations -- ties between candidates then fall as they do in the
+// reference (0.2 + 0.4 > 0.6 in float64, a tie on the float32 values).
+__global__ void __launch_bounds__(256) greedy_kernel(EnvDev P, const float *__restrict__ obs, int *__restrict__ action) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.E * P.A) return;
+    const int a = i % P.A;
+    const float *ob = obs + (size_t)i * P.SMAX;
+    const int8_t *term = P.g_term + (size_t)a * P.GC * P.GT;
+    const float clipf = (float)P.clip_wave;
+    double best = 0.0;
+    int arg = 0;
+    const int nc = P.g_ncand[a];
+    for (int c = 0; c < nc; ++c) {
+        double flow = 0.0;
+        for (int k = 0; k < P.GT; ++k) {
+            const int j = term[c * P.GT + k];
+            if (j < 0) break;
+            const float o = ob[j];
+            double x = rint((double)o * P.norm_wave) / P.norm_wave;
+            if (P.clip_wave >= 0.0 && (x > P.clip_wave || o == clipf)) x = P.clip_wave;
+            flow += x;
+        }
+        if (c == 0 || flow > best) { best = flow; arg = c; }
+    }
+    action[i] = P.g_action[a * P.GC + arg];
 }
 
 // Work decomposition of one workgroup (= one env instance):
@@ -1151,7 +1190,7 @@ const char *tsc_profile_name(int32_t id) {
     return (id >= 0 && id < tsc::KID_COUNT) ? names[id] : "";
 }
 
-int tsc_version(void) { return 104; }      // 1.04: round 4 (tsc_env_counters, negative arrival = truncated trip in tsc_env_read_trips)
+int tsc_version(void) { return 105; }      // 1.05: round 5 (tsc_env_set_greedy / tsc_env_greedy_actions); 1.04: tsc_env_counters, negative arrival = truncated trip
 
 #define UP(field, T, src, count)                                                 \
     do {                                                                         \
@@ -1568,6 +1607,42 @@ int tsc_env_set_fingerprint(tsc_env *h, const float *pi_dev) {
     size_t tot = (size_t)h->P.E * h->P.A * h->P.PMAX;
     tsc::ProfScope ps(tsc::KID_FINGERPRINT, h->stream);
     hipLaunchKernelGGL(fingerprint_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->P, pi_dev);
+    TSC_HIP(hipGetLastError());
+    return 0;
+}
+
+int tsc_env_set_greedy(tsc_env *h, int32_t n_cand_max, int32_t n_term_max, const int32_t *n_cand, const int32_t *term,
+                       const int32_t *cand_action) {
+    if (!h || !n_cand || !term || !cand_action || n_cand_max <= 0 || n_term_max <= 0)
+        return tsc::fail("tsc_env_set_greedy: bad arguments");
+    EnvDev &P = h->P;
+    std::vector<int8_t> t8((size_t)P.A * n_cand_max * n_term_max);
+    for (int a = 0; a < P.A; ++a) {
+        if (n_cand[a] <= 0 || n_cand[a] > n_cand_max) return tsc::fail("tsc_env_set_greedy: agent %d has %d candidates of %d", a, n_cand[a], n_cand_max);
+        for (int c = 0; c < n_cand_max; ++c) {
+            if (c < n_cand[a] && (cand_action[a * n_cand_max + c] < 0 || cand_action[a * n_cand_max + c] >= P.PMAX))
+                return tsc::fail("tsc_env_set_greedy: agent %d candidate %d: action %d of %d", a, c, cand_action[a * n_cand_max + c], P.PMAX);
+            for (int k = 0; k < n_term_max; ++k) {
+                const int j = term[((size_t)a * n_cand_max + c) * n_term_max + k];
+                if (j >= P.SMAX || j > 127) return tsc::fail("tsc_env_set_greedy: agent %d candidate %d: observation index %d of %d", a, c, j, P.SMAX);
+                t8[((size_t)a * n_cand_max + c) * n_term_max + k] = (int8_t)(j < 0 ? -1 : j);
+            }
+        }
+    }
+    (void)hipSetDevice(h->device);
+    TSC_HIP(hipStreamSynchronize(h->stream));                  // a running greedy_kernel may still read the old tables
+    UP(g_ncand, int, n_cand, P.A);
+    UP(g_term, int8_t, t8.data(), t8.size());
+    UP(g_action, int, cand_action, (size_t)P.A * n_cand_max);
+    P.GC = n_cand_max; P.GT = n_term_max;
+    return 0;
+}
+
+int tsc_env_greedy_actions(tsc_env *h, const float *obs_dev, int32_t *action_dev) {
+    if (!h || !obs_dev || !action_dev) return tsc::fail("tsc_env_greedy_actions: bad arguments");
+    if (!h->P.g_ncand) return tsc::fail("tsc_env_greedy_actions: no controller tables (tsc_env_set_greedy)");
+    const int tot = h->P.E * h->P.A;
+    hipLaunchKernelGGL(greedy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->P, obs_dev, action_dev);
     TSC_HIP(hipGetLastError());
     return 0;
 }

@@ -204,6 +204,25 @@ class VecTrafficEnv:
         fn = self._L.tsc_env_bind_fingerprint if zero_copy else self._L.tsc_env_set_fingerprint
         _lib.check(fn(self._h, C.c_void_p(pi.data_ptr())))
 
+    def greedy_actions(self, obs=None, out=None):
+        """Controller.forward(obs) of the scenario's greedy controller (envs/large_grid_env.py:45-60,
+        envs/real_net_env.py:78-111, envs/small_grid_env.py:40-55) for every instance, on the device (greedy_kernel,
+        csrc/tsc_env.hip): obs float32 [E, A, SMAX] (default: the observation the env returned last) -> int32 [E, A]."""
+        if not getattr(self, '_greedy_set', False):
+            n_cand, term, action = self.scn.greedy_controller_tables()
+            ip = C.POINTER(C.c_int32)
+            n_cand, term, action = (np.ascontiguousarray(x, np.int32) for x in (n_cand, term, action))
+            _lib.check(self._L.tsc_env_set_greedy(self._h, term.shape[1], term.shape[2], n_cand.ctypes.data_as(ip),
+                                                  term.ctypes.data_as(ip), action.ctypes.data_as(ip)))
+            self._greedy_set = True
+        obs = self.obs if obs is None else obs
+        assert obs.dtype == torch.float32 and obs.is_contiguous() and tuple(obs.shape) == (self.E, self.A, self.SMAX)
+        if out is None:
+            out = torch.empty(self.E, self.A, dtype=torch.int32, device=self.device)
+        assert out.dtype == torch.int32 and out.is_contiguous() and tuple(out.shape) == (self.E, self.A)
+        _lib.check(self._L.tsc_env_greedy_actions(self._h, C.c_void_p(obs.data_ptr()), C.c_void_p(out.data_ptr())))
+        return out
+
     def reward_sum(self, reset=False):
         """Sum of the global reward over instances and control steps since the accumulator was reset."""
         v = C.c_double()

@@ -84,19 +84,16 @@ def find_file(cur_dir, suffix='.ini'):
 
 
 class GreedyPolicy:
-    """LargeGridController / RealNetController / SmallGridController (envs/*_env.py) on the device obs tensor."""
+    """LargeGridController / RealNetController / SmallGridController (envs/*_env.py) on the device obs tensor: the env's
+    greedy kernel (VecTrafficEnv.greedy_actions -> tsc_env_greedy_actions) over the scenario's controller tables."""
     name = 'greedy'
     n_step = 1
 
-    def __init__(self, scn):
-        from .trainer import greedy_actions, greedy_actions_large_grid, greedy_actions_small_grid, greedy_table
-        self.scn, self.table = scn, greedy_table(scn)
-        self._fn = (greedy_actions_large_grid if scn.name == 'large_grid' else
-                    (lambda ob: greedy_actions_small_grid(scn, ob)) if scn.name == 'small_grid' else
-                    (lambda ob: greedy_actions(scn, ob, self.table)))
+    def __init__(self, env):
+        self.env = env
 
     def forward(self, ob, *_a, **_k):
-        return self._fn(ob)
+        return self.env.greedy_actions(ob)
 
     def reset(self):
         pass
@@ -181,7 +178,7 @@ def evaluate_agent(agent_dir, output_dir, seeds, policy_type='default', device=0
             logging.error('Evaluation: no checkpoint under %s/model/' % agent_dir)
             return None
     else:
-        model = GreedyPolicy(scn)
+        model = GreedyPolicy(env)
     env.train_mode = False
     env.set_record(True)
     trainer = VecTrainer(env, model)

@@ -122,6 +122,51 @@ class Scenario:
     def n_stream(self) -> int:
         return self.n_route if self.stream_entry_lane is None else len(self.stream_entry_lane)
 
+    def greedy_controller_tables(self):
+        """What the reference's greedy controller of this scenario holds, as tables for tsc_env_set_greedy: per agent the
+        candidates it compares, each a list of indices into the agent's observation (its own wave entries come first in every
+        layout) summed IN THIS ORDER, and the action a winning candidate stands for.  Returns (n_cand i32 [A], term i32
+        [A, GC, GT] -1-padded, action i32 [A, GC]).
+        large_grid: LargeGridController.greedy's hard-coded lane pairs (envs/large_grid_env.py:56-60), candidate = phase.
+        small_grid: SmallGridController.greedy compares the first len(STATE_PHASE_MAP[node]) entries and returns the mapped
+        phase (envs/small_grid_env.py:29-30,51-55).
+        otherwise (real_net): RealNetController.greedy (envs/real_net_env.py:90-111) -- per phase the lanes of its 'G' links
+        ('g' does not count) in link order, every lane once."""
+        A = self.n_agent
+        cands, acts = [], []
+        if self.name == 'large_grid':
+            pairs = [(0, 3), (2, 5), (1, 4), (1, 2), (4, 5)]
+            cands, acts = [[list(p) for p in pairs]] * A, [list(range(5))] * A
+        elif self.name == 'small_grid':
+            spm = self.extra['state_phase_map']
+            for n in self.node_names:
+                cands.append([[k] for k in range(len(spm[n]))])
+                acts.append([int(x) for x in spm[n]])
+        else:
+            for a in range(A):
+                lanes = [int(x) for x in self.agent_lanes[a, :self.agent_nlane[a]]]
+                ca = []
+                for p in range(int(self.agent_nphase[a])):
+                    seen = []
+                    for k in range(int(self.agent_nlink[a])):
+                        if self.green_tab[a, p, k] == ord('G'):
+                            j = lanes.index(int(self.link_lane[a, k]))
+                            if j not in seen:
+                                seen.append(j)
+                    ca.append(seen)
+                cands.append(ca)
+                acts.append(list(range(len(ca))))
+        GC = max(len(c) for c in cands)
+        GT = max(1, max(len(t) for c in cands for t in c))
+        n_cand = np.array([len(c) for c in cands], np.int32)
+        term = np.full((A, GC, GT), -1, np.int32)
+        action = np.zeros((A, GC), np.int32)
+        for a in range(A):
+            for c, t in enumerate(cands[a]):
+                term[a, c, :len(t)] = t
+                action[a, c] = acts[a][c]
+        return n_cand, term, action
+
     def streams_ready(self):
         """Fill the optional stream tables (whole-lane insertion window) once streams are declared."""
         if self.stream_entry_lane is not None:

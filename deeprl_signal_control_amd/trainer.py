@@ -357,67 +357,26 @@ class MultiBatchTrainer:
         return tot / (steps * sum(p.env.E for p in self.parts))
 
 
-def greedy_actions_large_grid(obs):
-    """envs/large_grid_env.py:56-60 on the batched obs tensor [E,A,SMAX] (first 6 entries = own
-    wave).  Host-side helper for sim-only benchmarks; plain indexing, no learned compute."""
-    w = obs[..., :6]
-    flows = torch.stack([w[..., 0] + w[..., 3], w[..., 2] + w[..., 5], w[..., 1] + w[..., 4],
-                         w[..., 1] + w[..., 2], w[..., 4] + w[..., 5]], -1)
-    return flows.argmax(-1).to(torch.int32)
-
-
-def greedy_actions_small_grid(scn, obs):
-    """envs/small_grid_env.py:40-55 SmallGridController on the batched obs tensor [E,A,SMAX] (or a numpy array): the
-    reference's hard-coded map from the index of the fullest incoming lane to a phase (STATE_PHASE_MAP, restated as is --
-    for the two-phase nodes it serves the OTHER lane)."""
-    spm = scn.extra['state_phase_map']
-    A = scn.n_agent
-    k = np.array([len(spm[n]) for n in scn.node_names])
-    tab = np.zeros((A, int(k.max())), np.int64)
-    for a, n in enumerate(scn.node_names):
-        tab[a, :k[a]] = spm[n]
-    if torch.is_tensor(obs):
-        w = obs[..., :tab.shape[1]].clone()
-        valid = torch.as_tensor(np.arange(tab.shape[1])[None, :] < k[:, None], device=obs.device)
-        w = torch.where(valid, w, torch.full_like(w, -1.0))
-        best = w.max(-1, keepdim=True).values
-        rank = torch.arange(tab.shape[1], 0, -1, device=obs.device)
-        idx = ((w == best) * rank).argmax(-1)                           # first maximum, like np.argmax
-        return torch.as_tensor(tab, device=obs.device).expand(idx.shape + (tab.shape[1],)).gather(-1, idx[..., None])[..., 0].to(torch.int32)
-    w = np.where(np.arange(tab.shape[1])[None, :] < k[:, None], np.asarray(obs)[..., :tab.shape[1]], -1.0)
-    idx = w.argmax(-1)
-    return np.take_along_axis(np.broadcast_to(tab, idx.shape + (tab.shape[1],)), idx[..., None], -1)[..., 0].astype(np.int32)
-
-
-def greedy_table(scn):
-    """[A, PMAX, LMAX] 0/1: lane j (ild order) of agent a has a 'G' link in phase p -- every lane once, as
-    RealNetController.greedy counts it (envs/real_net_env.py:96-111; lower-case 'g' links do not count)."""
-    A, P = scn.n_agent, scn.green_tab.shape[1]
-    gm = np.zeros((A, P, scn.agent_lanes.shape[1]), np.float64)
-    for a in range(A):
-        lanes = [int(x) for x in scn.agent_lanes[a, :scn.agent_nlane[a]]]
-        for p in range(int(scn.agent_nphase[a])):
-            for k in range(int(scn.agent_nlink[a])):
-                if scn.green_tab[a, p, k] == ord('G'):
-                    gm[a, p, lanes.index(int(scn.link_lane[a, k]))] = 1.0
-    return gm
-
-
-def greedy_actions(scn, wave, table=None):
-    """Max-green-wave phase per agent (the reference's greedy controllers).  wave [..., A, >= LMAX]:
-    the agents' own wave entries first (as in every obs layout).  numpy or torch (device) input; ties go to the
-    lowest phase like np.argmax."""
-    gm = greedy_table(scn) if table is None else table
-    L = gm.shape[2]
-    nph = np.asarray(scn.agent_nphase)
+def greedy_actions(scn, wave):
+    """HOST restatement of the reference's greedy controllers (envs/large_grid_env.py:56-60,
+    envs/real_net_env.py:90-111, envs/small_grid_env.py:51-55) over Scenario.greedy_controller_tables -- the same tables the
+    device kernel reads (VecTrafficEnv.greedy_actions -> tsc_env_greedy_actions, the product path for device tensors).  For
+    host arrays only: CPU tools and tests that drive the oracle.  wave [..., A, >= terms]: the agents' own wave entries
+    first (as in every obs layout), float64 like the controllers' input; candidates are summed in table order from 0 and
+    np.argmax keeps the first maximum."""
     if torch.is_tensor(wave):
-        g = torch.as_tensor(gm, dtype=wave.dtype, device=wave.device)
-        flows = torch.einsum('...al,apl->...ap', wave[..., :L], g)
-        valid = torch.as_tensor(np.arange(gm.shape[1])[None, :] < nph[:, None], device=wave.device)
-        flows = torch.where(valid, flows, torch.full_like(flows, -1.0))
-        best = flows.max(-1, keepdim=True).values
-        rank = torch.arange(gm.shape[1], 0, -1, device=wave.device)       # first maximum wins
-        return ((flows == best) * rank).argmax(-1).to(torch.int32)
-    flows = np.einsum('...al,apl->...ap', np.asarray(wave, np.float64)[..., :L], gm)
-    flows = np.where(np.arange(gm.shape[1])[None, :] < nph[:, None], flows, -1.0)
-    return flows.argmax(-1).astype(np.int32)
+        raise TypeError('greedy_actions is the host restatement; device tensors go through VecTrafficEnv.greedy_actions (HIP)')
+    n_cand, term, action = scn.greedy_controller_tables()
+    w = np.asarray(wave, np.float64)
+    out = np.zeros(w.shape[:-1], np.int32)
+    for a in range(scn.n_agent):
+        flows = []
+        for c in range(int(n_cand[a])):
+            f = np.zeros(w.shape[:-2], np.float64)
+            for j in term[a, c]:
+                if j < 0:
+                    break
+                f = f + w[..., a, int(j)]
+            flows.append(f)
+        out[..., a] = action[a][np.argmax(np.stack(flows, -1), -1)]
+    return out

@@ -165,14 +165,41 @@ def test_ia2c_adapter_and_make_env_and_test_seeds():
     env.close(); model.vec.close()
 
 
-def test_greedy_controllers_on_device():
-    """trainer.greedy_actions_large_grid (LargeGridController, envs/large_grid_env.py:56-60: hard-coded lane sums, not
-    the 'G' links of the phase strings) on the device obs tensor against the oracle's restatement, along a
-    greedy-driven episode.  (The generic greedy_actions = RealNetController is pinned in tests/test_real_net.py.)"""
+def test_greedy_controllers_on_device(golden_dir):
+    """tsc_env_greedy_actions (greedy_kernel over Scenario.greedy_controller_tables; VecTrafficEnv.greedy_actions) against the
+    reference's three controllers:
+    * LargeGridController (envs/large_grid_env.py:56-60, hard-coded lane sums) under the configs' norms (wave / 5 clipped at
+      2): the controller sees float64 state, the kernel the float32 observation -- random counts incl. the float64
+      non-tie 0.2 + 0.4 > 0.6 + 0 that IS a tie on the float32 values; then along a greedy-driven episode;
+    * RealNetController: the fixture recorded from the reference class (tools/make_golden.py:greedy_fixtures; its waves are
+      multiples of 0.1 = counts over norm_wave 10);
+    * SmallGridController (STATE_PHASE_MAP) against the host restatement on float64 counts / 5."""
     from deeprl_signal_control_amd.env import VecTrafficEnv
-    from deeprl_signal_control_amd.scenario import build_large_grid
-    from deeprl_signal_control_amd.trainer import greedy_actions_large_grid
+    from deeprl_signal_control_amd.scenario import build_large_grid, build_real_net, build_small_grid
+    from deeprl_signal_control_amd.trainer import greedy_actions
     from oracle.env_oracle import greedy_large_grid
+    rng = np.random.RandomState(5)
+
+    def on_device(env, ob64):
+        ob = np.zeros((env.E, env.A, env.SMAX), np.float32)
+        ob[:, :, :ob64.shape[2]] = ob64.astype(np.float32)
+        return env.greedy_actions(torch.from_numpy(ob).cuda()).cpu().numpy()
+
+    # large_grid, default norms
+    scn = build_large_grid('greedy')
+    assert (scn.norm_wave, scn.clip_wave) == (5.0, 2.0)
+    E = 64
+    env = VecTrafficEnv(scn, E, seed=40)
+    cnt = rng.randint(0, 14, (E, 25, 6))
+    cnt[0, 0] = [1, 0, 3, 2, 0, 0]             # phase 0: 0.2 + 0.4 (= 0.6000000000000001 in float64), phase 1: 0.6 + 0
+    cnt[0, 1] = [3, 0, 1, 0, 0, 2]             # the other way round: phase 0 0.6 + 0, phase 1 0.2 + 0.4
+    ob64 = np.clip(cnt / scn.norm_wave, 0, scn.clip_wave)
+    want = np.array([[greedy_large_grid(ob64[e, a]) for a in range(25)] for e in range(E)])
+    assert want[0, 0] == 0 and want[0, 1] == 1
+    np.testing.assert_array_equal(on_device(env, ob64), want)
+    np.testing.assert_array_equal(greedy_actions(scn, ob64), want)
+    env.close()
+    # ... and along an episode the controller itself drives (unit norms: the observations are the counts)
     scn = build_large_grid('greedy', norm_wave=1.0, norm_wait=1.0, clip_wave=-1.0, clip_wait=-1.0)
     E = 6
     env = VecTrafficEnv(scn, E, seed=40)
@@ -180,13 +207,27 @@ def test_greedy_controllers_on_device():
     ob = env.reset(test_ind=0)
     tot = 0.0
     for t in range(240):
-        act = greedy_actions_large_grid(ob)
+        act = env.greedy_actions(ob)
         o = ob.cpu().numpy()
         want = np.array([[greedy_large_grid(o[e, a, :6]) for a in range(25)] for e in range(E)])
         np.testing.assert_array_equal(act.cpu().numpy(), want)
         ob, _, _, g = env.step(act)
         tot += float(g.mean().item())
     assert tot / 240 < -1.0
+    env.close()
+    # Monaco: the reference controller's own answers
+    g = np.load(os.path.join(golden_dir, 'real_net_greedy_controller.npz'))
+    scn = build_real_net('greedy', norm_wave=10.0, clip_wave=-1.0)
+    env = VecTrafficEnv(scn, g['wave'].shape[0], seed=1)
+    np.testing.assert_array_equal(on_device(env, g['wave']), g['action'])
+    env.close()
+    # small_grid
+    scn = build_small_grid('greedy')
+    E = 32
+    env = VecTrafficEnv(scn, E, seed=1)
+    n_own = max(len(v) for v in scn.extra['state_phase_map'].values())
+    ob64 = np.clip(rng.randint(0, 12, (E, scn.n_agent, n_own)) / scn.norm_wave, 0, scn.clip_wave)
+    np.testing.assert_array_equal(on_device(env, ob64), greedy_actions(scn, ob64))
     env.close()
 
 

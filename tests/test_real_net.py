@@ -128,16 +128,15 @@ def test_gpu_batched_vs_oracle_monaco(threads, monkeypatch):
 
 
 def test_greedy_controller_matches_reference(golden_dir):
-    """trainer.greedy_actions (phase -> lanes with a 'G' link -> wave sums -> first argmax) against
-    RealNetController.greedy of the reference (tools/make_golden.py:greedy_fixtures), numpy and torch paths.
-    (large_grid has its own hard-coded controller, trainer.greedy_actions_large_grid, pinned by
-    tests/golden/large_grid_greedy.npz.)"""
-    import torch
+    """The controller tables (Scenario.greedy_controller_tables: phase -> lanes with a 'G' link in link order, every lane
+    once) through the host restatement trainer.greedy_actions (wave sums in table order -> first argmax) against
+    RealNetController.greedy of the reference (tools/make_golden.py:greedy_fixtures).  The device kernel reads the same
+    tables: tests/test_binding_gpu.py::test_greedy_controllers_on_device.  (large_grid has its own hard-coded controller,
+    pinned by tests/golden/large_grid_greedy.npz.)"""
     from deeprl_signal_control_amd.trainer import greedy_actions
     g = np.load(os.path.join(golden_dir, 'real_net_greedy_controller.npz'))
     scn = build_real_net('greedy')
     np.testing.assert_array_equal(greedy_actions(scn, g['wave']), g['action'])
-    np.testing.assert_array_equal(greedy_actions(scn, torch.from_numpy(g['wave'])).numpy(), g['action'])
 
 
 def test_lane_chain_contraction_preserves_routes_and_detectors():

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from deeprl_signal_control_amd.scenario import build_small_grid, small_grid_demand
-from deeprl_signal_control_amd.trainer import greedy_actions_small_grid
+from deeprl_signal_control_amd.trainer import greedy_actions
 
 KW = dict(norm_wave=1.0, norm_wait=1.0, clip_wave=1000.0, clip_wait=1000.0, coop_gamma=0.75)
 
@@ -53,7 +53,7 @@ def _replay(env, g):
         o = np.zeros((scn.n_agent, scn.s_max))
         for a, x in enumerate(ob):
             o[a, :len(x)] = x
-        act = greedy_actions_small_grid(scn, o)
+        act = greedy_actions(scn, o)
         np.testing.assert_array_equal(act, g['actions'][t], err_msg='SmallGridController t=%d' % t)
         ob, r, done, gr = env.step(list(act))
         np.testing.assert_array_equal(np.concatenate(ob).astype(np.float32), g['obs'][t + 1].astype(np.float32), err_msg='obs t=%d' % t)

@@ -11,7 +11,7 @@ import torch
 
 from deeprl_signal_control_amd.env import VecTrafficEnv
 from deeprl_signal_control_amd.scenario import build_large_grid
-from deeprl_signal_control_amd.trainer import greedy_actions_large_grid
+
 
 
 
