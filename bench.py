@@ -40,23 +40,54 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 
 
-def pmc_traffic(kernel, default_workload=True):
-    """(HBM bytes per launch of `kernel`, source) from the newest committed rocprofv3 --pmc summary (profiles/rNN_pmc.json:
-    separate FETCH_SIZE / WRITE_SIZE passes, KB units; the gfx950 x2 FETCH correction only applies to 16 B/lane streams and
-    is NOT applied to these dword-per-lane kernels) or (None, None).  It is a COMMITTED measurement of an earlier run of this
-    very command (one iteration from reset: fewer vehicles than the timed window), not a counter read in this run -- the
-    JSON line says so in `traffic_source`."""
-    if not default_workload:            # the committed counters were collected on the default workload (configs[2]) only
-        return None, None
-    for tag in ('r04', 'r03'):
+PROFILE_TAGS = ('r05',)           # committed rocprofv3 summaries this file may quote, newest first
+
+
+def pmc_traffic(kernel, cfg_name, live):
+    """(HBM bytes per launch of `kernel`, source) from the committed rocprofv3 --pmc summary of THIS configuration
+    (profiles/rNN_pmc{,_c2,_c5}.json: separate FETCH_SIZE / WRITE_SIZE passes, KB units; the gfx950 x2 FETCH correction only
+    applies to 16 B/lane streams and is NOT applied to these dword-per-lane kernels) or (None, reason).  It is a COMMITTED
+    measurement of an earlier run of this very command, not a counter read in this run; the counters average over whole
+    episodes (tools/profile_round.sh) and the summary records the window-mean vehicles per instance of that run: a summary
+    whose figure is more than 15 % away from this run's is REFUSED (the simulator's traffic scales with the vehicles)."""
+    suffix = {'c3': '', 'c2': '_c2', 'c5': '_c5'}.get(cfg_name)
+    if suffix is None:
+        return None, 'no committed PMC summary for this configuration'
+    why = 'no committed PMC summary (profiles/%s_pmc%s.json)' % (PROFILE_TAGS[0], suffix)
+    for tag in PROFILE_TAGS:
         try:
-            d = json.load(open(os.path.join(ROOT, 'profiles', '%s_pmc.json' % tag)))
+            d = json.load(open(os.path.join(ROOT, 'profiles', '%s_pmc%s.json' % (tag, suffix))))
             k = d['kernels'][kernel]
-            return (k['fetch_kb'] + k['write_kb']) * 1024.0, ('profiles/%s_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of '
-                                                             'one iteration from reset, mean live vehicles ~300 per instance): committed '
-                                                             'measurement, not collected in this run' % tag)
+            v = float(d['mean_live_vehicles_per_env'])
         except Exception:
             continue
+        if live and abs(v - live) > 0.15 * live:
+            why = ('profiles/%s_pmc%s.json refused: collected at %.0f vehicles per instance, this run\'s window mean is %.0f '
+                   '(more than 15 %% apart)' % (tag, suffix, v, live))
+            continue
+        return (k['fetch_kb'] + k['write_kb']) * 1024.0, (
+            'profiles/%s_pmc%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over whole episodes of this '
+            'configuration, window mean %.0f vehicles per instance against %.0f in this run): committed measurement, not '
+            'collected in this run' % (tag, suffix, v, live or 0.0))
+    return None, why
+
+
+def rocprof_avg_us(kernel_key, cfg_name):
+    """Average launch duration (us) of the kernel whose name contains `kernel_key` in the committed rocprofv3 --kernel-trace
+    --stats summary of this configuration (profiles/rNN_kernel_stats{,_c2,_c5}.csv), or (None, None)."""
+    import csv
+    suffix = {'c3': '', 'c2': '_c2', 'c5': '_c5'}.get(cfg_name)
+    if suffix is None:
+        return None, None
+    for tag in PROFILE_TAGS:
+        path = os.path.join(ROOT, 'profiles', '%s_kernel_stats%s.csv' % (tag, suffix))
+        try:
+            rows = [r for r in csv.DictReader(open(path)) if kernel_key in r['kernel']]
+        except Exception:
+            continue
+        if rows:
+            r = max(rows, key=lambda r_: float(r_['total_us']))
+            return float(r['avg_us']), 'profiles/%s_kernel_stats%s.csv' % (tag, suffix)
     return None, None
 
 
@@ -176,6 +207,7 @@ def cpu_baseline(n_env=48, n_step=120, threads=8):
             ms.set_links(a, scn.phases[a][(t // 30) % 5])
         ms.step(5)
     sim_dt = time.perf_counter() - t1
+    allc = sim_only_all_cores(scn)
     out = {'value': steps / dt32, 'unit': 'env-steps/s', 'cores': torch.get_num_threads(), 'kind': 'port',
            'sample': 'oracle/ (C microsim + NumPy env wrapper + float32 torch-CPU nets = the reference\'s TensorFlow arithmetic): %d env '
                      'instances x %d control steps + 1 update, %.1f s' % (n_env, n_step, dt32),
@@ -183,6 +215,8 @@ def cpu_baseline(n_env=48, n_step=120, threads=8):
            'sample_float64_nets': 'the same with the float64 nets the parity tests check against, %.1f s' % dt64,
            'sim_only_value': scn.n_agent * 3600 / sim_dt,
            'sim_only_sample': 'oracle/microsim.c alone, 1 instance, 1 core, 3600 simulated seconds, %.2f s' % sim_dt}
+    if allc:
+        out['sim_only_all_cores'] = allc
     try:                                # SURVEY 8(d) baseline (i), measured where /root/reference exists (not on this box)
         oa = json.load(open(os.path.join(ROOT, 'profiles', 'r04_oracle_a.json')))
         out['reference_env_over_fake_traci'] = {
@@ -194,12 +228,68 @@ def cpu_baseline(n_env=48, n_step=120, threads=8):
     return out
 
 
+def sim_only_all_cores(scn, target_s=4.0):
+    """SURVEY 8(d) CPU baseline (ii): the C microsim alone over many env instances on ALL host cores -- one process per core
+    (oracle/microsim_worker.py), every process a share of the instances, one full episode each under a fixed signal cycle,
+    released together; value = agents x instances x simulated seconds / wall time from the release to the last answer."""
+    import subprocess
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    per = max(1024 // cores, int(target_s / 0.06))         # one episode is ~0.04-0.07 s of one core
+    procs = []
+    try:
+        for w in range(cores):
+            procs.append(subprocess.Popen([sys.executable, '-m', 'oracle.microsim_worker', str(per), str(12 + w * per)], cwd=ROOT,
+                                          stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True))
+        for p in procs:
+            if p.stdout.readline().strip() != 'ready':
+                raise RuntimeError('worker did not come up')
+        t0 = time.perf_counter()
+        for p in procs:
+            p.stdin.write('go\n'); p.stdin.flush()
+        ans = [p.stdout.readline().split() for p in procs]
+        dt = time.perf_counter() - t0
+        live = float(np.mean([float(a[1]) for a in ans]))
+        return {'value': scn.n_agent * cores * per * scn.episode_length_sec / dt, 'unit': 'env-steps/s', 'cores': cores,
+                'sample': 'oracle/microsim.c alone (no env wrapper, no nets), %d processes x %d instances x one 3600-s episode under a '
+                          'fixed 30-s signal cycle, %.1f s wall, slowest worker %.1f s, %.0f vehicles per instance on average'
+                          % (cores, per, dt, max(float(a[0]) for a in ans), live)}
+    except Exception as ex:                                 # a baseline leg must never take the bench line down
+        return {'error': repr(ex)}
+    finally:
+        for p in procs:
+            try:
+                p.stdin.close(); p.wait(timeout=10)
+            except Exception:
+                p.kill()
+
+
 def extra_lines(env, model, scn, n_ctrl=240):
     """SURVEY 8d asks for the simulator alone and simulator + policy forward next to the training figure: the same env
     instances, `n_ctrl` control steps each, actions pre-generated (uniform) for the sim-only line so that nothing but
     tsc_env_step is on the stream; env-steps/s = agents x instances x simulated seconds / wall time."""
     E, A, ctrl = env.E, scn.n_agent, scn.control_interval_sec
     out = {}
+    # (a) the reference's greedy controller of the scenario as the action source, on the device (greedy_kernel): two launches
+    # per control step, nothing pre-generated
+    ob = env.reset(); model.reset()
+    act = torch.zeros(E, A, dtype=torch.int32, device='cuda')
+    for t in range(20):
+        ob, _, _, _ = env.step(env.greedy_actions(ob, out=act))
+    torch.cuda.synchronize()
+    env.live_vehicle_mean(1)
+    t0 = time.perf_counter()
+    for t in range(n_ctrl):
+        ob, _, _, _ = env.step(env.greedy_actions(ob, out=act))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out['sim_only'] = {'value': A * E * n_ctrl * ctrl / dt, 'unit': 'env-steps/s', 'us_per_control_step': 1e6 * dt / n_ctrl,
+                       'actions': 'the reference\'s greedy controller on the device (tsc_env_greedy_actions), one launch per control step',
+                       'mean_live_vehicles_per_env': env.live_vehicle_mean(n_ctrl)}
+    # (b) uniform random actions, pre-generated: nothing but tsc_env_step on the stream (more vehicles: random phases jam)
     g = torch.Generator(device='cuda'); g.manual_seed(1)
     na = torch.as_tensor(np.asarray(scn.n_a_ls), device='cuda')
     acts = (torch.rand(16, E, A, generator=g, device='cuda') * na).to(torch.int32).contiguous()
@@ -213,8 +303,9 @@ def extra_lines(env, model, scn, n_ctrl=240):
         env.step(acts[t % 16])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    out['sim_only'] = {'value': A * E * n_ctrl * ctrl / dt, 'unit': 'env-steps/s', 'us_per_control_step': 1e6 * dt / n_ctrl,
-                       'actions': 'uniform random, pre-generated on the device', 'mean_live_vehicles_per_env': env.live_vehicle_mean(n_ctrl)}
+    out['sim_only_random_actions'] = {'value': A * E * n_ctrl * ctrl / dt, 'unit': 'env-steps/s', 'us_per_control_step': 1e6 * dt / n_ctrl,
+                                      'actions': 'uniform random, pre-generated on the device',
+                                      'mean_live_vehicles_per_env': env.live_vehicle_mean(n_ctrl)}
     ob = env.reset(); model.reset()
     done = True
     for t in range(20):
@@ -238,7 +329,38 @@ def extra_lines(env, model, scn, n_ctrl=240):
     return out
 
 
-PRESETS = {'c2': ('large_grid', 'ia2c', 'fc', 256), 'c3': ('large_grid', 'ma2c', 'lstm', 1024), 'c5': ('real_net', 'ma2c', 'lstm', 512)}
+PRESETS = {'c2': ('large_grid', 'ia2c', 'fc', 256), 'c3': ('large_grid', 'ma2c', 'lstm', 1024), 'c5': ('real_net', 'ma2c', 'lstm', 512),
+           'q1': ('large_grid', 'iqld', 'dqn', 1024)}      # q1: config/config_iqld_large.ini, not a BASELINE config
+
+
+def preset_name(scenario, agent, policy, E):
+    for k, v in PRESETS.items():
+        if v == (scenario, agent, policy, E):
+            return k
+    return None
+
+
+def rank_table(rank, world, local, backend):
+    """What proves that N ranks ran on N devices: every rank's (rank, device index, device name, uuid / PCI bus id),
+    all-gathered; rank 0 reports the list, the number of distinct devices, the backend and the RCCL version."""
+    pr = torch.cuda.get_device_properties(local)
+    ident = str(getattr(pr, 'uuid', '')) or str(getattr(pr, 'pci_bus_id', ''))
+    try:
+        ident += ' pci %04x:%02x:%02x' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
+        pass
+    me = {'rank': rank, 'device_index': local, 'device_name': torch.cuda.get_device_name(local), 'device_id': ident,
+          'host': os.uname().nodename, 'pid': os.getpid()}
+    rows = [me]
+    if world > 1:
+        rows = [None] * world
+        torch.distributed.all_gather_object(rows, me)
+    try:
+        ver = '.'.join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        ver = None
+    return {'world': world, 'backend': ('%s (RCCL %s)' % (backend, ver) if backend == 'nccl' else backend) if world > 1 else 'none (one rank)',
+            'rccl_version': ver, 'distinct_devices': len({(r['host'], r['device_id'] or r['device_index']) for r in rows}), 'ranks': rows}
 
 
 def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warmup, want_extra, want_cpu, want_profile):
@@ -251,20 +373,29 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
     from deeprl_signal_control_amd.trainer import MultiBatchTrainer, VecTrainer
 
     scn = build_scenario(scenario, agent)
-    if scenario == 'large_grid':        # config/config_{ma2c,ia2c}_large.ini
+    cfg_name = preset_name(scenario, agent, policy, E)
+    is_q = agent in ('iqld', 'iqll')
+    if is_q:                            # config/config_iql{d,l}_large.ini: batch 20, replay 1000, reward_norm 3000, Adam 1e-4
+        mcfg, seed0, tseeds = dict(batch_size=20, buffer_size=1000, reward_norm=3000.0), 12, (10000, 20000)
+    elif scenario == 'large_grid':      # config/config_{ma2c,ia2c}_large.ini
         mcfg, seed0, tseeds = dict(reward_norm=2000.0 if agent == 'ma2c' else 3000.0, batch_size=120), 12, (10000, 20000)
     else:                               # config/config_{ma2c,ia2c}_real.ini
         mcfg, seed0, tseeds = dict(reward_norm=1.0, batch_size=40), 42, (10000, 20000, 30000)
     B = max(1, args.batches)
-    assert E % B == 0
+    assert E % B == 0 and not (is_q and B > 1)
     Eb = E // B
     envs, models = [], []
     for b in range(B):
         envs.append(VecTrafficEnv(scn, Eb, device=local, seed=seed0 + rank * E + b * Eb, seed_stride=E * world,
                                   test_seeds=tseeds))
         # same weight-init seed on every rank / half-batch (replicas of one learner), own action stream each
-        mdl = VecA2C(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, scn.n_f_ls, Eb, scn.s_max, int(scn.green_tab.shape[1]), mcfg,
-                     device=local, seed=0, name=agent, policy=policy, replica=b)
+        if is_q:
+            from deeprl_signal_control_amd.iql import VecIQL
+            mdl = VecIQL(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, Eb, scn.s_max, int(scn.green_tab.shape[1]), mcfg,
+                         total_step=10 ** 6, device=local, seed=0, model_type='dqn' if agent == 'iqld' else 'lr')
+        else:
+            mdl = VecA2C(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, scn.n_f_ls, Eb, scn.s_max, int(scn.green_tab.shape[1]), mcfg,
+                         device=local, seed=0, name=agent, policy=policy, replica=b)
         models.append(mdl)
     env, model = envs[0], models[0]
     tr = VecTrainer(env, model) if B == 1 else MultiBatchTrainer(envs, models)
@@ -301,8 +432,9 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
         _lib.profile(enable=False)
         live_prof = float(np.mean([e_.live_vehicle_mean(psteps * model.n_step) for e_ in envs]))
     extra = {}
-    if rank == 0 and world == 1 and B == 1 and want_extra:
+    if rank == 0 and world == 1 and B == 1 and want_extra and not is_q:
         extra = extra_lines(env, model, scn)
+    ranks = rank_table(rank, world, local, args.backend)          # collective: every rank
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -316,7 +448,12 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
                'value': env_steps / dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': steps,
                'warmup': warmup, 'ms_per_step': 1e3 * dt / steps, 'higher_is_better': True,
                'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-               'config': {'workload': '%s (%d agents), %s %s policy%s, %d env instances per GPU; step = %d control steps '
+               'config': {'workload': ('%s (%d agents), %s (%s Q net), %d env instances per GPU; step = %d epsilon-greedy control steps '
+                                       '(x%d sim-steps) of every instance into the replay rings + 10 minibatch steps (%d transitions per '
+                                       'instance and agent each: TD loss, clip, Adam%s)'
+                                       % ('large_grid 5x5', scn.n_agent, agent.upper(), policy.upper(), E, n_step, ctrl, n_step,
+                                          ', RCCL grad all-reduce' if world > 1 else '')) if is_q else
+                                      '%s (%d agents), %s %s policy%s, %d env instances per GPU; step = %d control steps '
                                       '(x%d sim-steps) of every instance + 1 A2C update (%sclip, RMSProp%s)'
                                       % ('large_grid 5x5' if scenario == 'large_grid' else 'real_net Monaco', scn.n_agent,
                                          agent.upper(), policy.upper(),
@@ -326,8 +463,9 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
                           'parallelism': 'env-sharded x%d%s' % (world, ', %d half-batches on separate streams' % B if B > 1 else ''),
                           'mean_live_vehicles_per_env': live, 'live_vehicles': 'window mean over the timed region',
                           'mean_step_reward': msr}}
-        is_default = (scenario, agent, policy, E) == ('large_grid', 'ma2c', 'lstm', 1024)
-        if prof:
+        if prof and is_q:                   # the Q learner's kernels are the grouped GEMM + small elementwise kernels: table only
+            out['kernels'] = {k: {'ms_total': round(v[0], 3), 'launches': v[1]} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+        elif prof:
             total = sum(ms for ms, _ in prof.values())
             dom = max(prof, key=lambda k: prof[k][0])
             ms, cnt = prof[dom]
@@ -338,12 +476,23 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
             for k, d in kern.items():
                 avg = d['ms_total'] / d['launches'] * 1e-3
                 if k == 'env_step':
-                    d['frac_hbm'] = round((32.0 * live_prof + 16.0 * scn.n_lane + scn.n_agent * 52.0 / 5.0) * ctrl * E / avg / 1e9 / PEAK_HBM_GBS, 4)
+                    alg = (32.0 * live_prof + 16.0 * scn.n_lane + scn.n_agent * 52.0 / 5.0) * ctrl * E      # SURVEY 8d bytes per launch
+                    d['frac_hbm'] = round(alg / avg / 1e9 / PEAK_HBM_GBS, 4)
+                    d['frac_hbm_timing'] = 'HIP-event pair around the launch: includes the event packets (~10 us at this launch length), i.e. understates the kernel'
+                    us, src = rocprof_avg_us('step_kernel', cfg_name)
+                    if us:      # the profiler's own figure of the same kernel in the committed trace of this configuration
+                        d['rocprofv3_avg_us'] = us
+                        d['frac_hbm_rocprofv3'] = round(alg / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)
+                        d['rocprofv3_source'] = src + ' (committed rocprofv3 --kernel-trace --stats run of this command, not this run)'
+                    tb, tsrc = pmc_traffic('env_step', cfg_name, live_prof)
+                    d['traffic'], d['traffic_source'] = tb, tsrc
+                    if tb:
+                        d['traffic_over_algorithmic'] = round(tb / alg, 3)
                 elif k == 'policy_fwd_fused':
                     d['frac_mfma'] = round(algorithmic_flops(model, E)[k] / avg / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
                 elif fl_all.get(k, 0.0) > 0 and d['launches'] == psteps:
                     d['frac_mfma'] = round(fl_all[k] / avg / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
-            traffic, traffic_src = pmc_traffic(dom, is_default)
+            traffic, traffic_src = pmc_traffic(dom, cfg_name, live_prof)
             if dom == 'env_step':
                 V, Ln, A = live_prof, scn.n_lane, scn.n_agent           # 32 V + 16 L + A*52/5 B per env-sim-step (V = window mean)
                 bytes_launch = (32.0 * V + 16.0 * Ln + A * 52.0 / 5.0) * ctrl * E
@@ -363,6 +512,11 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
                 roof = {'bound': 'mfma', 'kernel': dom, 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS,
                         'unit': 'TFLOP/s', 'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic}
             roof['traffic_source'] = traffic_src
+            us, src = rocprof_avg_us({'env_step': 'step_kernel', 'policy_fwd_fused': 'policy_fwd_', 'dwx_gemm': 'dwxh_kernel',
+                                      'dx1_gemm': 'fc_bwd_kernel' if policy == 'fc' else 'dx1w1_kernel2'}.get(dom, dom), cfg_name)
+            if us:
+                roof['rocprofv3_avg_launch_ms'] = us * 1e-3
+                roof['rocprofv3_source'] = src + ' (committed rocprofv3 --kernel-trace --stats run of this command, not this run)'
             roof['timed'] = ('HIP events on the launch stream around every %slaunch, in a second pass of %d iterations of the same loop '
                              'right after the timed region (the timed region itself carries no events); that pass took %.2f ms '
                              'per iteration' % ('%d-th per-control-step ' % args.profile_stride if args.profile_stride > 1 else '',
@@ -373,8 +527,8 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
             roof['kernel_time_ms_total'] = total
             out['roofline'] = roof
             out['kernels'] = kern
-        if extra:
-            out['extra'] = extra
+        extra['ranks'] = ranks
+        out['extra'] = extra
         if world == 1 and want_cpu:
             out['cpu_baseline'] = cpu_baseline()
     for m_ in models:
@@ -392,9 +546,9 @@ def main():
     ap.add_argument('--steps', type=int, default=None, help='timed iterations (default 10; 20 for the short iterations of c2 / c5)')
     ap.add_argument('--warmup', type=int, default=None, help='untimed iterations before (default 10: a cold device needs ~0.3 s of load to reach its clocks)')
     ap.add_argument('--envs', type=int, default=1024, help='env instances per GPU')
-    ap.add_argument('--agent', default='ma2c', choices=['ma2c', 'ia2c'])
+    ap.add_argument('--agent', default='ma2c', choices=['ma2c', 'ia2c', 'iqld', 'iqll'])
     ap.add_argument('--scenario', default='large_grid', choices=['large_grid', 'real_net'])
-    ap.add_argument('--policy', default='lstm', choices=['lstm', 'fc'], help='fc = FcACPolicy (BASELINE configs[1], ia2c only)')
+    ap.add_argument('--policy', default='lstm', choices=['lstm', 'fc', 'dqn', 'lr'], help='fc = FcACPolicy (BASELINE configs[1], ia2c only); dqn / lr: the IQL agents\' Q nets')
     ap.add_argument('--batches', type=int, default=1, help='independent half-batches per GPU on separate HIP streams')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the sim-only / sim+forward lines (SURVEY 8d) and the other single-GPU configs')
@@ -402,15 +556,16 @@ def main():
     ap.add_argument('--profile-stride', type=int, default=1,
                     help='profiled pass: HIP-event timing of every n-th launch of the per-control-step kernels (1 = all)')
     ap.add_argument('--profile-steps', type=int, default=0, help='iterations of the profiled pass (0 = same as --steps)')
-    ap.add_argument('--config', default=None, choices=['c2', 'c3', 'c5'],
+    ap.add_argument('--config', default=None, choices=['c2', 'c3', 'c5', 'q1'],
                     help='BASELINE.json configs[i] presets: c2 = large_grid IA2C FC, 256 envs; c3 = large_grid MA2C LSTM, 1024 envs '
-                         '(the default); c5 = real_net Monaco MA2C LSTM, 512 envs per GPU')
+                         '(the default); c5 = real_net Monaco MA2C LSTM, 512 envs per GPU; q1 = large_grid IQL-DNN, 1024 envs (SURVEY 8f rank 1: 20 control '
+                         'steps + 10 Adam minibatch steps per iteration)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='process-group backend for N > 1 (nccl = RCCL; gloo only for the two-ranks-on-one-GPU test)')
     ap.add_argument('--device', type=int, default=None, help='force this device index on every rank (test only)')
     args = ap.parse_args()
     # an iteration of c2 / c5 is 9-13 ms: two of them do not bring a cold device up to its clocks, six are 60 ms of timed region
-    short = args.config in ('c2', 'c5')
+    short = args.config in ('c2', 'c5', 'q1')
     if args.steps is None:
         args.steps = 20 if short else 10
     if args.warmup is None:
@@ -451,6 +606,10 @@ def main():
                 c['kernels'] = o['kernels']
             cfgs[name] = c
         out.setdefault('extra', {})['configs'] = cfgs
+        # the next row of SURVEY 8(f): the IQL-DNN learner on the same env path (config/config_iqld_large.ini), same method
+        o = run_config(args, rank, world, local, *PRESETS['q1'], 20, 10, want_extra=False, want_cpu=False, want_profile=False)
+        out['extra']['iql'] = {'workload': o['config']['workload'], 'value': o['value'], 'unit': o['unit'], 'ms_per_step': o['ms_per_step'],
+                               'steps': o['steps'], 'warmup': o['warmup'], 'mean_live_vehicles_per_env': o['config']['mean_live_vehicles_per_env']}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

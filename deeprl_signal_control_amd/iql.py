@@ -299,13 +299,17 @@ class VecIQL:
                                                stats.ctypes.data_as(C.c_void_p) if want_stats else None))
         return stats
 
-    def minibatch_step_at(self, idx, lr, want_stats=False):
+    def minibatch_step_at(self, idx, lr, want_stats=False, validate=True):
         """minibatch_step with the caller's draw: idx int32 [E, A, batch_size] (device), ring slots of every (instance,
-        agent) -- ReplayBuffer.sample_transition's pick (include/tsc.h tsc_iql_compute_grads_at)."""
+        agent) -- ReplayBuffer.sample_transition's pick (include/tsc.h tsc_iql_compute_grads_at).  validate: check the
+        draw against the filled part of the rings on the host (one device reduction + one blocking read; the library clamps
+        the indices anyway) -- switch it off on a throughput path."""
         assert idx.dtype == torch.int32 and idx.is_contiguous() and tuple(idx.shape) == (self.E, self.n_agent, self.n_step)
-        lo, hi, size = int(idx.min()), int(idx.max()), self.replay_size()[0]
-        if lo < 0 or hi >= size:        # the library would clamp; an index nobody filled is a caller bug (random.sample cannot produce one)
-            raise ValueError('minibatch_step_at: ring slots [%d, %d] outside the filled part [0, %d)' % (lo, hi, size))
+        if validate:
+            lo, hi = torch.stack(torch.aminmax(idx)).tolist()      # one reduction, one blocking read
+            size = self.replay_size()[0]                           # host-side bookkeeping of the library, no device access
+            if lo < 0 or hi >= size:    # an index nobody filled is a caller bug (random.sample cannot produce one)
+                raise ValueError('minibatch_step_at: ring slots [%d, %d] outside the filled part [0, %d)' % (lo, hi, size))
         _lib.check(self._L.tsc_iql_compute_grads_at(self._h, C.c_void_p(idx.data_ptr())))
         self.update_step += 1
         stats = np.zeros((self.n_agent, 2), np.float64) if want_stats else None

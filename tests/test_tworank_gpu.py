@@ -125,3 +125,8 @@ def test_bench_two_ranks_one_gpu():
     # whole-job figure: agents x instances of BOTH ranks x simulated seconds / the slower rank's time
     assert abs(d['value'] - 25 * 64 * 2 * 120 * 5 / (d['ms_per_step'] * 1e-3)) <= 1e-6 * d['value']
     assert 'cpu_baseline' not in d and 'configs' not in d.get('extra', {})          # N = 1 only
+    # the line proves how many ranks ran on how many devices (here: two ranks sharing device 0 over gloo)
+    rk = d['extra']['ranks']
+    assert rk['world'] == 2 and rk['backend'] == 'gloo' and rk['distinct_devices'] == 1
+    assert sorted(r['rank'] for r in rk['ranks']) == [0, 1] and len({r['pid'] for r in rk['ranks']}) == 2
+    assert all(r['device_index'] == 0 and r['device_name'] for r in rk['ranks'])
