@@ -228,7 +228,7 @@ def cpu_baseline(n_env=48, n_step=120, threads=8):
     return out
 
 
-def sim_only_all_cores(scn, target_s=4.0):
+def sim_only_all_cores(scn, target_s=3.0):
     """SURVEY 8(d) CPU baseline (ii): the C microsim alone over many env instances on ALL host cores -- one process per core
     (oracle/microsim_worker.py), every process a share of the instances, one full episode each under a fixed signal cycle,
     released together; value = agents x instances x simulated seconds / wall time from the release to the last answer."""
@@ -238,7 +238,18 @@ def sim_only_all_cores(scn, target_s=4.0):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    per = max(1024 // cores, int(target_s / 0.06))         # one episode is ~0.04-0.07 s of one core
+    # a container usually sees every core of the host but may only run on a quota of them: one process per core it can USE
+    for path, parse in (('/sys/fs/cgroup/cpu.max', lambda t: (lambda q, p_: None if q == 'max' else float(q) / float(p_))(*t.split()[:2])),
+                        ('/sys/fs/cgroup/cpu/cpu.cfs_quota_us', lambda t: None if int(t) <= 0 else int(t) / float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read()))):
+        try:
+            q = parse(open(path).read().strip())
+            if q:
+                cores = max(1, min(cores, int(q + 0.5)))
+            break
+        except Exception:
+            continue
+    cores = min(cores, 32)           # (a 256-thread GPU host ran 256 workers at the speed of ~9 cores: the quota is not always visible)
+    per = max(1, int(target_s / 0.06))                     # one episode is ~0.04-0.07 s of one core
     procs = []
     try:
         for w in range(cores):
@@ -250,7 +261,13 @@ def sim_only_all_cores(scn, target_s=4.0):
         t0 = time.perf_counter()
         for p in procs:
             p.stdin.write('go\n'); p.stdin.flush()
-        ans = [p.stdout.readline().split() for p in procs]
+        import select
+        ans = []
+        for p in procs:                                     # bounded: a box with fewer usable cores than it reports must not stall the line
+            left = 60.0 - (time.perf_counter() - t0)
+            if left <= 0 or not select.select([p.stdout], [], [], left)[0]:
+                raise RuntimeError('workers did not finish within 60 s (%d processes x %d instances)' % (cores, per))
+            ans.append(p.stdout.readline().split())
         dt = time.perf_counter() - t0
         live = float(np.mean([float(a[1]) for a in ans]))
         return {'value': scn.n_agent * cores * per * scn.episode_length_sec / dt, 'unit': 'env-steps/s', 'cores': cores,
@@ -262,7 +279,7 @@ def sim_only_all_cores(scn, target_s=4.0):
     finally:
         for p in procs:
             try:
-                p.stdin.close(); p.wait(timeout=10)
+                p.stdin.close(); p.wait(timeout=2)
             except Exception:
                 p.kill()
 

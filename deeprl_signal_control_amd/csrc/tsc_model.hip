@@ -31,6 +31,7 @@
 #include "../../include/tsc.h"
 
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -1256,8 +1257,14 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
         if (gs < 0) return;
         g = gs >> 8; sp = gs & 255;
     }
-    const int n_tiles = (E + 31) / 32;
-    const int t0 = (int)((long long)n_tiles * sp / S), t1 = (int)((long long)n_tiles * (sp + 1) / S);
+    // the workgroup's instances [eb, Ee): the tower's 16-instance half tiles dealt out evenly (E = 1024 over S = 5: 13 / 13 /
+    // 13 / 13 / 12 halves = at most 6.5 tiles; whole tiles would be 7 / 6 / 7 / 6 / 6).  It walks them as 32-instance tiles
+    // from eb; a last tile of <= 16 instances runs the half-tile gate GEMM (gate_interval<true>)
+    const int n_half = (E + 15) / 16;
+    const int eb = 16 * (int)((long long)n_half * sp / S);
+    const int Ee = min(E, 16 * (int)((long long)n_half * (sp + 1) / S));
+    const int nt = (Ee - eb + 31) / 32;                            // tiles of this workgroup, tile i = instances eb + 32 i ...
+    const bool last_half = Ee - (eb + 32 * (nt - 1)) <= 16;
     const int a = g >> 1, tower = g & 1, SMAX = lay.SMAX;
     const float *P = params + (long long)g * lay.stride;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31;
@@ -1287,18 +1294,18 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
     float *stb = state + (long long)g * E * 2 * kL;
     const float *obs_a = obs + a * SMAX;
     auto fetch_obs = [&](int e0) {
-        const unsigned e = (unsigned)(e0 + om < E ? e0 + om : E - 1);
+        const unsigned e = (unsigned)(e0 + om < Ee ? e0 + om : Ee - 1);
         return *reinterpret_cast<const float4 *>(obs_a + (e * (unsigned)AS + (unsigned)ok4));
     };
     auto fetch_state = [&](int e0, int off) {
-        const unsigned e = (unsigned)(e0 + ce < E ? e0 + ce : E - 1);
+        const unsigned e = (unsigned)(e0 + ce < Ee ? e0 + ce : Ee - 1);
         return *reinterpret_cast<const float4 *>(stb + (e * (unsigned)(2 * kL) + (unsigned)(off + cu)));
     };
-    auto fetch_keep = [&](int e0) { return 1.0f - (float)done[(unsigned)(e0 + ce < E ? e0 + ce : E - 1)]; };
+    auto fetch_keep = [&](int e0) { return 1.0f - (float)done[(unsigned)(e0 + ce < Ee ? e0 + ce : Ee - 1)]; };
     float4 ov = make_float4(0.f, 0.f, 0.f, 0.f), c4 = ov, h4 = ov;
     float keep = 0.f;
-    if (t0 >= t1) return;                                      // fewer tiles than workgroups per tower
-    ov = fetch_obs(32 * t0); c4 = fetch_state(32 * t0, 0); h4 = fetch_state(32 * t0, kL); keep = fetch_keep(32 * t0);
+    if (eb >= Ee) return;                                      // fewer half tiles than workgroups per tower
+    ov = fetch_obs(eb); c4 = fetch_state(eb, 0); h4 = fetch_state(eb, kL); keep = fetch_keep(eb);
     // ---- stationary operand, requested LAST: the first tile's obs / first-layer phases wait (counted, in order) only
     // for what was requested before it, so the 144 weight loads land under them instead of in front of the loop
     float bwg[KS2];
@@ -1316,7 +1323,7 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
     // softmax + action of the buffered tiles (~600 instructions per instance, half of them float64): one instance
     // per thread for up to kWsBuf tiles at once instead of 32 threads after every tile
     auto emit = [&](int e0p, int nbuf) {
-        if (tid >= 32 * nbuf || e0p + tid >= E) return;
+        if (tid >= 32 * nbuf || e0p + tid >= Ee) return;
         const long long idx = (long long)(e0p + tid) * lay.A + a;
         const float *lg = LG + tid * kOut;
         if (tower == 0) {
@@ -1402,7 +1409,7 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
         if (on) {
             const int t_ = opaque_tid(), ce = t_ >> 4, cu = (t_ & 15) * 4;
             *reinterpret_cast<float4 *>(XH + ce * LDK + H + cu) = hm;
-            if (tslot >= 0 && e0n + ce < E) st_stream4(Hpc + nbn * kL + (unsigned)(ce * kL + cu), hm);
+            if (tslot >= 0 && e0n + ce < Ee) st_stream4(Hpc + nbn * kL + (unsigned)(ce * kL + cu), hm);
         }
         return cmn;
     };
@@ -1421,7 +1428,7 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
             hn[jj] = go[jj] * tanhf_(cn[jj]);
             Hn[u * kWsLdg + ce] = hn[jj];
         }
-        if (e0c + ce < E) {
+        if (e0c + ce < Ee) {
             const float4 c4n = make_float4(cn[0], cn[1], cn[2], cn[3]), h4n = make_float4(hn[0], hn[1], hn[2], hn[3]);
             if (advance) {
                 float *st = stb + (long long)e0c * 2 * kL;
@@ -1439,32 +1446,37 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
         }
     };
     // head, second half: logits of tile tj = (units 0..31) + (units 32..63) + bias -> slot of the buffer
-    auto head_finish = [&](int tj) {
+    auto head_finish = [&](int ij) {                           // ij: tile index within the workgroup
         if (tid < 256) {
-            const int e = tid & 31, k0 = (tid >> 5) & 7, slot = (tj - t0) % kWsBuf;
+            const int e = tid & 31, k0 = (tid >> 5) & 7, slot = ij % kWsBuf;
             LG[(slot * 32 + e) * kOut + k0] = (LGp[tid] + LGp[256 + tid]) + WoS[kL * kOut + k0];
         }
     };
     const long long nbase = (long long)g * Ntot + (long long)(tslot < 0 ? 0 : tslot) * E;   // cache row of instance 0
-    // ---- pipeline fill: tile t0 staged, first layer + state in place, tile t0 + 1 requested
+    // ---- pipeline fill: tile 0 staged, first layer + state in place, tile 1 requested
     stage_obs();
     __syncthreads();
     first_layer();
-    cm = stage_state(32 * t0, nbase + 32 * t0, true);
+    cm = stage_state(eb, nbase + eb, true);
     // (all prefetches are unconditional -- the instance index is clamped -- so that each prefetched register has ONE
     //  definition per iteration and is waited for where it is consumed, not at a control-flow join)
-    ov = fetch_obs(32 * t0 + 32);
+    ov = fetch_obs(eb + 32);
     __syncthreads();
     WSTAMP();
-    for (int tt = t0; tt < t1; ++tt) {
-        const int e0 = 32 * tt;
+    // One tile = two barrier intervals.  HALF: the tile holds <= 16 instances (only ever the workgroup's last one): its gate
+    // GEMM runs on v_mfma_f32_16x16x4_f32 with the SAME stationary registers, re-paired in place for that instruction by
+    // v_permlane16_swap (below) -- half the matrix-core time of a 32-row tile, which is what lets the tower's instances be
+    // dealt out in 16-instance units.  Everything else of the tile (riding work, cell update, head) is shared.
+    auto tile = [&](auto half_tag, int it) {
+        constexpr bool HALF = decltype(half_tag)::value;
+        const int e0 = eb + 32 * it;
         const long long nb0 = nbase + e0;                         // first cache row of the tile
-        const bool more = tt + 1 < t1;
+        const bool more = it + 1 < nt;
         // ---- interval 1: next tile's obs -> LDS (the staging area is free since its first layer ran), the obs of the
         // tile after it requested; gate tile of this wave = bl + [X1 | h] [Wx ; Wh][:, 32w .. 32w+32)
         // the group of kWsBuf tiles whose last logits were written two intervals ago: softmax + action (LG is rewritten
         // only after this interval's barrier)
-        if (tt - t0 >= 2 && (tt - 2 - t0) % kWsBuf == kWsBuf - 1) emit(32 * (tt - 1 - kWsBuf), kWsBuf);
+        if (it >= 2 && (it - 2) % kWsBuf == kWsBuf - 1) emit(eb + 32 * (it - 1 - kWsBuf), kWsBuf);
         if (more) stage_obs();
         ov = fetch_obs(e0 + 64);
         c4 = fetch_state(e0 + 32, 0); h4 = fetch_state(e0 + 32, kL); keep = fetch_keep(e0 + 32);   // consumed right after the GEMM
@@ -1476,50 +1488,90 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
             const int t_ = opaque_tid(), li = t_ & 31, kh = (t_ >> 5) & 1, col = 32 * (t_ >> 6) + li;
             const float *hp = Hn + (32 * (t_ >> 8)) * kWsLdg + (t_ & 31), *wp = WoS + (32 * (t_ >> 8)) * kOut + ((t_ >> 5) & 7);
             f32x16 acc;
+            f32x4 acl, ach;                                        // HALF: columns [32w, 32w + 16) / [32w + 16, 32w + 32) of 16 instances
             float bl_ = blc;
             asm volatile("" : "+v"(bl_));                          // (a hoisted 16-register splat would be spilled)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = bl_;
-            const float4 *As = reinterpret_cast<const float4 *>(XH + li * LDK + 4 * kh);
             constexpr int NJ = KS2 / 4, PER = NJ / 4, HP = NJ / 8;
+            if constexpr (HALF) {
+                // v_mfma_f32_16x16x4_f32 wants B[k = lane / 16][n = lane % 16]; register 4 j4 + c holds W[8 j4 + 4 (lane / 32) + c]
+                // [32 w + lane % 32], i.e. its four 16-lane rows are (k_c, cols 0-15), (k_c, cols 16-31), (k_c + 4, cols 0-15),
+                // (k_c + 4, cols 16-31).  v_permlane16_swap exchanges the odd rows of its first operand with the even rows of its
+                // second: registers (c, c + 2) become rows (k_c, k_c + 2, k_c + 4, k_c + 6) x cols 0-15 and the same x cols 16-31 --
+                // two valid B operands whose A operand is X[row = lane % 16][8 j4 + 2 (lane / 16) + c], c = 0 / 1: one 8-byte
+                // LDS read per lane and j4.  In place: the half tile is the workgroup's last one, the weights are not needed again.
+#pragma unroll
+                for (int j4 = 0; j4 < NJ; ++j4) {
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const auto r2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(bwg[4 * j4 + c]), __float_as_uint(bwg[4 * j4 + c + 2]), false, false);
+                        bwg[4 * j4 + c] = __uint_as_float(r2[0]); bwg[4 * j4 + c + 2] = __uint_as_float(r2[1]);
+                    }
+                }
+                const float bl_lo = __shfl(bl_, (t_ & 15), 64), bl_hi = __shfl(bl_, 16 + (t_ & 15), 64);   // bias of the lane's two columns
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { acl[r] = bl_lo; ach[r] = bl_hi; }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = bl_;
+            }
+            const float4 *As = reinterpret_cast<const float4 *>(XH + li * LDK + 4 * kh);
+            const float2 *Ah = reinterpret_cast<const float2 *>(XH + (t_ & 15) * LDK + 2 * ((t_ >> 4) & 3));
             float hv[4], wv[4];
             float4 x1q = make_float4(0.f, 0.f, 0.f, 0.f);
             unsigned x1o = 0;
             float *x1b = tslot >= 0 ? X1c + nb0 * H : X1c + (long long)lay.G * Ntot * H;   // cache off: the spare tile behind the buffer
-            float4 a4 = As[0];
+            float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            float2 a2 = make_float2(0.f, 0.f);
+            if constexpr (HALF) a2 = Ah[0]; else a4 = As[0];
 #pragma unroll
             for (int j4 = 0; j4 < NJ; ++j4) {
-                const float4 an = As[2 * (j4 + 1 < NJ ? j4 + 1 : j4)];   // next quad in flight under this one's MFMAs
+                float4 an = a4;
+                float2 a2n = a2;
+                if constexpr (HALF) a2n = Ah[4 * (j4 + 1 < NJ ? j4 + 1 : j4)];      // next operands in flight under this group's MFMAs
+                else an = As[2 * (j4 + 1 < NJ ? j4 + 1 : j4)];
                 if (j4 % HP == 0 && j4 / HP < 8) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { hv[q] = hp[(4 * (j4 / HP) + q) * kWsLdg]; wv[q] = wp[(4 * (j4 / HP) + q) * kOut]; }
                 }
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bwg[4 * j4], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bwg[4 * j4 + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bwg[4 * j4 + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bwg[4 * j4 + 3], acc, 0, 0, 0);
+                if constexpr (HALF) {
+                    acl = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, bwg[4 * j4], acl, 0, 0, 0);
+                    ach = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, bwg[4 * j4 + 2], ach, 0, 0, 0);
+                    acl = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, bwg[4 * j4 + 1], acl, 0, 0, 0);
+                    ach = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, bwg[4 * j4 + 3], ach, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, bwg[4 * j4], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, bwg[4 * j4 + 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, bwg[4 * j4 + 2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, bwg[4 * j4 + 3], acc, 0, 0, 0);
+                }
                 if (j4 % HP == HP - 1 && j4 / HP < 8) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) hs0 += hv[q] * wv[q];
                 }
                 // this tile's X1 (in XH, row-major) -> the update's activation cache, 16 bytes per lane and quarter.  Branch-free:
-                // lanes past the tile re-store the quad of the lane 256 below, rows past E the last valid row (same values;
-                // distinct addresses, so that the duplicates do not serialise on one)
+                // lanes past the tile re-store the quad of the lane 256 below, rows past the workgroup's last instance the last
+                // valid row (same values; distinct addresses, so that the duplicates do not serialise on one)
                 if (j4 % PER == 3 && j4 / PER < (32 * (H / 4) + 511) / 512) {
                     int f = t_ + 512 * (j4 / PER);
                     f = f < 32 * (H / 4) ? f : f - 256;
                     int row = f / (H / 4);
                     const int c4i = f - row * (H / 4);
-                    row = e0 + row < E ? row : E - 1 - e0;
+                    row = e0 + row < Ee ? row : Ee - 1 - e0;
                     x1q = *reinterpret_cast<const float4 *>(XH + row * LDK + 4 * c4i);
                     x1o = (unsigned)(row * H + 4 * c4i);
                 }
                 if (j4 % PER == 5 && j4 / PER < (32 * (H / 4) + 511) / 512 ) st_stream4(x1b + x1o, x1q);
-                a4 = an;
+                a4 = an; a2 = a2n;
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (HALF) {                                  // D[row = 4 (lane / 16) + r][col = lane % 16]
+                const int cl = 32 * (t_ >> 6) + (t_ & 15), rw = 4 * ((t_ >> 4) & 3);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Gz[col * kWsLdg + (r & 3) + 8 * (r >> 2) + 4 * kh] = acc[r];
+                for (int r = 0; r < 4; ++r) { Gz[cl * kWsLdg + rw + r] = acl[r]; Gz[(cl + 16) * kWsLdg + rw + r] = ach[r]; }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Gz[col * kWsLdg + (r & 3) + 8 * (r >> 2) + 4 * kh] = acc[r];
+            }
             LGp[t_] = hs0;                                        // [half][output][instance]
             // what was requested before the GEMM has long arrived: wait for it HERE, in front of the stores below (vmcnt
             // retires in order and the stores are conditional, so a later wait would be a wait for the stores)
@@ -1529,35 +1581,38 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
         WSTAMP();
         __syncthreads();
         WSTAMP();
-        if (tt > t0) head_finish(tt - 1);
+        if (it > 0) head_finish(it - 1);
         // ---- interval 2: cell update of this tile | first layer of the next one (XH is free: the gate GEMM is done).
         // vmcnt retires in order and counts stores: what was requested before the GEMM is consumed (or at least waited
         // for) BEFORE this interval's ~30 streaming stores are issued, never behind them
         const float4 cmn = stage_state(e0 + 32, nb0 + 32, more);
 #pragma unroll 1
         for (int ph = 0; ph < 2; ++ph) {
-            if ((ph == 0) == (wave < 4)) cell(e0, nb0);
+            if ((ph == 0) == (wave < 4)) { if (!HALF || wave < 4) cell(e0, nb0); }    // HALF: instances 16 .. 31 (waves 4 - 7) do not exist
             else if (more) first_layer();
             WSTAMP();
         }
         cm = cmn;
         __syncthreads();
         WSTAMP();
-    }
+    };
+    const int nt_full = last_half ? nt - 1 : nt;
+    for (int it = 0; it < nt_full; ++it) tile(std::false_type{}, it);
+    if (last_half) tile(std::true_type{}, nt - 1);
     // ---- drain: a full group still waiting for its softmax, then the head of the last tile and its group
     {
-        const int tl = t1 - 1;
-        if (tl - t0 >= 1 && (tl - 1 - t0) % kWsBuf == kWsBuf - 1) emit(32 * (tl - kWsBuf), kWsBuf);
+        const int il = nt - 1;
+        if (il >= 1 && (il - 1) % kWsBuf == kWsBuf - 1) emit(eb + 32 * (il - kWsBuf), kWsBuf);
         float hs0 = 0.f;
         const int e = tid & 31, k0 = (tid >> 5) & 7, hf = tid >> 8;
 #pragma unroll 8
         for (int jj = 0; jj < 32; ++jj) hs0 += Hn[(32 * hf + jj) * kWsLdg + e] * WoS[(32 * hf + jj) * kOut + k0];
         LGp[tid] = hs0;
         __syncthreads();
-        head_finish(tl);
+        head_finish(il);
         __syncthreads();
-        const int slot = (tl - t0) % kWsBuf;
-        emit(32 * (tl - slot), slot + 1);
+        const int slot = il % kWsBuf;
+        emit(eb + 32 * (il - slot), slot + 1);
     }
     if (stamp) dbg[63] = nstamp;
 #undef WSTAMP

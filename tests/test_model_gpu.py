@@ -409,8 +409,11 @@ def _read_cache(m, what, g, row0, nrows, width):
 
 
 @pytest.mark.parametrize('scenario,agent,E,ws', [
-    ('large_grid', 'ma2c', 1024, '1'),      # bench.py's shape: 5 workgroups per tower x 6-7 tiles each, 8-slot logits buffer
-    ('large_grid', 'ma2c', 200, '1'),       # ragged last tile (200 = 6 x 32 + 8)
+    ('large_grid', 'ma2c', 1024, '1'),      # bench.py's shape: 5 workgroups per tower x 13 / 12 half tiles (6 tiles + a 16-instance one), 8-slot logits buffer
+    ('large_grid', 'ma2c', 200, '1'),       # ragged: 13 half tiles over 5 workgroups (2 / 3 / 2 / 3 / 3), the last one holds 8 instances
+    ('large_grid', 'ma2c', 1000, '1'),      # 63 half tiles: 12 / 13 / 12 / 13 / 13, the last one 8 instances
+    ('large_grid', 'ma2c', 48, '1'),        # one workgroup per tower: a full tile + a half tile
+    ('large_grid', 'ma2c', 16, '1'),        # nothing but a half tile
     ('large_grid', 'ia2c', 1024, '1'),      # H = 160 instantiation
     ('large_grid', 'ma2c', 200, '0'),       # TSC_FWD_WS=0: policy_fwd_fused_kernel, ragged 64-instance tile
     ('real_net', 'ma2c', 200, '1'),         # Monaco: H = 192 -> policy_fwd_ws_kernel<128>, n_a 2..6, no wait state
@@ -428,7 +431,7 @@ def test_forward_sample_multi_tile_vs_oracle(scenario, agent, E, ws, monkeypatch
     rng = np.random.RandomState(E + len(agent))
     m.reset(); o.reset()
     done = np.ones(E, np.uint8)
-    rows = sorted(set(list(range(0, E, 37)) + [31, 32, 63, 64, E - 33, E - 2, E - 1]))       # rows of every tile
+    rows = sorted(r for r in set(list(range(0, E, 37)) + [15, 16, 31, 32, 63, 64, E - 33, E - 17, E - 2, E - 1]) if 0 <= r < E)   # rows of every tile
     for t in range(T):
         obs = _rand_obs(scn, E, rng)
         s_before = [s.clone() for s in o.s_fw]
