@@ -1305,6 +1305,7 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
     float4 ov = make_float4(0.f, 0.f, 0.f, 0.f), c4 = ov, h4 = ov;
     float keep = 0.f;
     if (eb >= Ee) return;                                      // fewer half tiles than workgroups per tower
+    if (dbg && threadIdx.x == 0) dbg[64 + 2 * blockIdx.x] = wall_clock64();      // tools/bench_fwd.py: start / end of every workgroup (100 MHz)
     ov = fetch_obs(eb); c4 = fetch_state(eb, 0); h4 = fetch_state(eb, kL); keep = fetch_keep(eb);
     // ---- stationary operand, requested LAST: the first tile's obs / first-layer phases wait (counted, in order) only
     // for what was requested before it, so the 144 weight loads land under them instead of in front of the loop
@@ -1615,6 +1616,7 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
         emit(eb + 32 * (il - slot), slot + 1);
     }
     if (stamp) dbg[63] = nstamp;
+    if (dbg && threadIdx.x == 0) dbg[64 + 2 * blockIdx.x + 1] = wall_clock64();
 #undef WSTAMP
 }
 

@@ -44,6 +44,15 @@ for label, fn in (('back to back', lambda: None), ('64 MB memset between', lambd
     live = w[:, 1] > 0
     if not live.any():
         continue
+    if n > 9:          # weight-stationary kernel: which workgroups are the long ones (13 or 12 half tiles of 16 instances)
+        S = max(1, 256 // m.G)
+        d_all = (w[:, 1] - w[:, 0]) / 100.0
+        e_all = (w[:, 1] - w[live, 0].min()) / 100.0
+        order = np.argsort(-e_all)[:8]
+        print('   last workgroups to end (block id: start, duration, end us): ' +
+              ', '.join('%d: %.1f %.1f %.1f' % (b, (w[b, 0] - w[live, 0].min()) / 100.0, d_all[b], e_all[b]) for b in order))
+        hist = np.histogram(d_all[live], bins=8)
+        print('   duration histogram (us): ' + ', '.join('%.1f-%.1f: %d' % (hist[1][i], hist[1][i + 1], hist[0][i]) for i in range(8)))
     st = (w[live, 0] - w[live, 0].min()) / 100.0
     en = (w[live, 1] - w[live, 0].min()) / 100.0
     dur = en - st

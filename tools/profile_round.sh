@@ -1,19 +1,45 @@
 #!/bin/bash
 # Profiles of one round, on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh r04
-# 1. rocprofv3 --kernel-trace --stats of `python bench.py` (every launch timed by the profiler)
-# 2. PMC passes, each in its own run without any trace (MI355X_MICROARCH.md "HBM / rocprofv3"): FETCH_SIZE, WRITE_SIZE, SQ
-# Output: rocpd databases under gpurun_out/<tag>_*; fold them with tools/rocpd_stats.py / tools/rocpd_pmc.py into profiles/.
+#   tools/profile_round.sh r05 [c3 c2 c5 q1]
+# per configuration (c3 = the default workload; suffix "" / _c2 / _c5 / _q1):
+# 1. the bench line (c3: the driver line `python bench.py` with extra.configs and cpu_baseline)
+# 2. rocprofv3 --kernel-trace --stats of the same command (every launch timed by the profiler)
+# 3. PMC passes, each in its own run without any trace (MI355X_MICROARCH.md "HBM / rocprofv3"): FETCH_SIZE, WRITE_SIZE, SQ.
+#    The FETCH / WRITE passes cover WHOLE EPISODES (one warm-up episode + one timed episode), so that the per-launch averages
+#    belong to the episode-mean vehicle count the bench line of the pass reports (bench.py refuses a summary whose count is
+#    more than 15 % off the run's).
+# Output: rocpd databases under gpurun_out/<tag>_*; folded into gpurun_out/<tag>/ by tools/rocpd_stats.py / tools/rocpd_pmc.py
+# (copy that directory's files into profiles/).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
+shift
+CFGS=${@:-c3 c2 c5 q1}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
-mkdir -p $OUT
+RES=$OUT/$TAG
+mkdir -p $RES
 cd /tmp && export TMPDIR=/tmp
-python $ROOT/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err       # the driver line (c3 + extra.configs c2 / c5 + cpu_baseline)
-B="python $ROOT/bench.py --no-cpu-baseline --no-extra"
-rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o ${TAG} -- $B --steps 3 --warmup 1 --no-profile > $OUT/${TAG}_bench_rocprof.json 2> $OUT/${TAG}_trace.err
-rocprofv3 --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_fetch -o f -- $B --steps 1 --warmup 1 --no-profile > /dev/null 2> $OUT/${TAG}_pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_write -o w -- $B --steps 1 --warmup 1 --no-profile > /dev/null 2> $OUT/${TAG}_pmc_write.err
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/${TAG}_pmc_sq -o s -- $B --steps 1 --warmup 1 --no-profile > /dev/null 2> $OUT/${TAG}_pmc_sq.err
-find $OUT -name "*.db" | xargs ls -la
+for C in $CFGS; do
+  case $C in
+    c3) SUF=""; EP=6;;        # iterations per episode: 720 control steps / n_step
+    c2) SUF="_c2"; EP=6;;
+    c5) SUF="_c5"; EP=18;;
+    q1) SUF="_q1"; EP=36;;
+  esac
+  B="python $ROOT/bench.py --config $C --no-cpu-baseline --no-extra"
+  if [ $C = c3 ]; then
+    python $ROOT/bench.py > $RES/${TAG}_bench.json 2> $OUT/${TAG}_bench.err           # the driver line
+  else
+    python $ROOT/bench.py --config $C --no-cpu-baseline > $RES/${TAG}_bench${SUF}.json 2> $OUT/${TAG}_bench${SUF}.err
+  fi
+  rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace${SUF} -o t -- $B --steps 3 --warmup 1 --no-profile > $RES/${TAG}_bench_rocprof${SUF}.json 2> $OUT/${TAG}_trace${SUF}.err
+  python $ROOT/tools/rocpd_stats.py $(find $OUT/${TAG}_trace${SUF} -name "*.db" | head -1) $RES/${TAG}_kernel_stats${SUF}.csv
+  [ $C = q1 ] && continue
+  rocprofv3 --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_fetch${SUF} -o f -- $B --steps $EP --warmup $EP --no-profile > $OUT/${TAG}_pmc_fetch${SUF}.json 2> $OUT/${TAG}_pmc_fetch${SUF}.err
+  rocprofv3 --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_write${SUF} -o w -- $B --steps $EP --warmup $EP --no-profile > $OUT/${TAG}_pmc_write${SUF}.json 2> $OUT/${TAG}_pmc_write${SUF}.err
+  python $ROOT/tools/rocpd_pmc.py traffic $(find $OUT/${TAG}_pmc_fetch${SUF} -name "*.db" | head -1) $(find $OUT/${TAG}_pmc_write${SUF} -name "*.db" | head -1) \
+         $RES/${TAG}_pmc${SUF}.json $OUT/${TAG}_pmc_fetch${SUF}.json "$B --steps $EP --warmup $EP --no-profile"
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/${TAG}_pmc_sq${SUF} -o s -- $B --steps 1 --warmup $EP --no-profile > /dev/null 2> $OUT/${TAG}_pmc_sq${SUF}.err
+  python $ROOT/tools/rocpd_pmc.py sq $(find $OUT/${TAG}_pmc_sq${SUF} -name "*.db" | head -1) $RES/${TAG}_pmc_sq${SUF}.csv
+done
+ls -la $RES

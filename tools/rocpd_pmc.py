@@ -41,16 +41,25 @@ def per_kernel(db, counter):
     return out
 
 
-def traffic(fetch_db, write_db, out_path):
+def traffic(fetch_db, write_db, out_path, bench_line=None, command=None):
+    """bench_line: the JSON line bench.py printed under the FETCH pass -- its window-mean vehicles per instance and its
+    workload are recorded next to the counters (bench.py:pmc_traffic compares that figure with its own run's)."""
     f, w = per_kernel(fetch_db, 'FETCH_SIZE'), per_kernel(write_db, 'WRITE_SIZE')
     kern = {}
     for k in sorted(set(f) | set(w)):
         ft, fn = f.get(k, (0.0, 0))
         wt, wn = w.get(k, (0.0, 0))
         kern[k] = {'fetch_kb': ft / max(fn, 1), 'write_kb': wt / max(wn, 1), 'launches': max(fn, wn)}
-    doc = {'command': 'tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python bench.py --steps 1 '
-                      '--warmup 1 --no-cpu-baseline --no-extra --no-profile; folded by tools/rocpd_pmc.py',
+    doc = {'command': 'tools/profile_round.sh: rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- %s; folded by '
+                      'tools/rocpd_pmc.py' % (command or 'python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra --no-profile'),
            'units': 'KB per launch (average over launches)', 'kernels': kern}
+    if bench_line:
+        line = [l for l in open(bench_line) if l.startswith('{')][-1]
+        b = json.loads(line)
+        doc['mean_live_vehicles_per_env'] = b['config']['mean_live_vehicles_per_env']
+        doc['live_vehicles'] = ('window mean over the timed iterations of the FETCH pass (one whole episode; the warm-up iterations are '
+                                'another whole episode with the same statistics, and the counters average over both)')
+        doc['workload'] = b['config']['workload']
     json.dump(doc, open(out_path, 'w'), indent=1)
     print('%d kernels -> %s' % (len(kern), out_path))
 
@@ -82,6 +91,6 @@ def sq(db, out_path):
 
 if __name__ == '__main__':
     if sys.argv[1] == 'traffic':
-        traffic(sys.argv[2], sys.argv[3], sys.argv[4])
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4], *(sys.argv[5:7]))
     else:
         sq(sys.argv[2], sys.argv[3])
