@@ -404,7 +404,7 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
     envs, models = [], []
     for b in range(B):
         envs.append(VecTrafficEnv(scn, Eb, device=local, seed=seed0 + rank * E + b * Eb, seed_stride=E * world,
-                                  test_seeds=tseeds))
+                                  test_seeds=tseeds, resident=E))      # half-batches share the device: its load is E, not E / B
         # same weight-init seed on every rank / half-batch (replicas of one learner), own action stream each
         if is_q:
             from deeprl_signal_control_amd.iql import VecIQL

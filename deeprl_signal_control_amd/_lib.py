@@ -41,7 +41,7 @@ _LIB = None
 
 # every symbol include/tsc.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = ['tsc_last_error', 'tsc_version', 'tsc_profile_enable', 'tsc_profile_reset', 'tsc_profile_read',
-           'tsc_profile_name', 'tsc_env_create', 'tsc_env_destroy', 'tsc_env_set_stream',
+           'tsc_profile_name', 'tsc_env_create', 'tsc_env_destroy', 'tsc_env_set_stream', 'tsc_env_set_resident_instances',
            'tsc_env_reset', 'tsc_env_set_stream_routes', 'tsc_env_set_greedy', 'tsc_env_greedy_actions', 'tsc_env_set_fingerprint', 'tsc_env_bind_fingerprint', 'tsc_env_reward_sum', 'tsc_env_step', 'tsc_env_get_state',
            'tsc_env_live_vehicles', 'tsc_env_counters', 'tsc_env_debug_clock', 'tsc_env_live_sum', 'tsc_env_record', 'tsc_env_read_record', 'tsc_env_read_trips',
            'tsc_model_create', 'tsc_model_destroy', 'tsc_model_set_stream', 'tsc_model_layout',
@@ -74,6 +74,7 @@ def lib():
     L.tsc_env_create.argtypes = [C.POINTER(TscScenario), C.c_int32, C.c_int32, C.POINTER(vp)]
     L.tsc_env_destroy.argtypes = [vp]
     L.tsc_env_set_stream.argtypes = [vp, vp]
+    L.tsc_env_set_resident_instances.argtypes = [vp, C.c_int32]
     L.tsc_env_reset.argtypes = [vp, C.POINTER(C.c_uint32), vp]
     L.tsc_env_set_stream_routes.argtypes = [vp, _ip]
     L.tsc_env_set_fingerprint.argtypes = [vp, vp]

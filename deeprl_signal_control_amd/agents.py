@@ -192,7 +192,7 @@ def coerce_config(model_config, defaults):
     return cfg
 
 
-CKPT_FORMAT = 2      # checkpoint npz `format` entry: 2 = counters hold the BASE seed (absent = rounds 1-2: the derived per-rank seed)
+CKPT_FORMAT = 2      # checkpoint npz `format` entry: 2 = counters hold the BASE seed (absent: rounds 1-3, the same meaning in practice -- resume_sample_seed)
 
 
 def replica_sample_seed(seed, rank=0, replica=0):
@@ -205,12 +205,13 @@ def replica_sample_seed(seed, rank=0, replica=0):
 
 
 def resume_sample_seed(stored_seed, fmt, rank=0, replica=0):
-    """(base_seed or None, sample_seed) from the seed slot of a checkpoint's `counters`: format >= 2 stores the BASE seed and
-    every rank / replica re-derives its own stream; files without a `format` entry (rounds 1-2) stored the stream seed the
-    saving rank had already derived, which is used as it is."""
-    if fmt is not None and int(fmt) >= 2:
-        return int(stored_seed), replica_sample_seed(int(stored_seed), rank, replica)
-    return None, int(stored_seed)
+    """(base_seed, sample_seed) from the seed slot of a checkpoint's `counters`.  Format 2 stores the BASE seed and every
+    rank / replica re-derives its own stream.  Files without a `format` entry are read the same way: round 3
+    already stored the base seed, without the marker, and the files of rounds 1 - 2 were written by rank 0 / replica 0, whose
+    stream seed IS the base seed (replica_sample_seed returns it unchanged there) -- taking the stored value as an
+    already-derived stream would put every rank and replica that resumes from such a file on rank 0's action stream."""
+    del fmt                                                        # every format written so far holds the base seed in this slot
+    return int(stored_seed), replica_sample_seed(int(stored_seed), rank, replica)
 
 
 def allreduce_grads_(flat_grad, group=None):

@@ -1141,7 +1141,27 @@ struct tsc_env {
     int spec;                       // 1: the scenario has the large_grid table dimensions -> specialised step_kernel (TSC_ENV_SPEC=0: off)
     uint32_t *d_seeds;
     std::vector<int> h_mode, h_sroute;      // host copies of the stream tables (tsc_env_set_stream_routes)
+    bool auto_threads;              // the workgroup size follows the number of instances resident on the device (pick_workgroup)
+    int kf_default;
 };
+
+// Workgroup size / flat-phase width of the specialised step kernels for `n_resident` env instances on the device (this handle's
+// and whatever shares the GPU with it); TSC_ENV_THREADS / TSC_ENV_KF override (measurement / test knobs).
+static void pick_workgroup(tsc_env *h, int n_resident) {
+    if (h->auto_threads) {
+        int dev_cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) dev_cus = prop.multiProcessorCount;
+        h->threads = 256; h->kf = h->kf_default;
+        if (n_resident <= dev_cus) { h->threads = 1024; h->kf = 1; }
+        else if (n_resident <= 2 * dev_cus) { h->threads = 512; h->kf = 2; }  // (Monaco, E = 512, saturated: 59.6 us with 2, 67.1 with 1)
+    }
+    if (const char *ev = getenv("TSC_ENV_THREADS")) {
+        const int tv = atoi(ev);
+        if (tv >= h->P.NLA && tv <= 1024 && tv % 64 == 0) h->threads = tv;
+    }
+    if (const char *ev = getenv("TSC_ENV_KF")) { const int kv = atoi(ev); h->kf = (kv == 2 || kv == 4) ? kv : 1; }
+}
 
 namespace tsc {
 ProfState &prof() { static ProfState p; return p; }
@@ -1449,18 +1469,11 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     // the same instance instead of leaving the slots idle (sim only, saturated large_grid: E = 256: 63.0 -> 52.5 us per control
     // step with 1024 threads, E = 512: 70.9 -> 64.8 us with 512; Monaco 69.6 -> 59.9 / 77.9 -> 71.5; E = 1024 wants 256).
     // TSC_ENV_THREADS overrides (parity tests run every size).
-    if (h->spec && P.help && h->threads == 256) {
-        int dev_cus = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) dev_cus = prop.multiProcessorCount;
-        if (n_env <= dev_cus) { h->threads = 1024; h->kf = 1; }
-        else if (n_env <= 2 * dev_cus) { h->threads = 512; h->kf = 2; }       // (Monaco, E = 512, saturated: 59.6 us with 2, 67.1 with 1)
-    }
-    if (const char *ev = getenv("TSC_ENV_THREADS")) {       // measurement / test knob
-        const int tv = atoi(ev);
-        if (tv >= P.NLA && tv <= 1024 && tv % 64 == 0) h->threads = tv;
-    }
-    if (const char *ev = getenv("TSC_ENV_KF")) { const int kv = atoi(ev); h->kf = (kv == 2 || kv == 4) ? kv : 1; }
+    // What counts is how many instances share the DEVICE, not this handle's own: tsc_env_set_resident_instances (half-batches on
+    // separate streams, ranks sharing a GPU).
+    h->auto_threads = h->spec && P.help && h->threads == 256;
+    h->kf_default = h->kf;
+    pick_workgroup(h, n_env);
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
@@ -1545,6 +1558,12 @@ int tsc_env_destroy(tsc_env *h) {
     (void)hipSetDevice(h->device);
     for (void *p : h->allocs) (void)hipFree(p);
     delete h;
+    return 0;
+}
+
+int tsc_env_set_resident_instances(tsc_env *h, int32_t n_resident) {
+    if (!h || n_resident <= 0) return tsc::fail("tsc_env_set_resident_instances: bad arguments");
+    pick_workgroup(h, n_resident > h->P.E ? n_resident : h->P.E);
     return 0;
 }
 

@@ -648,7 +648,10 @@ __device__ __forceinline__ int sample_action(const float *pi, int na, unsigned l
 // cache: its update re-evaluates the forward at training shape.  51 us per launch at E = 256 (round 2's four launches per
 // control step -- two grouped GEMMs, heads, sampling -- took 85 us); the 100 workgroups are a latency chain each (quad LDS
 // reads with all 16 units per pass measured slower: 57 us).  Since the MFMA formulation below (22.7 us) this kernel serves first
-// layers that are not a multiple of 32 columns wide, and TSC_FC_MFMA=0.
+// layers that are not a multiple of 32 columns wide, and TSC_FC_MFMA=0.  The two kernels are NOT bit-identical: this one sums the 64
+// hidden units of a head sequentially (head_eval), the MFMA kernel as 16 four-unit partial sums folded by an xor-shuffle tree; logits,
+// pi and v agree to float32 rounding and a sampled action can differ where the uniform sits within that rounding of a boundary of
+// the cumulative distribution (tests/test_model_gpu.py::test_fc_policy_forward_kernels_agree_with_each_other).
 // ------------------------------------------------------------------------------------------------
 constexpr int kFcLdo = 64 + 1;
 __global__ void __launch_bounds__(512) policy_fwd_fc_kernel(const float *__restrict__ params, Layout lay, const int *__restrict__ n_act,

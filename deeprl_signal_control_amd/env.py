@@ -25,7 +25,7 @@ class VecTrafficEnv:
     mode advances its seed by ``seed_stride`` (1 for E = 1, like the reference)."""
 
     def __init__(self, scn: Scenario, n_env: int, device=0, seed=12, test_seeds=(10000, 20000),
-                 seed_stride=None):
+                 seed_stride=None, resident=None):
         if not torch.cuda.is_available():
             raise RuntimeError('VecTrafficEnv needs a GPU (MI355X); there is no CPU fallback')
         self.scn = scn
@@ -52,6 +52,8 @@ class VecTrafficEnv:
         h = C.c_void_p()
         _lib.check(L.tsc_env_create(C.byref(sc), self.E, self.device.index or 0, C.byref(h)))
         self._h = h
+        if resident is not None:        # env instances sharing the device with these (other handles / ranks), these included
+            _lib.check(L.tsc_env_set_resident_instances(h, int(resident)))
         with torch.cuda.device(self.device):
             self.stream = torch.cuda.current_stream(self.device)
             _lib.check(L.tsc_env_set_stream(h, C.c_void_p(self.stream.cuda_stream)))
@@ -103,6 +105,7 @@ class VecTrafficEnv:
             self.control_data = [[] for _ in range(self.E)]
             self.trip_data = [[] for _ in range(self.E)]
             self.teleported_trips = [0] * self.E     # trips of the episode the teleport surrogate truncated (not in trip_data)
+            self.truncated_trip_data = [[] for _ in range(self.E)]     # ... their rows (own table, see collect_tripinfo)
 
     def counters(self):
         """Per-instance counters of the running episode: (arrived, teleported), int64 [E] each.  `arrived` is the episode sum
@@ -150,6 +153,16 @@ class VecTrafficEnv:
             # a negative arrival marks a trip the teleport surrogate truncated (include/tsc.h tsc_env_read_trips): SUMO's
             # tripinfo file only lists vehicles that arrived, so the reference's collect_tripinfo never sees such a row
             self.teleported_trips[e] += int((tr[:, 3] < 0).sum())
+            # ... but SUMO would have teleported the vehicle on and listed it later with a LONG duration: leaving these rows
+            # out drops the worst-delayed trips of the episode, so they are kept apart (a fourth table, *_trip_truncated.csv,
+            # with the time in the network and the waiting accumulated up to the removal) -- any trip-time / wait average
+            # over the trip table alone is biased low by them
+            cut = tr[tr[:, 3] < 0]
+            cut = cut[np.lexsort((cut[:, 1], cut[:, 0], -cut[:, 3]))]
+            for r, ser, dep, arr, wsec, wcnt in cut:
+                self.truncated_trip_data[e].append({'episode': self.cur_episode, 'id': 'f_%d.%d' % (r, ser), 'depart_sec': '%.2f' % dep,
+                                                    'removed_sec': '%.2f' % (-arr), 'duration_sec': '%.2f' % (-arr - dep),
+                                                    'wait_step': '%d' % wcnt, 'wait_sec': '%.2f' % wsec})
             tr = tr[tr[:, 3] >= 0]
             tr = tr[np.lexsort((tr[:, 1], tr[:, 0], tr[:, 3]))]
             for r, ser, dep, arr, wsec, wcnt in tr:
@@ -162,7 +175,10 @@ class VecTrafficEnv:
         alphabetical order, as in real_net_experimental_data/eva_data/)."""
         import pandas as pd
         name = name or self.scn.name
-        for kind, rows in (('control', self.control_data[e]), ('traffic', self.traffic_data[e]), ('trip', self.trip_data[e])):
+        for kind, rows in (('control', self.control_data[e]), ('traffic', self.traffic_data[e]), ('trip', self.trip_data[e]),
+                           ('trip_truncated', self.truncated_trip_data[e])):
+            if kind == 'trip_truncated' and not rows:
+                continue                                    # the reference's three tables always; the fourth only when it has rows
             df = pd.DataFrame(rows)
             df = df[sorted(df.columns)] if len(df.columns) else df
             df.to_csv(output_path + ('%s_%s_%s.csv' % (name, self.agent, kind)))
@@ -351,6 +367,7 @@ class TrafficEnv:
     traffic_data = property(lambda self: self.vec.traffic_data[0])
     control_data = property(lambda self: self.vec.control_data[0])
     trip_data = property(lambda self: self.vec.trip_data[0])
+    truncated_trip_data = property(lambda self: self.vec.truncated_trip_data[0])
 
     def collect_tripinfo(self):
         """envs/env.py:498-515 (call after the episode, like the reference's evaluation scripts)."""

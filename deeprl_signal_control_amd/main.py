@@ -197,10 +197,20 @@ def write_eval_tables(env, output_dir):
     """envs/env.py:534-542 over all evaluated instances: instance e is episode e + 1 (the reference runs the seeds one
     after the other and numbers them by cur_episode)."""
     import pandas as pd
-    for kind, per_env in (('control', env.control_data), ('traffic', env.traffic_data), ('trip', env.trip_data)):
+    for kind, per_env in (('control', env.control_data), ('traffic', env.traffic_data), ('trip', env.trip_data),
+                          ('trip_truncated', getattr(env, 'truncated_trip_data', []))):
         rows = []
         for e, rs in enumerate(per_env):
             rows += [dict(r, episode=e + 1) for r in rs]
+        if kind == 'trip_truncated':
+            if not rows:
+                continue
+            # trips the teleport surrogate cut short (DESIGN.md 3 rule 1): not in the trip table (SUMO's tripinfo would list them
+            # later, with long durations), so averages over the trip table alone are biased low -- say so where it is read
+            logging.info('Evaluation: %d trips truncated by the teleport surrogate (mean %.1f s in the network, %.1f s waiting) are in '
+                         '%s_%s_trip_truncated.csv, not in the trip table' % (
+                             len(rows), np.mean([float(r['duration_sec']) for r in rows]), np.mean([float(r['wait_sec']) for r in rows]),
+                             env.scn.name, env.agent))
         df = pd.DataFrame(rows)
         if len(df.columns):
             df = df[sorted(df.columns)]

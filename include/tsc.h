@@ -110,6 +110,11 @@ const char *tsc_profile_name(int32_t kernel_id);   /* "" past the last id */
 int tsc_env_create(const tsc_scenario *scn, int32_t n_env, int32_t device, tsc_env **out);
 int tsc_env_destroy(tsc_env *h);                               /* terminate(), envs/env.py:563 */
 int tsc_env_set_stream(tsc_env *h, void *hip_stream);
+/* How many env instances share the DEVICE with this handle's (other handles of the process -- half-batches on separate
+ * streams -- or other ranks on the same GPU), this handle's included.  The step kernel's workgroup size follows the device's
+ * load, not the handle's: with fewer instances than workgroup slots an instance is spread over 512 / 1024 threads, with a full
+ * device it runs 256.  Default: the handle's own n_env.  (No reference counterpart: one SUMO process per env, main.py:93.) */
+int tsc_env_set_resident_instances(tsc_env *h, int32_t n_resident);
 
 /* reset(), envs/env.py:544-561.  seeds: host [E] (the caller does the reference's
  * `seed += 1` bookkeeping); obs: dev float32 [E, A, SMAX] = float32(state) at t = 0. */

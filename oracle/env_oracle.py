@@ -165,6 +165,11 @@ class OracleEnv:
         for r, ser, dep, arr, wsec, wcnt in self.ms.trips():
             if arr < 0:                                        # truncated by the teleport surrogate: not in SUMO's tripinfo file
                 self.teleported_trips = getattr(self, 'teleported_trips', 0) + 1
+                if not hasattr(self, 'truncated_trip_data'):
+                    self.truncated_trip_data = []
+                self.truncated_trip_data.append({'episode': self.cur_episode, 'id': 'f_%d.%d' % (r, ser), 'depart_sec': '%.2f' % dep,
+                                                 'removed_sec': '%.2f' % (-arr), 'duration_sec': '%.2f' % (-arr - dep),
+                                                 'wait_step': '%d' % wcnt, 'wait_sec': '%.2f' % wsec})
                 continue
             self.trip_data.append({'episode': self.cur_episode, 'id': 'f_%d.%d' % (r, ser), 'depart_sec': '%.2f' % dep,
                                    'arrival_sec': '%.2f' % arr, 'duration_sec': '%.2f' % (arr - dep), 'wait_step': '%d' % wcnt,

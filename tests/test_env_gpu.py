@@ -219,3 +219,25 @@ def test_flat_phase_super_rounds_at_saturation(kf, spec, threads, monkeypatch):
         for k in ('n', 'x', 'v', 'sf', 'w', 'r'):
             np.testing.assert_array_equal(st[k], sn[k], err_msg='state %s e=%d' % (k, e))
     env.close()
+
+
+def test_resident_instances_hint_changes_the_launch_shape_not_the_results():
+    """tsc_env_set_resident_instances: a handle of 64 instances on an otherwise empty device spreads every instance
+    over 1024 threads; told that 2048 instances share the device it runs the 256-thread workgroups of a full device.  Same
+    observations, rewards and vehicle state bit for bit (the parity tests above pin each size to the oracle)."""
+    from deeprl_signal_control_amd.env import VecTrafficEnv
+    scn = build_large_grid('ma2c')
+    E = 64
+    envs = [VecTrafficEnv(scn, E, seed=31), VecTrafficEnv(scn, E, seed=31, resident=2048)]
+    rng = np.random.RandomState(4)
+    for e_ in envs:
+        e_.reset()
+    for t in range(40):
+        act = torch.from_numpy(rng.randint(0, 5, (E, 25)).astype(np.int32)).cuda()
+        outs = [e_.step(act) for e_ in envs]
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    s0, s1 = envs[0].get_state(5), envs[1].get_state(5)
+    for k in ('n', 'x', 'v', 'sf', 'w', 'r'):
+        np.testing.assert_array_equal(s0[k], s1[k])
+    for e_ in envs:
+        e_.close()

@@ -145,6 +145,13 @@ def test_teleported_trips_are_counted_apart_from_arrivals():
     assert len(env.trip_data) == len(orc.trip_data) == tot['arrived']
     key = lambda r: (float(r['arrival_sec']), r['id'])
     assert sorted(env.trip_data, key=key) == sorted(orc.trip_data, key=key)
+    # the truncated trips keep their rows in a table of their own (they are the worst-delayed trips of the episode --
+    # every one stood for time-to-teleport seconds -- and must not silently vanish from the evaluation output)
+    kc = lambda r: (float(r['removed_sec']), r['id'])
+    assert len(env.truncated_trip_data) == tot['teleported']
+    assert sorted(env.truncated_trip_data, key=kc) == sorted(orc.truncated_trip_data, key=kc)
+    assert min(float(r['wait_sec']) for r in env.truncated_trip_data) >= scn.teleport_sec
+    assert np.mean([float(r['duration_sec']) for r in env.truncated_trip_data]) > np.mean([float(r['duration_sec']) for r in env.trip_data])
     assert sum(r['number_arrived_car'] for r in env.traffic_data) == tot['arrived']
     assert [r['number_arrived_car'] for r in env.traffic_data] == [r['number_arrived_car'] for r in orc.traffic_data]
     env.close()

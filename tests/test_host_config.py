@@ -117,15 +117,17 @@ def test_replica_sampling_streams_are_distinct():
 
 
 def test_checkpoint_seed_slot_keeps_its_meaning_per_format():
-    """`counters` of a checkpoint hold the BASE seed since format 2 (every rank / replica re-derives its action
-    stream); files written before (no `format` entry) hold the stream seed the saving rank had derived and are used as is."""
+    """`counters` of a checkpoint hold the BASE seed (format 2; round 3 wrote the same without the marker,
+    rounds 1-2 wrote rank 0's stream seed, which equals the base seed): every rank / replica re-derives its action stream,
+    whatever the file's format entry says -- a marker-less file must not put all ranks on rank 0's stream."""
     from deeprl_signal_control_amd.agents import CKPT_FORMAT, replica_sample_seed, resume_sample_seed
     assert CKPT_FORMAT >= 2
     base, s0 = resume_sample_seed(7, CKPT_FORMAT, rank=0, replica=0)
     assert (base, s0) == (7, 7)                                  # rank 0 / replica 0 keeps the base stream
     base, s3 = resume_sample_seed(7, CKPT_FORMAT, rank=3, replica=1)
     assert base == 7 and s3 == replica_sample_seed(7, 3, 1) != 7
-    assert resume_sample_seed(123456789, None, rank=3, replica=1) == (None, 123456789)
+    assert resume_sample_seed(123456789, None, rank=3, replica=1) == (123456789, replica_sample_seed(123456789, 3, 1))
+    assert resume_sample_seed(123456789, None, rank=0, replica=0) == (123456789, 123456789)
 
 
 def test_initial_traffic_draw_handles_streams_with_different_candidate_counts():

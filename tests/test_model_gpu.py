@@ -204,6 +204,40 @@ def test_sampling_is_numpy_choice_on_documented_uniform():
     m.close()
 
 
+def test_fc_policy_forward_kernels_agree_with_each_other(monkeypatch):
+    """the two FcACPolicy forward kernels sum the 64 hidden units of a head in different orders (the MFMA
+    kernel: 16 lanes x 4 units, xor-shuffle tree; the per-thread kernel: sequentially), so their logits -- and with them pi
+    -- agree to float32 rounding, not bit for bit.  Pinned here: |d pi| <= 4e-7 (a few ulp of a probability), v likewise, and
+    the sampled action of the same (seed, step, index) uniform is the same wherever that uniform is not within 1e-6 of a
+    boundary of the cumulative distribution (and nowhere else may it differ)."""
+    from oracle.nets_oracle import sample_uniform
+    E = 256
+    out = {}
+    for mfma in ('1', '0'):
+        monkeypatch.setenv('TSC_FC_MFMA', mfma)
+        scn, m, _ = _make('ia2c', E, 4, policy='fc', seed=3)
+        rng = np.random.RandomState(5)
+        m.reset()
+        rows = []
+        for t in range(3):
+            obs = _rand_obs(scn, E, rng)
+            step = m.sample_step
+            pi, v, act = m.forward_sample(torch.from_numpy(obs).cuda(), False, cache=False)
+            rows.append((pi.cpu().numpy().copy(), v.cpu().numpy().copy(), act.cpu().numpy().copy(), step, m.sample_seed))
+        out[mfma] = rows
+        m.close()
+    differ = 0
+    for (pa, va, aa, step, seed), (pb, vb, ab, _, _) in zip(out['1'], out['0']):
+        assert np.abs(pa - pb).max() <= 4e-7 and np.abs(va - vb).max() <= 2e-6 * max(1.0, np.abs(va).max())
+        for e, a in zip(*np.nonzero(aa != ab)):
+            u = sample_uniform(seed, step, e * aa.shape[1] + a)
+            cdf = np.cumsum(pa[e, a].astype(np.float64))
+            assert np.abs(cdf - u).min() < 1e-6, (e, a, u, cdf)
+            differ += 1
+    assert differ <= 2                      # 3 x 256 x 25 draws: a boundary within 1e-6 of the uniform is a ~1e-5 event per draw
+    print('FC kernels: %d of %d sampled actions differ (all on a cdf boundary)' % (differ, 3 * E * 25))
+
+
 def _fill(scn, m, o, E, T, rng, p_done=0.1, terminal=False, use_cache=False):
     obs = _rand_obs(scn, E, rng)
     done = np.ones(E, np.uint8)

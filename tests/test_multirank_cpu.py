@@ -166,7 +166,9 @@ def test_eight_rank_shards_streams_allreduce_and_resume(tmp_path):
     streams = [int(r[2]) for r in rows]
     assert streams[0] == 0 and len(set(streams)) == world
     assert [int(r[3]) for r in rows] == [replica_sample_seed(0, k, 0) for k in range(world)] and all(int(r[4]) == 0 for r in rows)
-    assert all(int(r[5]) == 424242 for r in rows)              # a round-1/2 file: the stored stream seed, not derived again
+    # a marker-less file (rounds 1 - 3): its slot holds the base seed too (rank 0 saved it), so every rank re-derives its own
+    # stream from it -- eight distinct streams again, rank 0 on the stored value
+    assert [int(r[5]) for r in rows] == [replica_sample_seed(424242, k, 0) for k in range(world)] and int(rows[0][5]) == 424242
     assert all(int(r[6]) == 10 + world - 1 for r in rows)      # MAX over ranks
     # the all-reduced buffer: sum_k (k + 1) = 36 everywhere, + 0.5 exactly once per element; identical on every rank
     g = [np.load(tmp_path / ('g8_%d.npy' % r)) for r in range(world)]
