@@ -46,6 +46,8 @@ def lib():
         L.ms_set_box.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_double]
         L.ms_box_count.argtypes = [C.c_void_p]
         L.ms_box_count.restype = C.c_int64
+        L.ms_set_lanechange.argtypes = [C.c_void_p, ip, ip, ip, C.c_double, C.c_double]
+        L.ms_lanechange_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         _LIB = L
     return _LIB
 
@@ -101,6 +103,49 @@ class MicroSim:
         foes = np.ascontiguousarray(self.scn.link_foes, np.uint32)
         assert foes.shape == (self.scn.n_agent, self.kmax)
         self.L.ms_set_box(self.h, foes.ctypes.data_as(C.POINTER(C.c_uint32)), float(p))
+
+    def set_lanechange(self, gap_front=None, gap_back=2.0):
+        """EXPERIMENT (DESIGN.md 3 "lane changing", not the spec; large_grid only): hand-offs enter the lane the junction's
+        connection leads to (large_grid/data/build_file.py:107-124: through and right turns lane 0 -> lane 0, a left turn
+        from an avenue -> street lane 1) and a vehicle on the wrong lane of a two-lane street must change to its sibling lane
+        inside the edge, gaps permitting (gap_front / gap_back metres + 1 s of the closing speed); None switches it off."""
+        ip = C.POINTER(C.c_int32)
+        if gap_front is None:
+            self.L.ms_set_lanechange(self.h, None, None, None, 0.0, 0.0)
+            return
+        scn = self.scn
+        names, NL, NR = scn.lane_names, scn.n_lane, scn.n_route
+        idx = {n: i for i, n in enumerate(names)}
+        sib = np.full(NL, -1, np.int32)
+        for i, n in enumerate(names):
+            base, k = n.rsplit('_', 1)
+            sib[i] = idx.get(base + '_' + ('1' if k == '0' else '0'), -1)
+        mv_next, mv_link = np.asarray(scn.mv_next).reshape(NL, NR), np.asarray(scn.mv_link).reshape(NL, NR)
+        entry = mv_next.astype(np.int32).copy()
+        feeders = [set(int(u) for u in np.asarray(scn.lane_up).reshape(NL, -1)[l] if u >= 0) for l in range(NL)]
+        for l in range(NL):
+            for r in range(NR):
+                tl = int(mv_next[l, r])
+                if tl < 0 or sib[tl] < 0:
+                    continue
+                left = scn.lane_node[l] >= 0 and mv_link[l, r] >= 0 and mv_link[l, r] % 3 == 2      # links: right, through, left per approach
+                want = '1' if left else '0'
+                el = tl if names[tl].endswith('_' + want) else int(sib[tl])
+                entry[l, r] = el
+                feeders[el].add(l)
+        up = np.full((NL, 4), -1, np.int32)
+        for l in range(NL):
+            f = sorted(feeders[l])
+            assert len(f) <= 4, (names[l], [names[x] for x in f])
+            up[l, :len(f)] = f
+        self._lc_keep = [sib, np.ascontiguousarray(entry, np.int32), up]
+        self.L.ms_set_lanechange(self.h, sib.ctypes.data_as(ip), self._lc_keep[1].ctypes.data_as(ip), up.ctypes.data_as(ip),
+                                 float(gap_front), float(gap_back))
+
+    def lanechange_counts(self):
+        out = (C.c_int64 * 2)()
+        self.L.ms_lanechange_counts(self.h, out)
+        return dict(changes=out[0], blocked_seconds=out[1])
 
     def set_links(self, agent, chars):
         if isinstance(chars, str):

@@ -34,6 +34,7 @@ for C in $CFGS; do
   fi
   rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace${SUF} -o t -- $B --steps 3 --warmup 1 --no-profile > $RES/${TAG}_bench_rocprof${SUF}.json 2> $OUT/${TAG}_trace${SUF}.err
   python $ROOT/tools/rocpd_stats.py $(find $OUT/${TAG}_trace${SUF} -name "*.db" | head -1) $RES/${TAG}_kernel_stats${SUF}.csv
+  rm -rf $OUT/${TAG}_trace${SUF}                 # the rocpd databases are tens of MB each; gpurun copies back at most 64 MiB
   [ $C = q1 ] && continue
   rocprofv3 --pmc FETCH_SIZE -d $OUT/${TAG}_pmc_fetch${SUF} -o f -- $B --steps $EP --warmup $EP --no-profile > $OUT/${TAG}_pmc_fetch${SUF}.json 2> $OUT/${TAG}_pmc_fetch${SUF}.err
   rocprofv3 --pmc WRITE_SIZE -d $OUT/${TAG}_pmc_write${SUF} -o w -- $B --steps $EP --warmup $EP --no-profile > $OUT/${TAG}_pmc_write${SUF}.json 2> $OUT/${TAG}_pmc_write${SUF}.err
@@ -41,5 +42,6 @@ for C in $CFGS; do
          $RES/${TAG}_pmc${SUF}.json $OUT/${TAG}_pmc_fetch${SUF}.json "$B --steps $EP --warmup $EP --no-profile"
   rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/${TAG}_pmc_sq${SUF} -o s -- $B --steps 1 --warmup $EP --no-profile > /dev/null 2> $OUT/${TAG}_pmc_sq${SUF}.err
   python $ROOT/tools/rocpd_pmc.py sq $(find $OUT/${TAG}_pmc_sq${SUF} -name "*.db" | head -1) $RES/${TAG}_pmc_sq${SUF}.csv
+  rm -rf $OUT/${TAG}_pmc_fetch${SUF} $OUT/${TAG}_pmc_write${SUF} $OUT/${TAG}_pmc_sq${SUF}
 done
 ls -la $RES
