@@ -34,6 +34,7 @@ class TscScenario(C.Structure):
         ('n_stream', C.c_int32), ('k_choice', C.c_int32),
         ('stream_entry', _ip), ('stream_origin', _fp), ('stream_limit', _fp), ('stream_mode', _ip), ('stream_choice', _ip),
         ('n_interval', C.c_int32), ('choice_interval_sec', C.c_int32),
+        ('lane_sib', _ip),
     ]
 
 
@@ -138,6 +139,8 @@ def scenario_struct(scn):
         coop_gamma=scn.coop_gamma, norm_wave=scn.norm_wave, norm_wait=scn.norm_wait,
         clip_wave=scn.clip_wave, clip_wait=scn.clip_wait, coef_wait=scn.coef_wait,
         lane_origin=arr(scn.lane_origin, np.float32, _fp))
+    if getattr(scn, 'lane_sib', None) is not None:
+        s.lane_sib = arr(scn.lane_sib, np.int32, _ip)
     scn.streams_ready()
     scn.check_limits()
     if scn.stream_entry_lane is not None:

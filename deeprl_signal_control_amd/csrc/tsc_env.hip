@@ -54,6 +54,7 @@ struct EnvDev {
     int help;                      // phase A1 enabled (step_kernel)
     const float *lane_len, *lane_vmax, *lane_det;
     const int *lane_node, *lane_up;
+    const int *lane_sib;           // [NL] sibling lane of a two-lane street or -1; null = no lane changing (rule 10)
     const int *mv;                 // [NL*NR] packed movement word, see mv_* helpers
     const uint8_t *zip;            // [NL*NR] zipper-merge slot: rank | count << 4 (0 = none)
     const int *route_entry;        // [NS] entry lane of every stream
@@ -191,7 +192,7 @@ __device__ __forceinline__ bool sig_open(int tl, int k, int a, int w, float x, f
 // scenario at create time): 1 = large_grid (5x5), 2 = real_net (Monaco, lane chains contracted)
 struct SpecDims { int NLP, NLA, NU, NR, A, KMAX, PMAX, LMAX, NBR, ctrl, yellow, teleport; };
 constexpr SpecDims kSpec[3] = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
-                               {192, 128, 81, 12, 25, 12, 5, 6, 4, 5, 2, 600},
+                               {192, 128, 88, 12, 25, 12, 5, 6, 4, 5, 2, 600},     // NU: 81 lanes carry vehicles (83 with lane changing); the rest stay empty
                                {192, 128, 113, 16, 28, 22, 6, 11, 5, 5, 2, 300}};
 
 struct Smem {
@@ -203,6 +204,7 @@ struct Smem {
     double *r;                                  // local rewards [A] (+1 for global)
     uint8_t *link_y, *link_g;                   // [A*KMAX]
     float *len, *vmax; int *node;               // lane length / speed limit / downstream agent [NLA]
+    int *sib;                                   // sibling lane (rule 10) or -1 [NLA]
     int *pend, *ser; uint8_t *emit;             // per-stream insertion state [NS], emissions [NS*8]
     uint8_t *zip;                               // [NU*NR]
     uint32_t *up4;                              // [NLA] the lane's feeders, a byte each (0xFF = none): merge arbitration
@@ -230,6 +232,7 @@ __host__ __device__ __forceinline__ void smem_layout(Smem &s, const EnvDev &P, T
     s.wave = (int *)take(4 * P.NLP); s.halt = (int *)take(4 * P.NLP); s.hwait = (int *)take(4 * P.NLP);
     s.link_y = (uint8_t *)take(P.A * P.KMAX); s.link_g = (uint8_t *)take(P.A * P.KMAX);
     s.len = (float *)take(4 * P.NLA); s.vmax = (float *)take(4 * P.NLA); s.node = (int *)take(4 * P.NLA);
+    s.sib = (int *)take(4 * P.NLA);
     s.pend = (int *)take(4 * P.NS); s.ser = (int *)take(4 * P.NS); s.emit = (uint8_t *)take(8 * P.NS);
     s.zip = (uint8_t *)take((P.NU * P.NR + 3) / 4 * 4);
     s.up4 = (uint32_t *)take(4 * P.NLA);
@@ -467,6 +470,8 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     for (int q = l; q < NLA; q += blockDim.x) {
         const bool in = q < P.NU;
         s.len[q] = in ? P.lane_len[q] : 1.0f; s.node[q] = in ? P.lane_node[q] : -1; s.vmax[q] = in ? P.lane_vmax[q] : 1.0f;
+        int sbq = (in && P.lane_sib) ? P.lane_sib[q] : -1;
+        s.sib[q] = sbq < P.NU ? sbq : -1;               // (a sibling no route ever reaches has no rows here and is never needed)
     }
     for (int q = l; q < NLP; q += blockDim.x) { s.wave[q] = 0; s.halt[q] = 0; s.hwait[q] = 0; }
     if constexpr (HELP) {                           // flat-phase marks: all clear (a second sets and clears its own)
@@ -582,7 +587,8 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 const float v0 = vmax * sf;
                 const bool sink = tl == -1;
                 const bool open = sig_open(tl, k, HELP ? s.node[l] : my_node, w, x, v, L, link, P.KMAX, P.teleport);
-                bool can_cross = false;
+                bool can_cross = false, lc = false;
+                int sb = -1;                                   // rule 10: the sibling lane this vehicle has to move over to
                 if (all_crossed) {
                     can_cross = open;
                     if (can_cross && y >= 0 && w < P.teleport && s.n[y] > 0) {
@@ -624,12 +630,28 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     if (can_cross && tl >= 0 && s.n[tl] > 0 && s.tx[tl] < kLen) can_cross = false;   // no room behind the tail
                     if (can_cross && ncross >= kMaxCross) can_cross = false;
                     if (tl < -1) can_cross = false;
+                    // rule 10: a head-platoon vehicle on the wrong lane of a two-lane street moves over to the sibling lane as a
+                    // hand-off that keeps its position: behind the sibling's OLD tail by the standstill gap + 1 s of the closing
+                    // speed, room for two full platoons there (the sibling may receive from its junction in the same second)
+                    if (tl < -1) {
+                        const int sq = s.sib[l];
+                        if (sq >= 0 && mv_tl(s.mv[sq * NR + r]) >= -1) {
+                            sb = sq;
+                            const int nsb = s.n[sb];
+                            lc = (nsb + 2 * kMaxCross <= kCap) && (ncross < kMaxCross);
+                            if (lc && nsb > 0) {
+                                float dv = v - s.tv[sb];
+                                if (dv < 0.0f) dv = 0.0f;
+                                lc = ((s.tx[sb] - kLen) - x) >= (kS0 + dv);
+                            }
+                        }
+                    }
                 }
                 // teleport (SUMO --time-to-teleport): the head, standing for >= teleport seconds, whose way is still blocked
                 // (merge slot, capacity, no room behind the target's tail) leaves the network where it stands.  SUMO would
                 // move it along its route and its trip would end later: the surrogate TRUNCATES the trip, so it is counted
                 // as a teleport, not as an arrival, and its trip row carries a negative arrival second
-                if (i == 0 && !can_cross && tl >= 0 && w >= P.teleport) {
+                if (i == 0 && !can_cross && !lc && (tl >= 0 || sb >= 0) && w >= P.teleport) {
                     ++tele;
                     if constexpr (REC) {
                         const int k = atomicAdd(&P.n_trips[e], 1);
@@ -641,6 +663,39 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     }
                     ++ncross;
                     pox = x; pov = v;
+                    cur = nxt;
+                    continue;
+                }
+                if (lc) {
+                    // the lane-change second: leader = the vehicle ahead on the own lane (old state) or, for the lane's head, the
+                    // sibling's old tail; the stop line counts as closed (no lane change and junction crossing in one second)
+                    const bool has_t = s.n[sb] > 0;
+                    const float ttx = s.tx[sb], ttv = s.tv[sb];
+                    float vn;
+                    if (i > 0) vn = follow(v, v0, true, (pox - kLen) - x, pov, kS0);
+                    else if (has_t) vn = follow(v, v0, true, (ttx - kLen) - x, ttv, kS0);
+                    else vn = follow(v, v0, false, 0.0f, 0.0f, 0.0f);
+                    {
+                        const float v2 = follow(v, v0, true, L - x, 0.0f, 0.0f);
+                        if (v2 < vn) vn = v2;
+                    }
+                    float xn = x + vn;
+                    bool clamped = false;
+                    if (xn > pnx - kLen) { xn = pnx - kLen; clamped = true; }
+                    if (has_t && xn > ttx - kLen) { xn = ttx - kLen; clamped = true; }
+                    if (xn > L) { xn = L; clamped = true; }
+                    if (xn < x) { xn = x; clamped = true; }
+                    if (clamped) vn = xn - x;
+                    uint32_t r1c = cur.r1;
+                    if constexpr (REC) {
+                        if (vn < kHalt) r1c = (r1c + 1u) + (w == 0 ? 0x10000u : 0u);
+                    }
+                    w = (vn < kHalt) ? w + 1 : 0;
+                    pnx = xn; pox = x; pov = v;
+                    const int o = nsent * NLA + l;
+                    s.ox[o] = xn; s.ov[o] = vn; s.osf[o] = sf; s.om[o] = (uint32_t)w | ((uint32_t)r << 16); s.oto[o] = sb;
+                    if constexpr (REC) { s.or0[o] = cur.r0; s.or1[o] = r1c; }
+                    ++nsent; ++ncross;
                     cur = nxt;
                     continue;
                 }
@@ -656,6 +711,15 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 if (line_block) {
                     const float v2 = follow(v, v0, true, L - x, 0.0f, 0.0f);
                     if (v2 < vn) vn = v2;
+                }
+                // rule 10: the head of a lane that has to move over lines up BEHIND the sibling's queue instead of driving past
+                // it: the sibling's old tail is a third leader while it is still ahead
+                if (sb >= 0 && i == 0 && s.n[sb] > 0) {
+                    const float g3 = (s.tx[sb] - kLen) - x;
+                    if (g3 >= 0.0f) {
+                        const float v3 = follow(v, v0, true, g3, s.tv[sb], kS0);
+                        if (v3 < vn) vn = v3;
+                    }
                 }
                 float xn = x + vn;
                 if (!HELP && !all_crossed) {
@@ -1270,10 +1334,13 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
                 if (r < 0) continue;
                 if (r >= NR) return tsc::fail("tsc_env_create: stream %d names route %d of %d", s_, r, NR);
                 int l = stream_entry(s_);
-                for (int hops = 0; l >= 0 && l < NL && hops <= NL; ++hops) {
+                for (int hops = 0; l >= 0 && l < NL && hops <= 2 * NL; ++hops) {
                     reach[l] = 1;
                     if (l + 1 > nu) nu = l + 1;
-                    l = sc->mv_next[(size_t)l * NR + r];
+                    int nx = sc->mv_next[(size_t)l * NR + r];
+                    if (nx < -1 && sc->lane_sib && sc->lane_sib[l] >= 0 && sc->lane_sib[l] < NL &&
+                        sc->mv_next[(size_t)sc->lane_sib[l] * NR + r] >= -1) nx = sc->lane_sib[l];     // rule 10: the vehicle moves over
+                    l = nx;
                 }
             }
         P.NU = nu < 1 ? 1 : nu;
@@ -1282,6 +1349,7 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     UP(lane_len, float, sc->lane_len, NL); UP(lane_vmax, float, sc->lane_vmax, NL);
     UP(lane_det, float, sc->lane_det_start, NL);
     UP(lane_node, int, sc->lane_node, NL);
+    if (sc->lane_sib) UP(lane_sib, int, sc->lane_sib, NL);
     {
         std::vector<int> up(sc->lane_up, sc->lane_up + (size_t)NL * kMaxUp);
         for (int &u : up) if (u >= 0 && (u >= NL || !reach[u])) u = -1;        // a feeder that is never occupied never sends
@@ -1446,9 +1514,10 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     h->spec = 0;
     for (int k = 1; k < 3; ++k) {
         const SpecDims &D = kSpec[k];
-        if (P.NS == P.NR && P.NLP == D.NLP && P.NLA == D.NLA && P.NU == D.NU && P.NR == D.NR && P.A == D.A && P.KMAX == D.KMAX && P.PMAX == D.PMAX &&
+        // (NU: the scenario's live lanes are a prefix of the instantiation's; the lanes in between stay empty)
+        if (P.NS == P.NR && P.NLP == D.NLP && P.NLA == D.NLA && P.NU <= D.NU && D.NU <= P.NL && P.NR == D.NR && P.A == D.A && P.KMAX == D.KMAX && P.PMAX == D.PMAX &&
             P.LMAX == D.LMAX && P.NBR == D.NBR && P.ctrl == D.ctrl && P.yellow == D.yellow && P.teleport == D.teleport &&
-            (k != 1 || (!any_zip && !P.sorigin)) && !P.sroute) h->spec = k;
+            (k != 1 || (!any_zip && !P.sorigin)) && !P.sroute) { h->spec = k; P.NU = D.NU; h->smem = smem_bytes(P); }
     }
     if (const char *ev = getenv("TSC_ENV_SPEC")) if (!atoi(ev)) h->spec = 0;
     // vehicles per thread and super-round of the flat phase (TSC_ENV_KF = 1 / 2 / 4 for A/B runs).  With runtime dimensions

@@ -35,6 +35,7 @@ VEH_DECEL = 10.0     # vType decel=10
 MIN_GAP = 2.5        # SUMO default minGap (not in the reference tree): sizes lane pieces and contracted chains
 STAND_GAP = 2.0      # standstill gap of the microsim spec (csrc/tsc_env.hip kS0)
 LANE_CAP = 28        # vehicle slots per lane: 200 m / 7.5 m = 26.7 -> 27 (+1); hand-offs stop at LANE_CAP - MAX_CROSS
+LANE_CHANGE_DEFAULT = False   # large_grid: lane choice by the junction's connections + lane changes on the two-lane streets (rule 10)
 MAX_CROSS = 4        # vehicles that may leave one lane in one sim-step
 MAX_UP = 4           # upstream feeder lanes per lane
 DET_LEN = 50.0       # lane-area detector covers the last 50 m
@@ -101,6 +102,8 @@ class Scenario:
     extra: Dict = field(default_factory=dict)
     link_foes: np.ndarray = None     # u32 [A, KMAX] bit k2 of row (a, k): the path of signal link k2 crosses or joins the path of link k
                                      # inside the junction (junction interiors, DESIGN.md 3 rule 10); None = no junction has foes
+    lane_sib: np.ndarray = None      # i32 [NL] the other lane of a two-lane street, -1 = none (None: the scenario has no lane changing,
+                                     # DESIGN.md 3 rule 10): a vehicle on a lane that does not serve its movement moves over to it
     lane_origin: np.ndarray = None   # f32 [NL] where the SUMO lane of that name begins inside the compiled lane (0 unless
                                      # contract_chains merged upstream pieces into it): `lane.*` TraCI getters count from here
 
@@ -395,7 +398,11 @@ def four_leg_foes():
 
 
 def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: int = 925,
-                     sort_lanes: bool = True, init_density: float = 0.0, **env_kw) -> Scenario:
+                     sort_lanes: bool = True, init_density: float = 0.0, lane_change: bool = LANE_CHANGE_DEFAULT, **env_kw) -> Scenario:
+    # lane_change (DESIGN.md 3 rule 10): a hand-off enters the lane the junction's CONNECTION leads to (build_file.py:107-124:
+    # through and right turns lane 0 -> lane 0, a left turn from an avenue -> street lane 1); a vehicle that then stands on the
+    # street lane its next movement does not use has to move over to the sibling lane inside the edge.  False: the vehicle is put
+    # on the lane its next movement needs right at edge entry (rounds 1 - 4)
     # init_density > 0: large_grid/data/build_file.py:223-266 seeds every internal edge (and both lanes of a street) with
     # int(30 * density) vehicles bound for a sink edge drawn per episode from np.random -- see the stream tables below
     L0, L0_END, N = 200.0, 75.0, 5
@@ -548,6 +555,8 @@ def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: in
         reference's connection table (build_file.py:107-124)."""
         if edges[edge][2] == 1:
             return 0
+        if lane_change and via_mv is not None:          # the connection's lane, whatever the route needs at the far end
+            return 1 if (via_mv == _LEFT and not from_street) else 0
         m = next_mv.get((edge, r))
         if m is None:                                   # arrival edge
             return 1 if (via_mv == _LEFT and not from_street) else 0
@@ -569,8 +578,8 @@ def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: in
             if m is None or not to.startswith('nt'):
                 continue
             if nl == 2 and ((m == _LEFT) != (lane_k[l] == 1)):
-                if init_density <= 0:
-                    continue                            # lane does not serve that movement
+                if init_density <= 0 or lane_change:
+                    continue                            # lane does not serve that movement (lane_change: the vehicle moves over)
                 # initial traffic stands on both lanes of a street whatever its sink (departLane, build_file.py:225);
                 # SUMO would change lanes, here the vehicle takes a movement its lane serves -- the left turn from lane 1,
                 # through (else right) from lane 0 -- and follows the sink's tree from the next edge on
@@ -583,9 +592,15 @@ def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: in
     route_entry = np.array([lane_id['%s_%d' % (src, lane_choice(src, r, None, False))] if src is not None else -1
                             for r, (src, _) in enumerate(route_names)], np.int32)
 
+    lane_sib = None
+    if lane_change:
+        lane_sib = np.array([lane_id.get('%s_%d' % (lane_edge[l], 1 - lane_k[l]), -1) if edges[lane_edge[l]][2] == 2 else -1
+                             for l in range(NL)], np.int32)
     lane_up = np.full((NL, MAX_UP), -1, np.int32)
     for l2 in range(NL):
         ups = sorted({l for l in range(NL) if (mv_next[l] == l2).any()})
+        if lane_sib is not None and lane_sib[l2] >= 0:
+            ups = [int(lane_sib[l2])] + ups             # lane changers keep their position: gathered before the junction's arrivals
         assert len(ups) <= MAX_UP
         lane_up[l2, :len(ups)] = ups
 
@@ -654,7 +669,7 @@ def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: in
     scn = Scenario(
         name='large_grid', agent=agent, node_names=node_names, n_agent=N * N,
         lane_names=lane_names, lane_len=lane_len, lane_vmax=lane_vmax, lane_node=lane_node,
-        lane_det_start=lane_det, lane_up=lane_up,
+        lane_det_start=lane_det, lane_up=lane_up, lane_sib=lane_sib,
         n_route=NR, mv_next=mv_next, mv_link=mv_link, mv_yield=mv_yield, mv_prio=mv_prio,
         mv_zip=np.zeros((NL, NR), np.int32), route_entry_lane=route_entry,
         route_names=route_names,
@@ -664,7 +679,7 @@ def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: in
         green_tab=green, yellow_tab=yellow,
         neighbors=neighbors, n_s_ls=n_s, n_w_ls=n_w, n_f_ls=n_f, n_a_ls=n_a_ls,
         obs_kind=obs_kind, obs_src=obs_src, flows=flows, obs_len=lens,
-        extra={'peak_flow1': peak_flow1, 'peak_flow2': peak_flow2, 'demand': demand},
+        extra={'peak_flow1': peak_flow1, 'peak_flow2': peak_flow2, 'demand': demand, 'lane_change': bool(lane_change)},
         **stream_kw, **env_kw)
     if init_density > 0:
         scn.extra.update(init_density=init_density, init_lanes=init_lanes, init_sinks=init_sinks, sink_routes=sink_routes,
@@ -1125,9 +1140,15 @@ def build_small_grid(agent: str = 'greedy', num_extra_car_per_hour: int = 1000, 
                 n = e.split('_')[1]
                 if n in aidx:
                     mv_link[last, r] = link_edges[n].index((e, path[p + 1]))
+    lane_sib = None
+    if lane_change:
+        lane_sib = np.array([lane_id.get('%s_%d' % (lane_edge[l], 1 - lane_k[l]), -1) if edges[lane_edge[l]][2] == 2 else -1
+                             for l in range(NL)], np.int32)
     lane_up = np.full((NL, MAX_UP), -1, np.int32)
     for l2 in range(NL):
         ups = sorted({l for l in range(NL) if (mv_next[l] == l2).any()})
+        if lane_sib is not None and lane_sib[l2] >= 0:
+            ups = [int(lane_sib[l2])] + ups             # lane changers keep their position: gathered before the junction's arrivals
         assert len(ups) <= MAX_UP
         lane_up[l2, :len(ups)] = ups
     A = len(node_names)
@@ -1230,9 +1251,12 @@ def lane_load(scn: Scenario) -> np.ndarray:
                     prev = int(c)
         for l, r, w in ways:
             hops = 0
-            while l >= 0 and hops <= scn.n_lane:
+            while l >= 0 and hops <= 2 * scn.n_lane:
                 load[l] += veh * w
-                l = int(scn.mv_next[l, r])
+                nx = int(scn.mv_next[l, r])
+                if nx < -1 and scn.lane_sib is not None and scn.lane_sib[l] >= 0 and scn.mv_next[scn.lane_sib[l], r] >= -1:
+                    nx = int(scn.lane_sib[l])           # rule 10: the vehicle moves over to the lane that serves its movement
+                l = nx
                 hops += 1
     return load
 
@@ -1254,9 +1278,13 @@ def permute_lanes(scn: Scenario, order) -> Scenario:
     scn.lane_names = [scn.lane_names[i] for i in order]
     for k in ('lane_len', 'lane_vmax', 'lane_node', 'lane_det_start', 'lane_origin'):
         setattr(scn, k, getattr(scn, k)[order])
+    if scn.lane_sib is not None:
+        scn.lane_sib = remap(scn.lane_sib[order])
     up = remap(scn.lane_up[order])
-    for i in range(len(up)):                                    # keep "ascending feeder index" order
+    for i in range(len(up)):                                    # keep "ascending feeder index" order (rule 10: the sibling first)
         row = np.sort(up[i][up[i] >= 0])
+        if scn.lane_sib is not None and scn.lane_sib[i] >= 0 and scn.lane_sib[i] in row:
+            row = np.concatenate([[scn.lane_sib[i]], row[row != scn.lane_sib[i]]])
         up[i] = -1
         up[i, :len(row)] = row
     scn.lane_up = up

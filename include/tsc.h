@@ -87,6 +87,12 @@ typedef struct tsc_scenario {
     const int32_t *stream_choice;  /* [n_stream, n_interval, k_choice, 2]; the choices in force at second t: interval
                                     * min(t / choice_interval_sec, n_interval - 1) (time-variant turn ratios) */
     int32_t n_interval, choice_interval_sec;
+    /* Lane changing on two-lane streets (round 5; DESIGN.md 3 rule 10; SUMO's lane-change model behind simulationStep,
+     * envs/env.py:464, with the reference's connection table large_grid/data/build_file.py:107-124): lane_sib[l] = the other lane
+     * of lane l's edge or -1; NULL = none.  mv_next then names the lane a junction's CONNECTION enters; a vehicle standing on a
+     * lane whose mv_next entry for its route is "not served" (< -1) while lane_sib[l] serves it moves over as a hand-off that keeps
+     * its position (lane_up must list the sibling FIRST: lane changers are gathered before the junction's arrivals). */
+    const int32_t *lane_sib;       /* [n_lane] or NULL */
 } tsc_scenario;
 
 typedef struct tsc_env tsc_env;

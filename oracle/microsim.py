@@ -48,6 +48,8 @@ def lib():
         L.ms_box_count.restype = C.c_int64
         L.ms_set_lanechange.argtypes = [C.c_void_p, ip, ip, ip, C.c_double, C.c_double]
         L.ms_lanechange_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        L.ms_set_sibling.argtypes = [C.c_void_p, ip]
+        L.ms_set_tables.argtypes = [C.c_void_p, ip, ip]
         _LIB = L
     return _LIB
 
@@ -77,6 +79,10 @@ class MicroSim:
         self.h = L.ms_create(scn.n_lane, scn.n_route, scn.n_agent, self.kmax, self.cap,
                              len(scn.flows), scn.teleport_sec, *ptrs)
         self.L = L
+        if getattr(scn, 'lane_sib', None) is not None:          # rule 10 (the compiled tables already name the connection lanes)
+            sib = _i(scn.lane_sib)
+            self._keep.append(sib)
+            L.ms_set_sibling(self.h, sib.ctypes.data_as(ip))
         scn.streams_ready()
         if scn.stream_entry_lane is not None:
             st = [_i(scn.stream_entry_lane), _f(scn.stream_origin), _f(scn.stream_limit), _i(scn.stream_mode), _i(scn.stream_choice)]
@@ -141,6 +147,42 @@ class MicroSim:
         self._lc_keep = [sib, np.ascontiguousarray(entry, np.int32), up]
         self.L.ms_set_lanechange(self.h, sib.ctypes.data_as(ip), self._lc_keep[1].ctypes.data_as(ip), up.ctypes.data_as(ip),
                                  float(gap_front), float(gap_back))
+
+    def set_rule10_from_needed_lane_tables(self):
+        """Test hook (tools/sweep_lane_change.py): turn a scenario compiled WITHOUT rule 10 (hand-offs enter the lane the route
+        needs) into its rule-10 form -- hand-offs enter the junction connection's lane, siblings feed each other first."""
+        ip = C.POINTER(C.c_int32)
+        scn = self.scn
+        names, NL, NR = scn.lane_names, scn.n_lane, scn.n_route
+        idx = {n: i for i, n in enumerate(names)}
+        sib = np.full(NL, -1, np.int32)
+        for i, n in enumerate(names):
+            base, k = n.rsplit('_', 1)
+            sib[i] = idx.get(base + '_' + ('1' if k == '0' else '0'), -1)
+        mv_next, mv_link = np.asarray(scn.mv_next).reshape(NL, NR), np.asarray(scn.mv_link).reshape(NL, NR)
+        entry = mv_next.astype(np.int32).copy()
+        feeders = [[] for _ in range(NL)]
+        for l in range(NL):
+            for r in range(NR):
+                tl = int(mv_next[l, r])
+                if tl < 0:
+                    continue
+                el = tl
+                if sib[tl] >= 0:
+                    left = scn.lane_node[l] >= 0 and mv_link[l, r] >= 0 and mv_link[l, r] % 3 == 2
+                    want = '1' if left else '0'
+                    el = tl if names[tl].endswith('_' + want) else int(sib[tl])
+                entry[l, r] = el
+                if l not in feeders[el]:
+                    feeders[el].append(l)
+        up = np.full((NL, 4), -1, np.int32)
+        for l in range(NL):
+            f = ([int(sib[l])] if sib[l] >= 0 else []) + sorted(feeders[l])
+            assert len(f) <= 4, (names[l], [names[x] for x in f])
+            up[l, :len(f)] = f
+        self._r10_keep = [sib, np.ascontiguousarray(entry, np.int32), up]
+        self.L.ms_set_tables(self.h, self._r10_keep[1].ctypes.data_as(ip), up.ctypes.data_as(ip))
+        self.L.ms_set_sibling(self.h, sib.ctypes.data_as(ip))
 
     def lanechange_counts(self):
         out = (C.c_int64 * 2)()

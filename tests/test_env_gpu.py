@@ -241,3 +241,52 @@ def test_resident_instances_hint_changes_the_launch_shape_not_the_results():
         np.testing.assert_array_equal(s0[k], s1[k])
     for e_ in envs:
         e_.close()
+
+
+@pytest.mark.parametrize('threads,spec,help_', [('256', '1', '1'), ('512', '1', '1'), ('1024', '1', '1'), ('256', '0', '1'), ('256', '1', '0')])
+def test_lane_change_rule_vs_oracle(threads, spec, help_, monkeypatch):
+    """DESIGN.md 3 rule 10 (lane choice by the junction's connections + lane changes on the two-lane streets, lane_change=True):
+    the step kernel against the CPU oracle over a whole greedy-driven episode of four instances -- obs, rewards, done, and
+    the complete vehicle state at the demand peak and at the end -- with lane changers in the head platoons, wrong-lane heads
+    lining up behind the sibling's queue, teleported changers, for every workgroup size, with and without the compile-time
+    table dimensions and the flat phase."""
+    from deeprl_signal_control_amd.env import VecTrafficEnv
+    from oracle.env_oracle import OracleEnv, greedy_large_grid
+    monkeypatch.setenv('TSC_ENV_THREADS', threads)
+    monkeypatch.setenv('TSC_ENV_SPEC', spec)
+    monkeypatch.setenv('TSC_ENV_HELP', help_)
+    scn = build_large_grid('ma2c', lane_change=True)
+    assert scn.lane_sib is not None and (scn.lane_sib >= 0).sum() == 120
+    E = 4
+    env = VecTrafficEnv(scn, E, seed=300)
+    orc = [OracleEnv(scn, seed=300 + e) for e in range(E)]
+    obs = env.reset().cpu().numpy()
+    oobs = [o.reset() for o in orc]
+    rng = np.random.RandomState(11)
+    for t in range(720):
+        pol = rng.dirichlet(np.ones(5), size=(E, 25)).astype(np.float32)
+        act = np.zeros((E, 25), np.int32)
+        for e in range(E):
+            for a in range(25):
+                act[e, a] = rng.randint(5) if rng.rand() < 0.1 * e else greedy_large_grid(oobs[e][a][:6])
+        env.update_fingerprint(torch.from_numpy(pol).cuda())
+        o, r, d, g = env.step(torch.from_numpy(act).cuda())
+        o, r, d, g = o.cpu().numpy(), r.cpu().numpy(), d.cpu().numpy(), g.cpu().numpy()
+        for e in range(E):
+            orc[e].update_fingerprint(list(pol[e]))
+            oo, orr, od, og = orc[e].step(list(act[e]))
+            oobs[e] = oo
+            for a in range(25):
+                np.testing.assert_array_equal(o[e, a, :scn.n_s_ls[a]], oo[a].astype(np.float32), err_msg='t=%d e=%d a=%d' % (t, e, a))
+            np.testing.assert_array_equal(r[e], orr, err_msg='t=%d e=%d' % (t, e))
+            assert g[e] == og and bool(d[e]) == bool(od)
+        if t in (299, 719):
+            for e in range(E):
+                st, sn = env.get_state(e), orc[e].ms.snapshot()
+                for k in ('n', 'x', 'v', 'sf', 'w', 'r'):
+                    np.testing.assert_array_equal(st[k], sn[k], err_msg='state %s t=%d e=%d' % (k, t, e))
+    arrived, teleported = env.counters()
+    tot = [o.ms.totals() for o in orc]
+    assert [int(x) for x in arrived] == [x['arrived'] for x in tot] and [int(x) for x in teleported] == [x['teleported'] for x in tot]
+    assert sum(o.ms.lanechange_counts()['changes'] for o in orc) > 2000 and sum(x['teleported'] for x in tot) > 0
+    env.close()
