@@ -1140,15 +1140,9 @@ def build_small_grid(agent: str = 'greedy', num_extra_car_per_hour: int = 1000, 
                 n = e.split('_')[1]
                 if n in aidx:
                     mv_link[last, r] = link_edges[n].index((e, path[p + 1]))
-    lane_sib = None
-    if lane_change:
-        lane_sib = np.array([lane_id.get('%s_%d' % (lane_edge[l], 1 - lane_k[l]), -1) if edges[lane_edge[l]][2] == 2 else -1
-                             for l in range(NL)], np.int32)
     lane_up = np.full((NL, MAX_UP), -1, np.int32)
     for l2 in range(NL):
         ups = sorted({l for l in range(NL) if (mv_next[l] == l2).any()})
-        if lane_sib is not None and lane_sib[l2] >= 0:
-            ups = [int(lane_sib[l2])] + ups             # lane changers keep their position: gathered before the junction's arrivals
         assert len(ups) <= MAX_UP
         lane_up[l2, :len(ups)] = ups
     A = len(node_names)
