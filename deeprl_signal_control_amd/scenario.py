@@ -35,7 +35,7 @@ VEH_DECEL = 10.0     # vType decel=10
 MIN_GAP = 2.5        # SUMO default minGap (not in the reference tree): sizes lane pieces and contracted chains
 STAND_GAP = 2.0      # standstill gap of the microsim spec (csrc/tsc_env.hip kS0)
 LANE_CAP = 28        # vehicle slots per lane: 200 m / 7.5 m = 26.7 -> 27 (+1); hand-offs stop at LANE_CAP - MAX_CROSS
-LANE_CHANGE_DEFAULT = False   # large_grid: lane choice by the junction's connections + lane changes on the two-lane streets (rule 10)
+LANE_CHANGE_DEFAULT = True    # large_grid: lane choice by the junction's connections + lane changes on the two-lane streets (rule 10)
 MAX_CROSS = 4        # vehicles that may leave one lane in one sim-step
 MAX_UP = 4           # upstream feeder lanes per lane
 DET_LEN = 50.0       # lane-area detector covers the last 50 m

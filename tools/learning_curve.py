@@ -23,12 +23,12 @@ import numpy as np          # noqa: E402
 import torch                # noqa: E402
 
 
-def run(episodes, n_env, scenario='large_grid', agent='ma2c', seed=0, lr=None, log=None, policy='lstm'):
+def run(episodes, n_env, scenario='large_grid', agent='ma2c', seed=0, lr=None, log=None, policy='lstm', scn_kw=None):
     from deeprl_signal_control_amd.agents import VecA2C
     from deeprl_signal_control_amd.env import VecTrafficEnv
     from deeprl_signal_control_amd.scenario import build_scenario
     from deeprl_signal_control_amd.trainer import VecTrainer
-    scn = build_scenario(scenario, agent)
+    scn = build_scenario(scenario, agent, **(scn_kw or {}))
     if scenario == 'large_grid':
         mcfg, seed0 = dict(reward_norm=2000.0 if agent == 'ma2c' else 3000.0, batch_size=120), 12
     else:
@@ -65,6 +65,20 @@ def run(episodes, n_env, scenario='large_grid', agent='ma2c', seed=0, lr=None, l
     if log:
         for pt, rws in ev.items():
             log('evaluation (%s policy): %s' % (pt, ', '.join('seed %d: %.1f' % (r['test_id'], r['avg_reward']) for r in rws)))
+    # the scenario's greedy controller on the same test seeds (the reference's baseline, envs/*_env.py controllers on the device)
+    class _Greedy:
+        name, n_step = 'greedy', 1
+        def forward(self, ob, *a, **k): return env.greedy_actions(ob)
+        def reset(self): pass
+    was = env.train_mode
+    env.train_mode = False
+    gtr = VecTrainer(env, _Greedy())
+    gtr.agent = 'greedy'
+    gm, _ = gtr.perform(np.arange(n_env) % env.test_num, 'default')
+    env.train_mode = was
+    ev['greedy'] = [dict(test_id=int(k), avg_reward=float(np.mean(gm[np.arange(n_env) % env.test_num == k]))) for k in range(env.test_num)]
+    if log:
+        log('greedy controller: %s' % ', '.join('seed %d: %.1f' % (r['test_id'], r['avg_reward']) for r in ev['greedy']))
     env.close(); model.close()
     return rows, ev
 
@@ -77,11 +91,13 @@ def main():
     ap.add_argument('--agent', default='ma2c')
     ap.add_argument('--lr', type=float, default=None)
     ap.add_argument('--policy', default='lstm', choices=['lstm', 'fc'], help='fc = FcACPolicy (ia2c only; BASELINE configs[1])')
+    ap.add_argument('--lane-change', type=int, default=None, help='large_grid: 1 / 0 = with / without DESIGN.md 3 rule 10 (default: the scenario default)')
     ap.add_argument('--out', default=None)
     args = ap.parse_args()
-    rows, ev = run(args.episodes, args.envs, args.scenario, args.agent, lr=args.lr, log=print, policy=args.policy)
+    kw = {} if args.lane_change is None else {'lane_change': bool(args.lane_change)}
+    rows, ev = run(args.episodes, args.envs, args.scenario, args.agent, lr=args.lr, log=print, policy=args.policy, scn_kw=kw)
     first, last = np.mean([r['avg_reward'] for r in rows[:5]]), np.mean([r['avg_reward'] for r in rows[-5:]])
-    out = dict(scenario=args.scenario, agent=args.agent, policy=args.policy, envs=args.envs, episodes=args.episodes,
+    out = dict(scenario=args.scenario, agent=args.agent, policy=args.policy, envs=args.envs, episodes=args.episodes, scenario_options=kw,
                control_steps_per_episode=rows[0]['step'], first5_mean=first, last5_mean=last, rows=rows, evaluation=ev,
                note='mean over env instances of the per-episode mean global step reward (train_reward.csv avg_reward); '
                     'this repo\'s microsim spec underneath, not SUMO')

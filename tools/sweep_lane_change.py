@@ -38,16 +38,24 @@ def episode(scn, seed, gaps):
 
 
 if __name__ == '__main__':
-    scn = build_large_grid('greedy', norm_wave=1.0, norm_wait=1.0, clip_wave=-1.0, clip_wait=-1.0)
+    kw = dict(norm_wave=1.0, norm_wait=1.0, clip_wave=-1.0, clip_wait=-1.0)
+    scn = build_large_grid('greedy', lane_change=False, **kw)            # the rounds 1 - 4 tables: the experiment hooks sit on top of them
+    scn10 = build_large_grid('greedy', lane_change=True, **kw)           # rule 10 as adopted (compiled tables + lane_sib)
     out = {}
-    cases = [('spec (needed lane at edge entry, no lane change)', None), ('gaps 0 / 0 m (any free slot)', (0.0, 0.0)),
-             ('gaps 2 / 2 m', (2.0, 2.0)), ('gaps 2.5 / 5 m', (2.5, 5.0)), ('gaps 5 / 10 m', (5.0, 10.0)), ('gaps 10 / 20 m', (10.0, 20.0))]
+    cases = [('rounds 1-4 (needed lane at edge entry, no lane change)', None), ('gap acceptance anywhere, gaps 0 / 0 m (any free slot)', (0.0, 0.0)),
+             ('gap acceptance anywhere, gaps 2 / 2 m', (2.0, 2.0)), ('gap acceptance anywhere, gaps 2.5 / 5 m', (2.5, 5.0)),
+             ('gap acceptance anywhere, gaps 5 / 10 m', (5.0, 10.0)), ('gap acceptance anywhere, gaps 10 / 20 m', (10.0, 20.0)),
+             ('behind the sibling tail only, gap 0 m', (0.0, -1.0)), ('behind the sibling tail only, gap 2 m', (2.0, -1.0)),
+             ('behind the sibling tail only, gap 5 m', (5.0, -1.0)), ('RULE 10 (adopted)', 'rule10')]
     for name, gaps in cases:
-        rows = [episode(scn, sd, gaps) for sd in (10000, 20000)]
+        if gaps == 'rule10':
+            rows = [episode(scn10, sd, None) for sd in (10000, 20000, 30000, 40000)]
+        else:
+            rows = [episode(scn, sd, gaps) for sd in (10000, 20000)]
         out[name] = rows
         print('%-52s reward %s  arrived %s  teleported %s  trip %s  changes %s  blocked veh-s %s' % (
             name, ' / '.join('%.1f' % r['reward'] for r in rows), ' / '.join(str(r['arrived']) for r in rows),
             ' / '.join(str(r['teleported']) for r in rows), ' / '.join('%.0f' % r['mean_trip'] for r in rows),
             ' / '.join(str(r['lane_changes']) for r in rows), ' / '.join(str(r['blocked_vehicle_seconds']) for r in rows)), flush=True)
-    json.dump(dict(anchor=dict(large_grid=-972.28), seeds=[10000, 20000], results=out),
+    json.dump(dict(anchor=dict(large_grid=-972.28), seeds=[10000, 20000], seeds_rule10=[10000, 20000, 30000, 40000], results=out),
               open(os.path.join(ROOT, 'profiles', 'r05_lane_change_sweep.json'), 'w'), indent=1)
