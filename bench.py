@@ -389,7 +389,7 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
     from deeprl_signal_control_amd.scenario import build_scenario
     from deeprl_signal_control_amd.trainer import MultiBatchTrainer, VecTrainer
 
-    scn = build_scenario(scenario, agent)
+    scn = build_scenario(scenario, agent, **({'lane_change': False} if (args.no_lane_change and scenario == 'large_grid') else {}))
     cfg_name = preset_name(scenario, agent, policy, E)
     is_q = agent in ('iqld', 'iqll')
     if is_q:                            # config/config_iql{d,l}_large.ini: batch 20, replay 1000, reward_norm 3000, Adam 1e-4
@@ -570,6 +570,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the sim-only / sim+forward lines (SURVEY 8d) and the other single-GPU configs')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--no-lane-change', action='store_true', help='large_grid without DESIGN.md 3 rule 10 (the rounds 1 - 4 spec): A/B measurement only')
     ap.add_argument('--profile-stride', type=int, default=1,
                     help='profiled pass: HIP-event timing of every n-th launch of the per-control-step kernels (1 = all)')
     ap.add_argument('--profile-steps', type=int, default=0, help='iterations of the profiled pass (0 = same as --steps)')

@@ -666,47 +666,18 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     cur = nxt;
                     continue;
                 }
-                if (lc) {
-                    // the lane-change second: leader = the vehicle ahead on the own lane (old state) or, for the lane's head, the
-                    // sibling's old tail; the stop line counts as closed (no lane change and junction crossing in one second)
-                    const bool has_t = s.n[sb] > 0;
-                    const float ttx = s.tx[sb], ttv = s.tv[sb];
-                    float vn;
-                    if (i > 0) vn = follow(v, v0, true, (pox - kLen) - x, pov, kS0);
-                    else if (has_t) vn = follow(v, v0, true, (ttx - kLen) - x, ttv, kS0);
-                    else vn = follow(v, v0, false, 0.0f, 0.0f, 0.0f);
-                    {
-                        const float v2 = follow(v, v0, true, L - x, 0.0f, 0.0f);
-                        if (v2 < vn) vn = v2;
-                    }
-                    float xn = x + vn;
-                    bool clamped = false;
-                    if (xn > pnx - kLen) { xn = pnx - kLen; clamped = true; }
-                    if (has_t && xn > ttx - kLen) { xn = ttx - kLen; clamped = true; }
-                    if (xn > L) { xn = L; clamped = true; }
-                    if (xn < x) { xn = x; clamped = true; }
-                    if (clamped) vn = xn - x;
-                    uint32_t r1c = cur.r1;
-                    if constexpr (REC) {
-                        if (vn < kHalt) r1c = (r1c + 1u) + (w == 0 ? 0x10000u : 0u);
-                    }
-                    w = (vn < kHalt) ? w + 1 : 0;
-                    pnx = xn; pox = x; pov = v;
-                    const int o = nsent * NLA + l;
-                    s.ox[o] = xn; s.ov[o] = vn; s.osf[o] = sf; s.om[o] = (uint32_t)w | ((uint32_t)r << 16); s.oto[o] = sb;
-                    if constexpr (REC) { s.or0[o] = cur.r0; s.or1[o] = r1c; }
-                    ++nsent; ++ncross;
-                    cur = nxt;
-                    continue;
-                }
-                const bool line_block = all_crossed ? !can_cross : !open;
-                const bool tgt_lead = can_cross && !sink && s.n[tl] > 0;
+                // (rule 10: a lane change is a hand-off to the sibling lane `sb` at distance 0 instead of L - x, with the stop line
+                //  closed -- no lane change and junction crossing in one second; it shares the evaluation below)
+                const bool line_block = lc || (all_crossed ? !can_cross : !open);
+                const bool tgt_lead = lc ? s.n[sb] > 0 : (can_cross && !sink && s.n[tl] > 0);
+                const int tq = tgt_lead ? (lc ? sb : tl) : 0;      // the lane whose old tail is the leader of the lane's head
+                const float Lq = lc ? 0.0f : L;                    // distance to that lane's start
                 // leader: vehicle ahead (old state), else the old tail of the target lane, else free road; the stop line
                 // is a second leader when the link is closed (evaluating both branch-free was measured no faster and
                 // costs 40 VGPRs)
                 const bool has_lead = i > 0 || tgt_lead;
-                const float lg = i > 0 ? (pox - kLen) - x : (L - x) + (s.tx[tgt_lead ? tl : 0] - kLen);
-                const float lvl = i > 0 ? pov : s.tv[tgt_lead ? tl : 0];
+                const float lg = i > 0 ? (pox - kLen) - x : (Lq - x) + (s.tx[tq] - kLen);
+                const float lvl = i > 0 ? pov : s.tv[tq];
                 float vn = follow(v, v0, has_lead, lg, lvl, kS0);
                 if (line_block) {
                     const float v2 = follow(v, v0, true, L - x, 0.0f, 0.0f);
@@ -714,7 +685,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 }
                 // rule 10: the head of a lane that has to move over lines up BEHIND the sibling's queue instead of driving past
                 // it: the sibling's old tail is a third leader while it is still ahead
-                if (sb >= 0 && i == 0 && s.n[sb] > 0) {
+                if (sb >= 0 && !lc && i == 0 && s.n[sb] > 0) {
                     const float g3 = (s.tx[sb] - kLen) - x;
                     if (g3 >= 0.0f) {
                         const float v3 = follow(v, v0, true, g3, s.tv[sb], kS0);
@@ -738,7 +709,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     bool clamped = false;
                     if (xn > pnx - kLen) { xn = pnx - kLen; clamped = true; }
                     if (tgt_lead) {
-                        const float lim = L + (s.tx[tl] - kLen);
+                        const float lim = Lq + (s.tx[tq] - kLen);
                         if (xn > lim) { xn = lim; clamped = true; }
                     }
                     if (can_cross && !sink) {                          // target lane shorter than one step's travel
@@ -756,7 +727,12 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 w = (vn < kHalt) ? w + 1 : 0;
                 pnx = xn; pox = x; pov = v;
                 const uint32_t nmeta = (uint32_t)w | ((uint32_t)r << 16);
-                if (can_cross && xn >= L) {
+                if (lc) {                                   // rule 10: over to the sibling lane, position kept
+                    const int o = nsent * NLA + l;
+                    s.ox[o] = xn; s.ov[o] = vn; s.osf[o] = sf; s.om[o] = nmeta; s.oto[o] = sb;
+                    if constexpr (REC) { s.or0[o] = cur.r0; s.or1[o] = r1n; }
+                    ++nsent; ++ncross;
+                } else if (can_cross && xn >= L) {
                     if (!sink) {
                         const int o = nsent * NLA + l;
                         const float ex = xn - L, Lt = s.len[tl];          // rounding of (L + Lt) - L
