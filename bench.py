@@ -132,7 +132,7 @@ def cpu_baseline(n_env=48, n_step=120, threads=8):
     one iteration (n_step control steps + update), run twice: with float32 nets (the reference's TensorFlow arithmetic:
     `value`) and with the float64 nets the parity tests use as the checker (`value_float64_nets`).  SURVEY 8(d) baseline (i)
     -- the reference's OWN env class over the fake TraCI backend, which only exists in the build container -- is quoted
-    from the committed profiles/r04_oracle_a.json (tools/time_oracle_a.py)."""
+    from the committed profiles/r05_oracle_a.json (tools/time_oracle_a.py)."""
     from deeprl_signal_control_amd.scenario import build_large_grid
     from oracle.env_oracle import OracleEnv
     import oracle.nets_oracle as nets
@@ -218,9 +218,9 @@ def cpu_baseline(n_env=48, n_step=120, threads=8):
     if allc:
         out['sim_only_all_cores'] = allc
     try:                                # SURVEY 8(d) baseline (i), measured where /root/reference exists (not on this box)
-        oa = json.load(open(os.path.join(ROOT, 'profiles', 'r04_oracle_a.json')))
+        oa = json.load(open(os.path.join(ROOT, 'profiles', 'r05_oracle_a.json')))
         out['reference_env_over_fake_traci'] = {
-            'source': 'profiles/r04_oracle_a.json (tools/time_oracle_a.py, build container, 1 core): committed measurement, NOT timed in this run',
+            'source': 'profiles/r05_oracle_a.json (tools/time_oracle_a.py, build container, 1 core): committed measurement, NOT timed in this run',
             'env_only': {k: oa['oracle_a_env'][k] for k in ('value', 'unit', 'what')},
             'training_loop': {k: oa['oracle_a_training_loop'][k] for k in ('value', 'unit', 'what')}}
     except Exception:

@@ -142,8 +142,8 @@ class Connection:
         self.tripinfo = tripinfo
         if tripinfo:
             self.ms.record()
-        from deeprl_signal_control_amd.scenario import draw_stream_routes
-        self.ms.reset(seed, draw_stream_routes(self.scn, seed))
+        from oracle.env_oracle import episode_stream_routes
+        self.ms.reset(seed, episode_stream_routes(self.scn, seed))
         self.tl_ids = list(scn.node_names)
         self.aidx = {n: i for i, n in enumerate(scn.node_names)}
         self.lidx = {n: i for i, n in enumerate(scn.lane_names)}

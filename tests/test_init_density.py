@@ -23,6 +23,8 @@ def test_initial_flows_match_the_reference_generator(golden_dir):
     route_sink = {r: dst for r, (_, dst) in enumerate(scn.route_names)}
     for seed, flows in ref.items():
         routes = draw_stream_routes(scn, int(seed))
+        from oracle.env_oracle import episode_stream_routes
+        np.testing.assert_array_equal(episode_stream_routes(scn, int(seed)), routes)     # the checker's own scalar draw agrees
         for k, (fid, src, dst, lane, number) in enumerate(flows):
             assert int(fid) == k + 1 and number == 6
             assert lanes[k] == '%s_%d' % (src, lane), (seed, k)

@@ -6,7 +6,7 @@ replaced by an in-process C library (so it is an UPPER bound on what the referen
 socket).  Second figure: the reference's whole training loop (agents/models.py MA2C + utils.py Trainer.run, unmodified) over
 oracle/fake_tf.py (float64 torch standing in for TensorFlow 1.12) on that env, one shortened episode.
 
-Build container only (/root/reference does not exist on the GPU box): writes profiles/r04_oracle_a.json, which bench.py
+Build container only (/root/reference does not exist on the GPU box): writes profiles/r05_oracle_a.json, which bench.py
 quotes inside `cpu_baseline`.
 
     python tools/time_oracle_a.py [control_steps=240] [episode_sec=600]
@@ -73,6 +73,6 @@ if __name__ == '__main__':
     out = dict(host=dict(machine=platform.machine(), cpus=os.cpu_count(), python=platform.python_version(),
                          note='build container (the GPU box has no /root/reference); one core'),
                oracle_a_env=time_env(n_ctrl), oracle_a_training_loop=time_loop(ep))
-    path = os.path.join(ROOT, 'profiles', 'r04_oracle_a.json')
+    path = os.path.join(ROOT, 'profiles', 'r05_oracle_a.json')
     json.dump(out, open(path, 'w'), indent=1)
     print(json.dumps(out, indent=1))
