@@ -437,17 +437,33 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
     live = float(np.mean([e_.live_vehicle_mean(steps * model.n_step) for e_ in envs]))
     msr = tr.mean_step_reward()
     # ---- a second, profiled pass of the same loop: HIP events on the launch stream around every kernel -------------
-    prof, psteps, live_prof, dt_prof = {}, args.profile_steps or steps, None, None
+    # a profiled pass covers one whole episode (T / n_step iterations, whatever its phase): its vehicle count is the episode mean,
+    # the figure the committed PMC summaries were collected at
+    prof, psteps, live_prof, dt_prof = {}, args.profile_steps or int(env.T // model.n_step), None, None
     if want_profile:
-        _lib.profile(enable=max(1, args.profile_stride), reset=True)
-        t1 = time.perf_counter()
-        for _ in range(psteps):
-            tr.run_iteration()
-        sync()
-        dt_prof = time.perf_counter() - t1
-        prof = _lib.profile()
-        _lib.profile(enable=False)
-        live_prof = float(np.mean([e_.live_vehicle_mean(psteps * model.n_step) for e_ in envs]))
+        # An event pair between two dependent launches costs the FOLLOWING launch (the packets behind the forward, which leaves
+        # 160 MB of dirty lines, add ~17 us to the simulator step's figure; 98 against 80 us by rocprofv3), so the kernels
+        # that alternate once per control step are bracketed in passes of their own: the simulator step alone, the other
+        # per-control-step kernels (the rollout forward) alone, then the update's kernels together (tsc_profile_select).
+        per_step = ('env_step', 'policy_fwd_fused', 'add_transition', 'fingerprint', 'sample')
+        names = _lib.profile_names()
+        passes = [['env_step'], [n for n in per_step if n != 'env_step'], [n for n in names if n not in per_step]]
+        dt_prof, live_prof = 0.0, None
+        for sel in passes:
+            _lib.profile_select(sel)
+            _lib.profile(enable=max(1, args.profile_stride), reset=True)
+            t1 = time.perf_counter()
+            for _ in range(psteps):
+                tr.run_iteration()
+            sync()
+            dt_prof = max(dt_prof, time.perf_counter() - t1)
+            got = _lib.profile()
+            _lib.profile(enable=False)
+            prof.update({k: v for k, v in got.items() if k in sel and v[0] > 0})
+            lv = float(np.mean([e_.live_vehicle_mean(psteps * model.n_step) for e_ in envs]))
+            if sel == ['env_step']:
+                live_prof = lv                      # the vehicle count that belongs to the simulator's figure
+        _lib.profile_select(None)
     extra = {}
     if rank == 0 and world == 1 and B == 1 and want_extra and not is_q:
         extra = extra_lines(env, model, scn)
@@ -495,7 +511,8 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
                 if k == 'env_step':
                     alg = (32.0 * live_prof + 16.0 * scn.n_lane + scn.n_agent * 52.0 / 5.0) * ctrl * E      # SURVEY 8d bytes per launch
                     d['frac_hbm'] = round(alg / avg / 1e9 / PEAK_HBM_GBS, 4)
-                    d['frac_hbm_timing'] = 'HIP-event pair around the launch: includes the event packets (~10 us at this launch length), i.e. understates the kernel'
+                    d['frac_hbm_timing'] = ('HIP-event pair around the launch, only this kernel bracketed in its pass: still includes the launch boundary '
+                                            'behind the forward (~8 us), i.e. understates the kernel')
                     us, src = rocprof_avg_us('step_kernel', cfg_name)
                     if us:      # the profiler's own figure of the same kernel in the committed trace of this configuration
                         d['rocprofv3_avg_us'] = us
@@ -534,9 +551,9 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
             if us:
                 roof['rocprofv3_avg_launch_ms'] = us * 1e-3
                 roof['rocprofv3_source'] = src + ' (committed rocprofv3 --kernel-trace --stats run of this command, not this run)'
-            roof['timed'] = ('HIP events on the launch stream around every %slaunch, in a second pass of %d iterations of the same loop '
-                             'right after the timed region (the timed region itself carries no events); that pass took %.2f ms '
-                             'per iteration' % ('%d-th per-control-step ' % args.profile_stride if args.profile_stride > 1 else '',
+            roof['timed'] = ('HIP events on the launch stream around every %slaunch of one group of kernels at a time (the simulator step / the '
+                             'rollout forward / the update), in passes of %d iterations of the same loop right after the timed region (which '
+                             'carries no events); the slowest pass took %.2f ms per iteration' % ('%d-th per-control-step ' % args.profile_stride if args.profile_stride > 1 else '',
                                                 psteps, 1e3 * dt_prof / psteps))
             roof['mean_live_vehicles_per_env'] = live_prof
             roof['avg_launch_ms'] = ms / cnt
@@ -573,7 +590,7 @@ def main():
     ap.add_argument('--no-lane-change', action='store_true', help='large_grid without DESIGN.md 3 rule 10 (the rounds 1 - 4 spec): A/B measurement only')
     ap.add_argument('--profile-stride', type=int, default=1,
                     help='profiled pass: HIP-event timing of every n-th launch of the per-control-step kernels (1 = all)')
-    ap.add_argument('--profile-steps', type=int, default=0, help='iterations of the profiled pass (0 = same as --steps)')
+    ap.add_argument('--profile-steps', type=int, default=0, help='iterations of every profiled pass (0 = one episode: T / n_step)')
     ap.add_argument('--config', default=None, choices=['c2', 'c3', 'c5', 'q1'],
                     help='BASELINE.json configs[i] presets: c2 = large_grid IA2C FC, 256 envs; c3 = large_grid MA2C LSTM, 1024 envs '
                          '(the default); c5 = real_net Monaco MA2C LSTM, 512 envs per GPU; q1 = large_grid IQL-DNN, 1024 envs (SURVEY 8f rank 1: 20 control '

@@ -41,7 +41,7 @@ class TscScenario(C.Structure):
 _LIB = None
 
 # every symbol include/tsc.h declares (tests/test_abi.py checks the header against this list)
-SYMBOLS = ['tsc_last_error', 'tsc_version', 'tsc_profile_enable', 'tsc_profile_reset', 'tsc_profile_read',
+SYMBOLS = ['tsc_last_error', 'tsc_version', 'tsc_profile_enable', 'tsc_profile_select', 'tsc_profile_reset', 'tsc_profile_read',
            'tsc_profile_name', 'tsc_env_create', 'tsc_env_destroy', 'tsc_env_set_stream', 'tsc_env_set_resident_instances',
            'tsc_env_reset', 'tsc_env_set_stream_routes', 'tsc_env_set_greedy', 'tsc_env_greedy_actions', 'tsc_env_set_fingerprint', 'tsc_env_bind_fingerprint', 'tsc_env_reward_sum', 'tsc_env_step', 'tsc_env_get_state',
            'tsc_env_live_vehicles', 'tsc_env_counters', 'tsc_env_debug_clock', 'tsc_env_live_sum', 'tsc_env_record', 'tsc_env_read_record', 'tsc_env_read_trips',
@@ -71,6 +71,7 @@ def lib():
     L.tsc_profile_name.restype = C.c_char_p
     L.tsc_profile_name.argtypes = [C.c_int32]
     L.tsc_profile_enable.argtypes = [C.c_int32]
+    L.tsc_profile_select.argtypes = [C.c_uint64]
     L.tsc_profile_read.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.tsc_env_create.argtypes = [C.POINTER(TscScenario), C.c_int32, C.c_int32, C.POINTER(vp)]
     L.tsc_env_destroy.argtypes = [vp]
@@ -152,6 +153,28 @@ def scenario_struct(scn):
         s.stream_mode = arr(scn.stream_mode, np.int32, _ip)
         s.stream_choice = arr(scn.stream_choice, np.int32, _ip)
     return s, keep
+
+
+def profile_names():
+    L = lib()
+    out, i = [], 0
+    while True:
+        name = L.tsc_profile_name(i).decode()
+        if not name:
+            return out
+        out.append(name)
+        i += 1
+
+
+def profile_select(names=None):
+    """Bracket only these kernels with event pairs (None = all): an event pair between two dependent launches inflates the
+    FOLLOWING launch's figure, so a kernel is measured cleanly with only its own launches bracketed."""
+    mask = 0
+    if names:
+        all_names = profile_names()
+        for n in names:
+            mask |= 1 << all_names.index(n)
+    check(lib().tsc_profile_select(mask))
 
 
 def profile(enable=None, reset=False):

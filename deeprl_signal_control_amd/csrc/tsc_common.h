@@ -51,6 +51,7 @@ enum KernelId : int {
 
 struct ProfState {
     bool on = false;
+    unsigned long long only = ~0ull;              // bit k: kernel id k is timed (tsc_profile_select); the others are only counted
     int stride = 1;                               // time every stride-th launch of the per-control-step kernels
     long long seq[KID_COUNT] = {0};               // all launches
     struct Rec { int id; hipEvent_t a, b; };
@@ -69,6 +70,7 @@ struct ProfScope {
         const bool per_step = id == KID_ENV_STEP || id == KID_FUSED_FWD || id == KID_ADD_TRANS || id == KID_FINGERPRINT ||
                               id == KID_SAMPLE;
         if (p.seq[id]++ % (per_step ? p.stride : 1) != 0) return;
+        if (!((p.only >> id) & 1ull)) return;
         auto get = [&]() { hipEvent_t e; if (!p.pool.empty()) { e = p.pool.back(); p.pool.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
         a = get(); b = get();
         (void)hipEventRecord(a, st);

@@ -1212,6 +1212,7 @@ extern "C" {
 const char *tsc_last_error(void) { return tsc::err_buf(); }
 
 int tsc_profile_enable(int32_t on) { tsc::prof().on = on != 0; tsc::prof().stride = on > 1 ? on : 1; return 0; }
+int tsc_profile_select(uint64_t mask) { tsc::prof().only = mask ? mask : ~0ull; return 0; }
 
 static int prof_fold() {
     tsc::ProfState &p = tsc::prof();

@@ -107,6 +107,10 @@ int tsc_version(void);            /* 100 * major + minor; 105: tsc_env_set_greed
  * total_ms = average of the timed launches x all launches, count = all launches. */
 int tsc_profile_enable(int32_t on);
 int tsc_profile_reset(void);
+/* Time only the kernel ids whose bit is set (0 = all, the default): an event pair between two dependent launches costs the
+ * FOLLOWING launch up to ~17 us (the packets behind a kernel that leaves much dirty data), so a kernel's own duration is
+ * measured with only ITS launches bracketed; read() of an unselected id returns count without time. */
+int tsc_profile_select(uint64_t mask);
 int tsc_profile_read(int32_t kernel_id, double *total_ms, int64_t *count);
 const char *tsc_profile_name(int32_t kernel_id);   /* "" past the last id */
 
