@@ -500,7 +500,15 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
             out['kernels'] = {k: {'ms_total': round(v[0], 3), 'launches': v[1]} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
         elif prof:
             total = sum(ms for ms, _ in prof.values())
-            dom = max(prof, key=lambda k: prof[k][0])
+            # which kernel dominates: by event totals -- except that the simulator step's event figure carries the launch boundary
+            # behind the forward (~9 us per launch even when bracketed alone; the profiler's figure does not), which at 80 - 100 us
+            # per launch of either kernel decides the order.  For the RANKING its per-launch time is capped at 1.1 x the committed
+            # rocprofv3 average of this configuration's step kernel, when there is one; every reported figure stays the event's.
+            rank = {k: v[0] for k, v in prof.items()}
+            us_rp, _ = rocprof_avg_us('step_kernel', cfg_name)
+            if us_rp and 'env_step' in rank:
+                rank['env_step'] = min(rank['env_step'], 1.1 * us_rp * 1e-3 * prof['env_step'][1])
+            dom = max(rank, key=lambda k: rank[k])
             ms, cnt = prof[dom]
             avg_s = ms / cnt * 1e-3
             kern = {k: {'ms_total': round(v[0], 3), 'launches': v[1]} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
@@ -556,6 +564,8 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
                              'carries no events); the slowest pass took %.2f ms per iteration' % ('%d-th per-control-step ' % args.profile_stride if args.profile_stride > 1 else '',
                                                 psteps, 1e3 * dt_prof / psteps))
             roof['mean_live_vehicles_per_env'] = live_prof
+            roof['dominant_by'] = ('largest total of the HIP-event passes; the simulator step enters the ranking with at most 1.1 x its committed '
+                                   'rocprofv3 average per launch (its event figure includes the launch boundary behind the forward)')
             roof['avg_launch_ms'] = ms / cnt
             roof['share_of_kernel_time'] = ms / total
             roof['kernel_time_ms_total'] = total
