@@ -93,3 +93,40 @@ def test_foe_tables_of_the_junction_experiment():
             for j in range(int(rn.agent_nlink[a])):
                 assert ((int(rn.link_foes[a, k]) >> j) & 1) == ((int(rn.link_foes[a, j]) >> k) & 1), (a, k, j)
             assert not (int(rn.link_foes[a, k]) >> k) & 1
+
+
+def test_greedy_controller_tables_restate_the_three_reference_controllers():
+    """Scenario.greedy_controller_tables (what tsc_env_set_greedy uploads and trainer.greedy_actions walks on the host):
+    large_grid = LargeGridController's hard-coded lane pairs (envs/large_grid_env.py:56-60, restated by the oracle's
+    greedy_large_grid) incl. first-argmax ties and the float64 non-tie 0.2 + 0.4 > 0.6; small_grid = STATE_PHASE_MAP
+    (envs/small_grid_env.py:29-30,51-55); Monaco = the 'G' links of every phase in link order, every lane once
+    (envs/real_net_env.py:90-111; its recorded answers: tests/test_real_net.py)."""
+    from deeprl_signal_control_amd.scenario import build_small_grid
+    from deeprl_signal_control_amd.trainer import greedy_actions
+    from oracle.env_oracle import greedy_large_grid
+    rng = np.random.RandomState(3)
+    lg = build_large_grid('greedy')
+    n_cand, term, action = lg.greedy_controller_tables()
+    assert n_cand.tolist() == [5] * 25 and term[0].tolist() == [[0, 3], [2, 5], [1, 4], [1, 2], [4, 5]] and action[0].tolist() == [0, 1, 2, 3, 4]
+    ob = np.clip(rng.randint(0, 12, (40, 25, 6)) / 5.0, 0, 2.0)
+    ob[0, 0] = [0.2, 0.0, 0.6, 0.4, 0.0, 0.0]
+    want = np.array([[greedy_large_grid(ob[e, a]) for a in range(25)] for e in range(40)])
+    np.testing.assert_array_equal(greedy_actions(lg, ob), want)
+    assert want[0, 0] == 0
+    sg = build_small_grid('greedy')
+    n_cand, term, action = sg.greedy_controller_tables()
+    spm = sg.extra['state_phase_map']
+    for a, n in enumerate(sg.node_names):
+        assert n_cand[a] == len(spm[n]) and action[a, :n_cand[a]].tolist() == list(spm[n])
+        assert term[a, :n_cand[a], 0].tolist() == list(range(len(spm[n]))) and (term[a, :, 1:] == -1).all()
+    w = rng.rand(10, sg.n_agent, 3)
+    for e in range(10):
+        for a, n in enumerate(sg.node_names):
+            assert greedy_actions(sg, w)[e, a] == spm[n][int(np.argmax(w[e, a, :len(spm[n])]))]
+    rn = build_real_net('greedy')
+    n_cand, term, action = rn.greedy_controller_tables()
+    assert n_cand.tolist() == [int(x) for x in rn.agent_nphase] and (action[0, :n_cand[0]] == np.arange(n_cand[0])).all()
+    for a in range(rn.n_agent):
+        for c in range(int(n_cand[a])):
+            t = [int(x) for x in term[a, c] if x >= 0]
+            assert len(t) == len(set(t)) and all(x < int(rn.agent_nlane[a]) for x in t)      # every lane once, own lanes only
