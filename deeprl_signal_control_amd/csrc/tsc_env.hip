@@ -1696,6 +1696,12 @@ int tsc_env_set_greedy(tsc_env *h, int32_t n_cand_max, int32_t n_term_max, const
     }
     (void)hipSetDevice(h->device);
     TSC_HIP(hipStreamSynchronize(h->stream));                  // a running greedy_kernel may still read the old tables
+    for (const void *old : {(const void *)P.g_ncand, (const void *)P.g_term, (const void *)P.g_action}) {      // a second call replaces them
+        if (!old) continue;
+        for (auto it = h->allocs.begin(); it != h->allocs.end(); ++it)
+            if (*it == old) { (void)hipFree(*it); h->allocs.erase(it); break; }
+    }
+    P.g_ncand = nullptr; P.g_term = nullptr; P.g_action = nullptr;
     UP(g_ncand, int, n_cand, P.A);
     UP(g_term, int8_t, t8.data(), t8.size());
     UP(g_action, int, cand_action, (size_t)P.A * n_cand_max);

@@ -828,6 +828,9 @@ policy_fwd_fc_mfma_kernel(const float *__restrict__ params, Layout lay, const in
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            // (one range test per step: every MFMA of this dependent 64-cycle chain sits in a block of its own behind its LDS
+            //  operand, whose latency the previous MFMA covers -- grouping eight steps behind one test was measured slower, round 5:
+            //  19.3 -> 20.4 us, six wasted steps at SMAX = 36)
 #pragma unroll
             for (int s = 0; s < 32; ++s)
                 if (s < KS1) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[(2 * s + kh) * kFmLd + li], w1[uu][s], acc, 0, 0, 0);
@@ -2023,6 +2026,14 @@ dx1w1_kernel2(const float *__restrict__ dZ, const float *__restrict__ X1, const 
         // dW1 += obs^T dX1 : contraction step i takes rows 16 r + 4 kq + i = the accumulator's own rows
         auto tail = [&](int r, const f32x4 &c, const float (&xm)[4]) {
             const float *Os = Ob + ((long long)buf * 32 + 16 * r + 4 * kq) * kObLd + n;
+            // all 16 obs operands first, unconditionally (the registers of the A-operand quads are free by now): with the
+            // feature-tile test around every single MFMA each of them sat in a basic block of its own -- LDS read, wait, MFMA --
+            // and paid its operand's LDS latency alone (round 5: 16 % of the kernel)
+            float os[16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) os[4 * ft + i] = Os[i * kObLd + 16 * ft];
             float d[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -2030,11 +2041,11 @@ dx1w1_kernel2(const float *__restrict__ dZ, const float *__restrict__ X1, const 
                 bs += d[i];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int ft = 0; ft < 4; ++ft)
+                if ((fm >> ft) & 1) {                                   // wave-uniform: one test per feature tile
 #pragma unroll
-                for (int ft = 0; ft < 4; ++ft)
-                    if ((fm >> ft) & 1)                                 // wave-uniform
-                        aw[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(Os[i * kObLd + 16 * ft], d[i], aw[ft], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) aw[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(os[4 * ft + i], d[i], aw[ft], 0, 0, 0);
+                }
         };
         if (r0) tail(0, c0, xm0);
         if (r1) tail(1, c1, xm1);
@@ -2236,6 +2247,11 @@ fc_bwd_kernel(const float *__restrict__ dZ, const float *__restrict__ X1, const 
         // dW1 += obs^T dX1 : contraction step i takes rows 16 r + 4 kq + i = the accumulator's own rows
         auto tail = [&](int r, const f32x4 &c, const float (&xm)[4]) {
             const float *Os = Ob + ((long long)buf * 32 + 16 * r + 4 * kq) * kObLd + n;
+            float os[16];                                      // all obs operands first (see dx1w1_kernel2: one test per feature tile)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) os[4 * ft + i] = Os[i * kObLd + 16 * ft];
             float d[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -2243,11 +2259,11 @@ fc_bwd_kernel(const float *__restrict__ dZ, const float *__restrict__ X1, const 
                 bs += d[i];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int ft = 0; ft < 4; ++ft)
+                if ((fm >> ft) & 1) {                                   // wave-uniform
 #pragma unroll
-                for (int ft = 0; ft < 4; ++ft)
-                    if ((fm >> ft) & 1)                                 // wave-uniform
-                        aw[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(Os[i * kObLd + 16 * ft], d[i], aw[ft], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) aw[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(os[4 * ft + i], d[i], aw[ft], 0, 0, 0);
+                }
         };
         if (r0) tail(0, c0, xm0);
         if (r1) tail(1, c1, xm1);
