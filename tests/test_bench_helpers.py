@@ -1,0 +1,50 @@
+"""bench.py's bookkeeping that does not need a GPU: the committed-profile lookups behind `roofline.traffic` and the rocprofv3
+figures quoted next to the event figures."""
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location('bench_module', os.path.join(ROOT, 'bench.py'))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    return b
+
+
+def test_pmc_traffic_is_quoted_only_at_a_matching_vehicle_count():
+    """A committed PMC summary belongs to the vehicle count of its own pass: quoted when this run's window mean is within
+    15 %, refused (None + the reason) otherwise, and per configuration (no summary: None)."""
+    b = _bench()
+    for cfg, suffix in (('c3', ''), ('c2', '_c2'), ('c5', '_c5')):
+        d = json.load(open(os.path.join(ROOT, 'profiles', '%s_pmc%s.json' % (b.PROFILE_TAGS[0], suffix))))
+        v = float(d['mean_live_vehicles_per_env'])
+        k = d['kernels']['env_step']
+        got, src = b.pmc_traffic('env_step', cfg, v * 1.1)
+        assert got == (k['fetch_kb'] + k['write_kb']) * 1024.0 and 'committed measurement' in src and 'whole episodes' in src
+        got, why = b.pmc_traffic('env_step', cfg, v * 1.3)
+        assert got is None and 'refused' in why and '15 %' in why
+        got, why = b.pmc_traffic('env_step', cfg, v * 0.7)
+        assert got is None and 'refused' in why
+    assert b.pmc_traffic('env_step', 'q1', 600.0)[0] is None and b.pmc_traffic('env_step', None, 600.0)[0] is None
+
+
+def test_rocprofv3_averages_come_from_the_configuration_s_own_trace():
+    b = _bench()
+    us3, src3 = b.rocprof_avg_us('step_kernel', 'c3')
+    us2, src2 = b.rocprof_avg_us('step_kernel', 'c2')
+    us5, _ = b.rocprof_avg_us('step_kernel', 'c5')
+    assert src3.endswith('_kernel_stats.csv') and src2.endswith('_kernel_stats_c2.csv')
+    assert 60 < us3 < 110 and 30 < us2 < 70 and 35 < us5 < 80 and us2 < us3          # 256 threads / 1024 instances vs 1024 threads / 256 instances
+    fw, _ = b.rocprof_avg_us('policy_fwd_', 'c3')
+    assert 85 < fw < 110
+    assert b.rocprof_avg_us('step_kernel', None) == (None, None) and b.rocprof_avg_us('no_such_kernel', 'c3') == (None, None)
+
+
+def test_presets_name_the_baseline_configurations():
+    b = _bench()
+    assert b.preset_name('large_grid', 'ma2c', 'lstm', 1024) == 'c3' and b.preset_name('large_grid', 'ia2c', 'fc', 256) == 'c2'
+    assert b.preset_name('real_net', 'ma2c', 'lstm', 512) == 'c5' and b.preset_name('large_grid', 'iqld', 'dqn', 1024) == 'q1'
+    assert b.preset_name('large_grid', 'ma2c', 'lstm', 64) is None
