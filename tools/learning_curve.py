@@ -23,7 +23,7 @@ import numpy as np          # noqa: E402
 import torch                # noqa: E402
 
 
-def run(episodes, n_env, scenario='large_grid', agent='ma2c', seed=0, lr=None, log=None, policy='lstm', scn_kw=None):
+def run(episodes, n_env, scenario='large_grid', agent='ma2c', seed=0, lr=None, log=None, policy='lstm', scn_kw=None, test_seeds=None):
     from deeprl_signal_control_amd.agents import VecA2C
     from deeprl_signal_control_amd.env import VecTrafficEnv
     from deeprl_signal_control_amd.scenario import build_scenario
@@ -35,7 +35,7 @@ def run(episodes, n_env, scenario='large_grid', agent='ma2c', seed=0, lr=None, l
         mcfg, seed0 = dict(reward_norm=1.0, batch_size=40), 42
     if lr is not None:
         mcfg['lr_init'] = lr
-    env = VecTrafficEnv(scn, n_env, device=0, seed=seed0)
+    env = VecTrafficEnv(scn, n_env, device=0, seed=seed0, **({'test_seeds': tuple(test_seeds)} if test_seeds else {}))
     model = VecA2C(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, scn.n_f_ls, n_env, scn.s_max, int(scn.green_tab.shape[1]), mcfg,
                    device=0, seed=seed, name=agent, policy=policy)
     tr = VecTrainer(env, model, log_rewards=True)
@@ -92,10 +92,12 @@ def main():
     ap.add_argument('--lr', type=float, default=None)
     ap.add_argument('--policy', default='lstm', choices=['lstm', 'fc'], help='fc = FcACPolicy (ia2c only; BASELINE configs[1])')
     ap.add_argument('--lane-change', type=int, default=None, help='large_grid: 1 / 0 = with / without DESIGN.md 3 rule 10 (default: the scenario default)')
+    ap.add_argument('--test-seeds', default=None, help='comma-separated evaluation seeds (default: the config\'s test_seeds)')
     ap.add_argument('--out', default=None)
     args = ap.parse_args()
     kw = {} if args.lane_change is None else {'lane_change': bool(args.lane_change)}
-    rows, ev = run(args.episodes, args.envs, args.scenario, args.agent, lr=args.lr, log=print, policy=args.policy, scn_kw=kw)
+    rows, ev = run(args.episodes, args.envs, args.scenario, args.agent, lr=args.lr, log=print, policy=args.policy, scn_kw=kw,
+                   test_seeds=[int(x) for x in args.test_seeds.split(',')] if args.test_seeds else None)
     first, last = np.mean([r['avg_reward'] for r in rows[:5]]), np.mean([r['avg_reward'] for r in rows[-5:]])
     out = dict(scenario=args.scenario, agent=args.agent, policy=args.policy, envs=args.envs, episodes=args.episodes, scenario_options=kw,
                control_steps_per_episode=rows[0]['step'], first5_mean=first, last5_mean=last, rows=rows, evaluation=ev,
