@@ -164,14 +164,37 @@ __global__ void __launch_bounds__(256, 2) gemm_grouped_kernel(GemmArgs p) {
         const int buf = kt & 1;
         if (kt + 1 < nk) load_tiles(kbeg + (kt + 1) * BK);
         const int kh = lane >> 5, li = lane & 31;
+        // One liveness test per K tile, not per MFMA (round 5): with the test around every MFMA each sat in a basic block of its own and
+        // the next step's LDS operands could not be requested under it.  The whole-wave cases -- all four 32 x 32 sub-tiles live, or one
+        // column of them (N <= 32 beyond the wave's first column: the skinny heads) -- run straight-line; ragged tiles keep the tests.
+        if (live_m1 && live_n1) {
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const float a0 = As[buf][kk + kh][wm + li], a1 = As[buf][kk + kh][wm + 32 + li];
-            const float b0 = Bs[buf][kk + kh][wn + li], b1 = Bs[buf][kk + kh][wn + 32 + li];
-            if (live_m0 && live_n0) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            if (live_m0 && live_n1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            if (live_m1 && live_n0) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            if (live_m1 && live_n1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            for (int kk = 0; kk < BK; kk += 2) {
+                const float a0 = As[buf][kk + kh][wm + li], a1 = As[buf][kk + kh][wm + 32 + li];
+                const float b0 = Bs[buf][kk + kh][wn + li], b1 = Bs[buf][kk + kh][wn + 32 + li];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        } else if (live_m1 && live_n0) {                    // (live_n1 false: one live column of sub-tiles)
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                const float a0 = As[buf][kk + kh][wm + li], a1 = As[buf][kk + kh][wm + 32 + li];
+                const float b0 = Bs[buf][kk + kh][wn + li];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                const float a0 = As[buf][kk + kh][wm + li], a1 = As[buf][kk + kh][wm + 32 + li];
+                const float b0 = Bs[buf][kk + kh][wn + li], b1 = Bs[buf][kk + kh][wn + 32 + li];
+                if (live_m0 && live_n0) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                if (live_m0 && live_n1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                if (live_m1 && live_n0) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                if (live_m1 && live_n1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
         }
         if (TN && p.colsum && m0 == 0 && tid < BN) {
 #pragma unroll
