@@ -350,6 +350,18 @@ PRESETS = {'c2': ('large_grid', 'ia2c', 'fc', 256), 'c3': ('large_grid', 'ma2c',
            'q1': ('large_grid', 'iqld', 'dqn', 1024)}      # q1: config/config_iqld_large.ini, not a BASELINE config
 
 
+def iterations_per_episode(scenario, agent):
+    """720 control steps per episode (3600 s / 5 s) over the agent's n_step (config/*.ini batch_size)."""
+    n_step = 20 if agent in ('iqld', 'iqll') else 120 if scenario == 'large_grid' else 40
+    return 720 // n_step
+
+
+def warmup_iterations(ipe):
+    """Whole warm-up episodes, at least 10 iterations (the first timed iterations of a fresh box otherwise run ~1 % below its
+    steady clock): the timed window then starts at an episode boundary."""
+    return ipe * max(1, -(-10 // ipe))
+
+
 def preset_name(scenario, agent, policy, E):
     for k, v in PRESETS.items():
         if v == (scenario, agent, policy, E):
@@ -501,8 +513,8 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
         elif prof:
             total = sum(ms for ms, _ in prof.values())
             # which kernel dominates: by event totals -- except that the simulator step's event figure carries the launch boundary
-            # behind the forward (~9 us per launch even when bracketed alone; the profiler's figure does not), which at 80 - 100 us
-            # per launch of either kernel decides the order.  For the RANKING its per-launch time is capped at 1.1 x the committed
+            # behind the forward (~3 us per launch when bracketed alone, ~17 us when every kernel is bracketed; the profiler's figure has
+            # neither), which at 90 - 100 us per launch of either kernel can decide the order.  For the RANKING its per-launch time is capped at 1.1 x the committed
             # rocprofv3 average of this configuration's step kernel, when there is one; every reported figure stays the event's.
             rank = {k: v[0] for k, v in prof.items()}
             us_rp, _ = rocprof_avg_us('step_kernel', cfg_name)
@@ -520,7 +532,7 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
                     alg = (32.0 * live_prof + 16.0 * scn.n_lane + scn.n_agent * 52.0 / 5.0) * ctrl * E      # SURVEY 8d bytes per launch
                     d['frac_hbm'] = round(alg / avg / 1e9 / PEAK_HBM_GBS, 4)
                     d['frac_hbm_timing'] = ('HIP-event pair around the launch, only this kernel bracketed in its pass: still includes the launch boundary '
-                                            'behind the forward (~8 us), i.e. understates the kernel')
+                                            'behind the forward (~3 us against the whole-episode rocprofv3 average), i.e. understates the kernel')
                     us, src = rocprof_avg_us('step_kernel', cfg_name)
                     if us:      # the profiler's own figure of the same kernel in the committed trace of this configuration
                         d['rocprofv3_avg_us'] = us
@@ -587,8 +599,8 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=None, help='timed iterations (default 10; 20 for the short iterations of c2 / c5)')
-    ap.add_argument('--warmup', type=int, default=None, help='untimed iterations before (default 10: a cold device needs ~0.3 s of load to reach its clocks)')
+    ap.add_argument('--steps', type=int, default=None, help='timed iterations (default: two episodes = 12 on large_grid, 36 on Monaco, 72 for IQL)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed iterations before (default: one episode, at least 10: a cold device needs ~0.3 s of load to reach its clocks)')
     ap.add_argument('--envs', type=int, default=1024, help='env instances per GPU')
     ap.add_argument('--agent', default='ma2c', choices=['ma2c', 'ia2c', 'iqld', 'iqll'])
     ap.add_argument('--scenario', default='large_grid', choices=['large_grid', 'real_net'])
@@ -609,14 +621,16 @@ def main():
                     help='process-group backend for N > 1 (nccl = RCCL; gloo only for the two-ranks-on-one-GPU test)')
     ap.add_argument('--device', type=int, default=None, help='force this device index on every rank (test only)')
     args = ap.parse_args()
-    # an iteration of c2 / c5 is 9-13 ms: two of them do not bring a cold device up to its clocks, six are 60 ms of timed region
-    short = args.config in ('c2', 'c5', 'q1')
-    if args.steps is None:
-        args.steps = 20 if short else 10
-    if args.warmup is None:
-        args.warmup = 10              # (4 until round 4: the first timed iterations of a fresh box then ran 1 % below its steady clock)
     if args.config:
         args.scenario, args.agent, args.policy, args.envs = PRESETS[args.config]
+    # the window covers >= 2 full episodes after >= 1 warm-up episode, so that the demand peak is inside and the window
+    # mean of the vehicles is the episode mean (what the committed PMC passes were collected at).  An episode is 720 control steps =
+    # 6 iterations of large_grid's A2C agents (n_step 120), 18 of Monaco's (40), 36 of the IQL agents (20).
+    ipe = iterations_per_episode(args.scenario, args.agent)
+    if args.steps is None:
+        args.steps = 2 * ipe
+    if args.warmup is None:
+        args.warmup = warmup_iterations(ipe)
     # the plain driver line (no --config / --envs ... given) also carries the other single-GPU configurations of BASELINE.json
     plain = (args.config is None and (args.scenario, args.agent, args.policy, args.envs, args.batches) == ('large_grid', 'ma2c', 'lstm', 1024, 1))
 
@@ -642,7 +656,8 @@ def main():
         cfgs = {}
         for name in ('c2', 'c5'):
             sc, ag, po, E = PRESETS[name]
-            o = run_config(args, rank, world, local, sc, ag, po, E, 20, 10, want_extra=False, want_cpu=False, want_profile=not args.no_profile)
+            o = run_config(args, rank, world, local, sc, ag, po, E, 2 * iterations_per_episode(sc, ag), warmup_iterations(iterations_per_episode(sc, ag)),
+                           want_extra=False, want_cpu=False, want_profile=not args.no_profile)
             c = {'workload': o['config']['workload'], 'value': o['value'], 'unit': o['unit'], 'ms_per_step': o['ms_per_step'],
                  'steps': o['steps'], 'warmup': o['warmup'], 'mean_live_vehicles_per_env': o['config']['mean_live_vehicles_per_env']}
             if 'roofline' in o:
@@ -652,7 +667,8 @@ def main():
             cfgs[name] = c
         out.setdefault('extra', {})['configs'] = cfgs
         # the next row of SURVEY 8(f): the IQL-DNN learner on the same env path (config/config_iqld_large.ini), same method
-        o = run_config(args, rank, world, local, *PRESETS['q1'], 20, 10, want_extra=False, want_cpu=False, want_profile=False)
+        o = run_config(args, rank, world, local, *PRESETS['q1'], 2 * iterations_per_episode('large_grid', 'iqld'),
+                       warmup_iterations(iterations_per_episode('large_grid', 'iqld')), want_extra=False, want_cpu=False, want_profile=False)
         out['extra']['iql'] = {'workload': o['config']['workload'], 'value': o['value'], 'unit': o['unit'], 'ms_per_step': o['ms_per_step'],
                                'steps': o['steps'], 'warmup': o['warmup'], 'mean_live_vehicles_per_env': o['config']['mean_live_vehicles_per_env']}
     if rank == 0:

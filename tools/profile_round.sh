@@ -3,7 +3,8 @@
 #   tools/profile_round.sh r05 [c3 c2 c5 q1]
 # per configuration (c3 = the default workload; suffix "" / _c2 / _c5 / _q1):
 # 1. the bench line (c3: the driver line `python bench.py` with extra.configs and cpu_baseline)
-# 2. rocprofv3 --kernel-trace --stats of the same command (every launch timed by the profiler)
+# 2. rocprofv3 --kernel-trace --stats of the same command (every launch timed by the profiler; bench.py's default window = whole
+#    episodes, so the per-kernel averages are episode averages like the live HIP-event figures)
 # 3. PMC passes, each in its own run without any trace (MI355X_MICROARCH.md "HBM / rocprofv3"): FETCH_SIZE, WRITE_SIZE, SQ.
 #    The FETCH / WRITE passes cover WHOLE EPISODES (one warm-up episode + one timed episode), so that the per-launch averages
 #    belong to the episode-mean vehicle count the bench line of the pass reports (bench.py refuses a summary whose count is
@@ -32,7 +33,7 @@ for C in $CFGS; do
   else
     python $ROOT/bench.py --config $C --no-cpu-baseline > $RES/${TAG}_bench${SUF}.json 2> $OUT/${TAG}_bench${SUF}.err
   fi
-  rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace${SUF} -o t -- $B --steps 3 --warmup 1 --no-profile > $RES/${TAG}_bench_rocprof${SUF}.json 2> $OUT/${TAG}_trace${SUF}.err
+  rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace${SUF} -o t -- $B --no-profile > $RES/${TAG}_bench_rocprof${SUF}.json 2> $OUT/${TAG}_trace${SUF}.err
   python $ROOT/tools/rocpd_stats.py $(find $OUT/${TAG}_trace${SUF} -name "*.db" | head -1) $RES/${TAG}_kernel_stats${SUF}.csv
   rm -rf $OUT/${TAG}_trace${SUF}                 # the rocpd databases are tens of MB each; gpurun copies back at most 64 MiB
   [ $C = q1 ] && continue
