@@ -28,6 +28,18 @@ inline int fail(const char *fmt, ...) {
             return tsc::fail("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// A create function's handle until it is handed out: an error return on the way destroys it (and the device buffers it owns);
+// the error text stays in the thread's buffer (the destroy functions do not write it).
+template <class H, int (*Destroy)(H *)>
+struct CreateGuard {
+    H *h;
+    explicit CreateGuard(H *h_) : h(h_) {}
+    CreateGuard(const CreateGuard &) = delete;
+    CreateGuard &operator=(const CreateGuard &) = delete;
+    ~CreateGuard() { if (h) (void)Destroy(h); }
+    H *release() { H *t = h; h = nullptr; return t; }
+};
+
 template <typename T>
 inline hipError_t upload(T **dst, const T *src, size_t count) {
     hipError_t e = hipMalloc((void **)dst, sizeof(T) * (count ? count : 1));

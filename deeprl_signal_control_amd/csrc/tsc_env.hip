@@ -1275,6 +1275,7 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     if (sc->n_route > 254) return tsc::fail("tsc_env_create: n_route %d > 254 unsupported", sc->n_route);
     TSC_HIP(hipSetDevice(device));
     tsc_env *h = new tsc_env();
+    tsc::CreateGuard<tsc_env, tsc_env_destroy> guard(h);        // an error return below frees the handle and its buffers
     h->device = device;
     h->stream = nullptr;
     EnvDev &P = h->P;
@@ -1326,7 +1327,11 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     UP(lane_len, float, sc->lane_len, NL); UP(lane_vmax, float, sc->lane_vmax, NL);
     UP(lane_det, float, sc->lane_det_start, NL);
     UP(lane_node, int, sc->lane_node, NL);
-    if (sc->lane_sib) UP(lane_sib, int, sc->lane_sib, NL);
+    if (sc->lane_sib) {
+        for (int l = 0; l < NL; ++l)
+            if (sc->lane_sib[l] >= NL || sc->lane_sib[l] == l) return tsc::fail("tsc_env_create: lane %d names sibling lane %d of %d", l, sc->lane_sib[l], NL);
+        UP(lane_sib, int, sc->lane_sib, NL);
+    }
     {
         std::vector<int> up(sc->lane_up, sc->lane_up + (size_t)NL * kMaxUp);
         for (int &u : up) if (u >= 0 && (u >= NL || !reach[u])) u = -1;        // a feeder that is never occupied never sends
@@ -1499,7 +1504,8 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     if (const char *ev = getenv("TSC_ENV_SPEC")) if (!atoi(ev)) h->spec = 0;
     // vehicles per thread and super-round of the flat phase (TSC_ENV_KF = 1 / 2 / 4 for A/B runs).  With runtime dimensions
     // 1 is best (296 M env-steps/s; 2: 294, 4: 284 -- fewer barriers do not pay for the registers); the specialised kernel
-    // has the registers for 2 (env step 11.5 -> 10.7 ms per rollout; 4 spills: 11.4)
+    // has the registers for 2 (env step 11.5 -> 10.7 ms per rollout; 4 spills: 11.4; round 5, rule-10 traffic, episode average:
+    // 3 -- 128 VGPRs, 8 spilled dwords, bit-exact -- 94.9 / 95.3 us per control step against 92.7 / 92.8 with 2)
     h->kf = h->spec == 1 ? 2 : 1;                            // (Monaco, spec 2: 330 M env-steps/s with 1, 323 M with 2)
     if (const char *ev = getenv("TSC_ENV_KF")) { const int kv = atoi(ev); h->kf = (kv == 2 || kv == 4) ? kv : 1; }
     if (h->spec && h->kf == 4) h->spec = 0;                  // (no specialised instantiation of the 4-wide variant)
@@ -1525,7 +1531,7 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)step_kernel<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
     TSC_HIP(hipFuncSetAttribute((const void *)reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smem));
-    *out = h;
+    *out = guard.release();
     return 0;
 }
 

@@ -306,6 +306,7 @@ int tsc_iql_create(const tsc_iql_cfg *cfg, int32_t n_env, int32_t device, tsc_iq
         return tsc::fail("tsc_iql_create: need 0 < batch_size <= 64 <= buffer_size");
     TSC_HIP(hipSetDevice(device));
     tsc_iql *h = new tsc_iql();
+    tsc::CreateGuard<tsc_iql, tsc_iql_destroy> guard(h);        // an error return below frees the handle and its buffers
     h->device = device; h->stream = nullptr; h->E = n_env; h->B = cfg->batch_size; h->cap = cfg->buffer_size; h->cum = 0;
     h->gamma = cfg->gamma; h->rnorm = cfg->reward_norm; h->rclip = cfg->reward_clip; h->max_norm = cfg->max_grad_norm;
     h->adam_t = 0;
@@ -356,7 +357,7 @@ int tsc_iql_create(const tsc_iql_cfg *cfg, int32_t n_env, int32_t device, tsc_iq
     QMALLOC(h->norm2, double, A); QMALLOC(h->stats, double, A * 2);
     h->ws_floats = (size_t)16 << 20; h->wsc_floats = (size_t)1 << 18;
     QMALLOC(h->ws, float, h->ws_floats); QMALLOC(h->wsc, float, h->wsc_floats);
-    *out = h;
+    *out = guard.release();
     return 0;
 }
 

@@ -2441,6 +2441,7 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
     if (cfg->s_max % 4) return tsc::fail("tsc_model_create: s_max must be a multiple of 4");
     TSC_HIP(hipSetDevice(device));
     tsc_model *m = new tsc_model();
+    tsc::CreateGuard<tsc_model, tsc_model_destroy> guard(m);        // an error return below frees the handle and its buffers
     m->device = device; m->stream = nullptr; m->E = n_env; m->T = cfg->n_step;
     m->gamma = cfg->gamma; m->rnorm = cfg->reward_norm; m->rclip = cfg->reward_clip; m->vcoef = cfg->value_coef;
     m->max_norm = cfg->max_grad_norm; m->alpha = cfg->rmsp_alpha; m->eps = cfg->rmsp_epsilon;
@@ -2558,7 +2559,7 @@ int tsc_model_create(const tsc_model_cfg *cfg, int32_t n_env, int32_t device, ts
         TSC_HIP(hipFuncSetAttribute((const void *)policy_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_fused));
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((m->nparam + 255) / 256)), dim3(256), 0, 0, m->ms, m->nparam, 1.0f);
     TSC_HIP(hipDeviceSynchronize());
-    *out = m;
+    *out = guard.release();
     return 0;
 }
 

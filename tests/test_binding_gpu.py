@@ -310,3 +310,31 @@ def test_two_half_batch_handles_sum_to_the_full_batch_gradient():
     np.testing.assert_array_equal(ha.get_flat(), hb.get_flat())
     for m in (full, ha, hb):
         m.close()
+
+
+@pytest.mark.gpu
+def test_failing_creates_report_and_free_what_they_allocated():
+    """An error return of tsc_env_create / tsc_model_create / tsc_iql_create hands out no handle, leaves the reason in
+    tsc_last_error, and frees the handle with the device buffers it had already allocated (csrc/tsc_common.h CreateGuard):
+    a scenario with a sibling lane out of range is refused AFTER the first lane tables were uploaded (four buffers); 2000 such
+    calls -- 8000 buffers, at least 32 MB at the allocator's 4-KB granularity -- leave the device's free memory where it was."""
+    import ctypes as C
+    import torch
+    from deeprl_signal_control_amd import _lib
+    from deeprl_signal_control_amd.scenario import build_large_grid
+    L = _lib.lib()
+    scn = build_large_grid('ma2c')
+    scn.lane_sib = scn.lane_sib.copy()
+    scn.lane_sib[3] = scn.n_lane + 7
+    sc, keep = _lib.scenario_struct(scn)
+    torch.zeros(1).cuda()                                  # (the runtime's first allocation sets up its pools: ~150 MB once)
+    assert L.tsc_env_create(C.byref(sc), 1024, 0, C.byref(C.c_void_p())) != 0
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(2000):
+        h = C.c_void_p()
+        assert L.tsc_env_create(C.byref(sc), 1024, 0, C.byref(h)) != 0 and not h.value
+        assert b'sibling lane' in L.tsc_last_error()
+    assert abs(torch.cuda.mem_get_info()[0] - free0) < (8 << 20)
+    with pytest.raises(RuntimeError, match='sibling lane'):
+        _lib.check(L.tsc_env_create(C.byref(sc), 4, 0, C.byref(C.c_void_p())))
