@@ -11,8 +11,11 @@
 //
 // Mapping: one workgroup per env instance: one thread per lane that a route can ever put a vehicle on (a
 // prefix after load sorting, padded to a multiple of 64 = NLA) plus helper threads up to 256.  Vehicles live
-// in HBM as slot-major SoA  X/V/SF/M[E][CAP][NLP]: slot i of all lanes of one env is contiguous, so the
-// per-lane front-to-back walk issues fully coalesced loads.  Everything lanes need from *other* lanes
+// in HBM as lane-major SoA  X/V/SF/M[E][NLP][CAP] (vslot): a lane's queue is contiguous, front first, so the flat phase --
+// consecutive threads own consecutive queued vehicles of a lane, and it is most of the kernel -- reads and writes runs of
+// up to 27 x 4 bytes (until round 5 the arrays were slot-major [CAP][NLP], coalesced for the lane threads' head walk instead:
+// every flat-phase access instruction touched 64 cache lines; 92.7 -> 86.3 us per control step at E = 1024 over whole
+// episodes).  Everything lanes need from *other* lanes
 // (tail/head summaries, signal states, the per-step hand-off outbox, the route tables) is staged in LDS; one
 // control step (2 yellow + 3 green simulated seconds, detectors, obs, reward) is a single launch.  Per
 // simulated second: phase H (lane threads: the platoon that crosses and the first vehicle that stays), phase F (all
@@ -38,6 +41,11 @@ constexpr float kLen = 5.0f, kS0 = 2.0f /* standstill gap (SUMO minGap 2.5 less 
                 kAcc = 5.0f, kDec = 10.0f, kTHead = 1.0f;   // headway = SUMO's default tau
 constexpr float kICab = 0.070710678f /* 1 / (2 sqrt(acc dec)): a multiply instead of an IEEE division */, kHalt = 0.1f, kYieldT = 3.0f, kYieldD = 10.0f;
 constexpr int kCap = TSC_LANE_CAP, kMaxCross = TSC_MAX_CROSS, kMaxUp = TSC_MAX_UP;
+// Element index of slot i of lane q in an instance's vehicle arrays X / V / SF / M (and R0 / R1).
+#ifndef TSC_LANE_MAJOR
+#define TSC_LANE_MAJOR 1
+#endif
+__host__ __device__ __forceinline__ int vslot(int i, int q, int NLP) { return TSC_LANE_MAJOR ? q * kCap + i : i * NLP + q; }
 
 constexpr int kMaxEntry = 8;           // routes that may share one entry lane (small_grid: 6 paths leave np1_nt1)
 // movement word of (lane, route):  [11:0] next lane (0xFFF = route ends here, 0xFFE = n/a)
@@ -440,8 +448,9 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     float hx = 0, hv = 0, tx = 0, tv = 0; uint32_t hm = 0;
     {
         const int nl = n > 0 ? n - 1 : 0;
-        const float x0 = X[lc], v0 = V[lc], xl = X[nl * NLP + lc], vl = V[nl * NLP + lc];
-        const uint32_t m0 = M[lc];
+        const int s0 = vslot(0, lc, NLP), sl = vslot(nl, lc, NLP);
+        const float x0 = X[s0], v0 = V[s0], xl = X[sl], vl = V[sl];
+        const uint32_t m0 = M[s0];
         if (n > 0) { hx = x0; hv = v0; hm = m0; tx = xl; tv = vl; }
     }
     // K1: signal FSM (envs/env.py:128-152) -> link chars for the yellow and the green interval
@@ -552,7 +561,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             float K = INFINITY;                            // plain walk: running min of the chain keys (DESIGN.md rule 4)
             // a vehicle that stays on the lane: compact it to slot `kept`, refresh the summary, count detectors
             auto keep = [&](float xn, float vn, float sf, uint32_t nmeta, uint32_t r0 = 0u, uint32_t r1 = 0u) {
-                const unsigned ob = (unsigned)(kept * NLP + l) * 4u;
+                const unsigned ob = (unsigned)vslot(kept, l, NLP) * 4u;
                 stg(X, ob, xn); stg(V, ob, vn); stg(SF, ob, sf); stg(M, ob, nmeta);
                 if constexpr (REC) { stg(R0, ob, r0); stg(R1, ob, r1); tally(xn, vn, nmeta); }
                 if (kept == 0) { hx = xn; hv = vn; hm = nmeta; }
@@ -567,7 +576,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             // load in flight across the evaluation of the previous vehicle (s_waitcnt vmcnt(N > 0)) when the
             // number of younger memory operations is known, which a load under `if (i < n)` destroys.
             auto load_raw = [&](int i) {
-                const unsigned ob = (unsigned)((i < kCap ? i : kCap - 1) * NLP + l) * 4u;
+                const unsigned ob = (unsigned)vslot(i < kCap ? i : kCap - 1, l, NLP) * 4u;
                 Raw r; r.x = ldg(X, ob); r.v = ldg(V, ob); r.sf = ldg(SF, ob); r.m = ldg(M, ob);
                 r.r0 = 0u; r.r1 = 0u;
                 if constexpr (REC) { r.r0 = ldg(R0, ob); r.r1 = ldg(R1, ob); }
@@ -843,7 +852,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                         const int q = max(lmax[u], excl) - 1;
                         const int i = kks[u] - s.pre[q] + 1;
                         eq[u] = q; ei[u] = i;
-                        const unsigned ob = (unsigned)(i * NLP + q) * 4u, pb = ob - (unsigned)NLP * 4u;
+                        const unsigned ob = (unsigned)vslot(i, q, NLP) * 4u, pb = (unsigned)vslot(i - 1, q, NLP) * 4u;
                         x[u] = ldg(X, ob); v[u] = ldg(V, ob); sf[u] = ldg(SF, ob); m[u] = ldg(M, ob);
                         px[u] = ldg(X, pb); pv[u] = ldg(V, pb);
                     }
@@ -909,7 +918,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     const uint32_t w = (vv < kHalt) ? (m[u] & 0xFFFFu) + 1u : 0u;
                     const uint32_t nmeta = w | (m[u] & 0xFFFF0000u);
                     const int shift = s.nc[q];
-                    const unsigned ob = (unsigned)((i - shift) * NLP + q) * 4u;
+                    const unsigned ob = (unsigned)vslot(i - shift, q, NLP) * 4u;
                     stg(X, ob, xn); stg(V, ob, vv); stg(M, ob, nmeta);
                     if (shift) stg(SF, ob, sf[u]);
                     if (i == s.n[q] - 1) { s.tx[q] = xn; s.tv[q] = vv; }
@@ -932,7 +941,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 // lane was compacted behind it by the flat phase
                 kept = has_first ? n - i0 : 0;
                 if (has_first) {
-                    const unsigned ob0 = (unsigned)l * 4u;
+                    const unsigned ob0 = (unsigned)vslot(0, l, NLP) * 4u;
                     stg(X, ob0, fxn); stg(V, ob0, fvn); stg(SF, ob0, fsf); stg(M, ob0, fmeta);
                     hx = fxn; hv = fvn; hm = fmeta;
                     if (kept >= 2) { tx = s.tx[l]; tv = s.tv[l]; } else { tx = fxn; tv = fvn; }
@@ -950,7 +959,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 for (int j = 0; j < cnt; ++j) {
                     const int o = j * NLA + src;
                     if (s.oto[o] == l && n < kCap) {
-                        const int d = n * NLP + l;
+                        const int d = vslot(n, l, NLP);
                         float ax = s.ox[o];
                         const float av = s.ov[o];
                         const uint32_t am = s.om[o];
@@ -1007,7 +1016,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                             }
                         }
                         const uint32_t am = (uint32_t)rt << 16;
-                        const int d = n * NLP + l;
+                        const int d = vslot(n, l, NLP);
                         X[d] = ax; V[d] = 0.0f; SF[d] = asf; M[d] = am;
                         if constexpr (REC) { R0[d] = (uint32_t)t | ((uint32_t)ser << 16); R1[d] = 0u; tally(ax, 0.0f, am); ++rq_dep; }
                         if (n == 0) { hx = ax; hv = 0.0f; hm = am; }
@@ -1786,7 +1795,7 @@ int tsc_env_get_state(tsc_env *h, int32_t e, int32_t *n, float *x, float *v, flo
         n[l] = hn[l];
         for (int i = 0; i < kCap; ++i) {
             const bool live = i < hn[l];
-            const size_t s = (size_t)i * P.NLP + l, d = (size_t)l * kCap + i;
+            const size_t s = (size_t)vslot(i, l, P.NLP), d = (size_t)l * kCap + i;
             x[d] = live ? hx[s] : 0.0f; v[d] = live ? hv[s] : 0.0f; sf[d] = live ? hs[s] : 0.0f;
             w[d] = live ? (int)(hm[s] & 0xFFFFu) : 0; r[d] = live ? (int)(hm[s] >> 16) : 0;
         }
