@@ -83,8 +83,7 @@ struct EnvDev {
     const int *obs_ks;             // [A*SMAX] obs_kind << 16 | obs_src (one load per observation entry)
     int ctrl, yellow, episode, teleport, queue_cap, objective, agent_kind, realnet_scale;
     double coop_gamma, norm_wave, norm_wait, clip_wave, clip_wait, coef_wait;
-    float *X, *V, *SF;
-    uint32_t *M;                   // w | route << 16
+    float4 *S;                     // [E][NLP][CAP] vehicle records {x, v, desired-speed factor, bits of (w | route << 16)}
     int *N;                        // [E][NLP]
     int *pending, *serial;         // [E][NS]
     int *tsec;
@@ -403,8 +402,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
 #define TSC_STAMP() do { if (stamp && nstamp < 62) P.dbg[nstamp++] = clock64(); } while (0)
     TSC_STAMP();
     if (P.dbg && threadIdx.x == 0) P.dbg[64 + 2 * blockIdx.x] = wall_clock64();
-    float *X = P.X + (size_t)e * kCap * NLP, *V = P.V + (size_t)e * kCap * NLP, *SF = P.SF + (size_t)e * kCap * NLP;
-    uint32_t *M = P.M + (size_t)e * kCap * NLP;
+    float4 *S = P.S + (size_t)e * kCap * NLP;
     static_assert(!(HELP && REC), "recording uses the plain walk");
     uint32_t *R0 = REC ? P.R0 + (size_t)e * kCap * NLP : nullptr, *R1 = REC ? P.R1 + (size_t)e * kCap * NLP : nullptr;
     const float origin = REC && lane ? P.lane_origin[l] : 0.0f;
@@ -449,9 +447,9 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     {
         const int nl = n > 0 ? n - 1 : 0;
         const int s0 = vslot(0, lc, NLP), sl = vslot(nl, lc, NLP);
-        const float x0 = X[s0], v0 = V[s0], xl = X[sl], vl = V[sl];
-        const uint32_t m0 = M[s0];
-        if (n > 0) { hx = x0; hv = v0; hm = m0; tx = xl; tv = vl; }
+        const float4 a0 = S[s0];
+        const float2 al = *(const float2 *)(S + sl);
+        if (n > 0) { hx = a0.x; hv = a0.y; hm = __float_as_uint(a0.w); tx = al.x; tv = al.y; }
     }
     // K1: signal FSM (envs/env.py:128-152) -> link chars for the yellow and the green interval
     if (ag) {
@@ -562,7 +560,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             // a vehicle that stays on the lane: compact it to slot `kept`, refresh the summary, count detectors
             auto keep = [&](float xn, float vn, float sf, uint32_t nmeta, uint32_t r0 = 0u, uint32_t r1 = 0u) {
                 const unsigned ob = (unsigned)vslot(kept, l, NLP) * 4u;
-                stg(X, ob, xn); stg(V, ob, vn); stg(SF, ob, sf); stg(M, ob, nmeta);
+                stg(S, 4u * ob, make_float4(xn, vn, sf, __uint_as_float(nmeta)));
                 if constexpr (REC) { stg(R0, ob, r0); stg(R1, ob, r1); tally(xn, vn, nmeta); }
                 if (kept == 0) { hx = xn; hv = vn; hm = nmeta; }
                 tx = xn; tv = vn;
@@ -577,7 +575,8 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             // number of younger memory operations is known, which a load under `if (i < n)` destroys.
             auto load_raw = [&](int i) {
                 const unsigned ob = (unsigned)vslot(i < kCap ? i : kCap - 1, l, NLP) * 4u;
-                Raw r; r.x = ldg(X, ob); r.v = ldg(V, ob); r.sf = ldg(SF, ob); r.m = ldg(M, ob);
+                const float4 a4 = ldg(S, 4u * ob);
+                Raw r; r.x = a4.x; r.v = a4.y; r.sf = a4.z; r.m = __float_as_uint(a4.w);
                 r.r0 = 0u; r.r1 = 0u;
                 if constexpr (REC) { r.r0 = ldg(R0, ob); r.r1 = ldg(R1, ob); }
                 return r;
@@ -853,8 +852,10 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                         const int i = kks[u] - s.pre[q] + 1;
                         eq[u] = q; ei[u] = i;
                         const unsigned ob = (unsigned)vslot(i, q, NLP) * 4u, pb = (unsigned)vslot(i - 1, q, NLP) * 4u;
-                        x[u] = ldg(X, ob); v[u] = ldg(V, ob); sf[u] = ldg(SF, ob); m[u] = ldg(M, ob);
-                        px[u] = ldg(X, pb); pv[u] = ldg(V, pb);
+                        const float4 a4 = ldg(S, 4u * ob);
+                        const float2 p2 = ldg((const float2 *)S, 4u * pb);
+                        x[u] = a4.x; v[u] = a4.y; sf[u] = a4.z; m[u] = __float_as_uint(a4.w);
+                        px[u] = p2.x; pv[u] = p2.y;
                     }
                     if (round > 0 && lf == 0 && ei[0] > 1) { px[0] = s.hz[0]; pv[0] = s.hz[1]; }   // overwritten by the previous super-round
     #pragma unroll
@@ -919,8 +920,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                     const uint32_t nmeta = w | (m[u] & 0xFFFF0000u);
                     const int shift = s.nc[q];
                     const unsigned ob = (unsigned)vslot(i - shift, q, NLP) * 4u;
-                    stg(X, ob, xn); stg(V, ob, vv); stg(M, ob, nmeta);
-                    if (shift) stg(SF, ob, sf[u]);
+                    stg(S, 4u * ob, make_float4(xn, vv, sf[u], __uint_as_float(nmeta)));
                     if (i == s.n[q] - 1) { s.tx[q] = xn; s.tv[q] = vv; }
                     if (last && xn >= P.lane_det[q]) { atomicAdd(&s.wave[q], 1); if (vv < kHalt) atomicAdd(&s.halt[q], 1); }
                 }
@@ -942,7 +942,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 kept = has_first ? n - i0 : 0;
                 if (has_first) {
                     const unsigned ob0 = (unsigned)vslot(0, l, NLP) * 4u;
-                    stg(X, ob0, fxn); stg(V, ob0, fvn); stg(SF, ob0, fsf); stg(M, ob0, fmeta);
+                    stg(S, 4u * ob0, make_float4(fxn, fvn, fsf, __uint_as_float(fmeta)));
                     hx = fxn; hv = fvn; hm = fmeta;
                     if (kept >= 2) { tx = s.tx[l]; tv = s.tv[l]; } else { tx = fxn; tv = fvn; }
                 }
@@ -967,7 +967,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                             ax = tx - kLen;
                             if (ax < 0.0f) ax = 0.0f;
                         }
-                        X[d] = ax; V[d] = av; SF[d] = s.osf[o]; M[d] = am;
+                        S[d] = make_float4(ax, av, s.osf[o], __uint_as_float(am));
                         if constexpr (REC) { R0[d] = s.or0[o]; R1[d] = s.or1[o]; tally(ax, av, am); }
                         if (n == 0) { hx = ax; hv = av; hm = am; }
                         tx = ax; tv = av;
@@ -1017,7 +1017,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                         }
                         const uint32_t am = (uint32_t)rt << 16;
                         const int d = vslot(n, l, NLP);
-                        X[d] = ax; V[d] = 0.0f; SF[d] = asf; M[d] = am;
+                        S[d] = make_float4(ax, 0.0f, asf, __uint_as_float(am));
                         if constexpr (REC) { R0[d] = (uint32_t)t | ((uint32_t)ser << 16); R1[d] = 0u; tally(ax, 0.0f, am); ++rq_dep; }
                         if (n == 0) { hx = ax; hv = 0.0f; hm = am; }
                         tx = ax; tv = 0.0f;
@@ -1471,7 +1471,7 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     }
 
     const size_t slots = (size_t)n_env * kCap * P.NLP;
-    ALLOC(X, float, slots); ALLOC(V, float, slots); ALLOC(SF, float, slots); ALLOC(M, uint32_t, slots);
+    ALLOC(S, float4, slots);
     ALLOC(N, int, (size_t)n_env * P.NLP);
     ALLOC(pending, int, (size_t)n_env * NS); ALLOC(serial, int, (size_t)n_env * NS);
     ALLOC(tsec, int, n_env); ALLOC(seed, uint32_t, n_env);
@@ -1783,21 +1783,19 @@ int tsc_env_get_state(tsc_env *h, int32_t e, int32_t *n, float *x, float *v, flo
     const EnvDev &P = h->P;
     TSC_HIP(hipStreamSynchronize(h->stream));
     const size_t slab = (size_t)kCap * P.NLP;
-    std::vector<float> hx(slab), hv(slab), hs(slab);
-    std::vector<uint32_t> hm(slab);
+    std::vector<float4> hs4(slab);
     std::vector<int> hn(P.NLP);
-    TSC_HIP(hipMemcpy(hx.data(), P.X + e * slab, slab * 4, hipMemcpyDeviceToHost));
-    TSC_HIP(hipMemcpy(hv.data(), P.V + e * slab, slab * 4, hipMemcpyDeviceToHost));
-    TSC_HIP(hipMemcpy(hs.data(), P.SF + e * slab, slab * 4, hipMemcpyDeviceToHost));
-    TSC_HIP(hipMemcpy(hm.data(), P.M + e * slab, slab * 4, hipMemcpyDeviceToHost));
+    TSC_HIP(hipMemcpy(hs4.data(), P.S + e * slab, slab * sizeof(float4), hipMemcpyDeviceToHost));
     TSC_HIP(hipMemcpy(hn.data(), P.N + (size_t)e * P.NLP, P.NLP * 4, hipMemcpyDeviceToHost));
     for (int l = 0; l < P.NL; ++l) {
         n[l] = hn[l];
         for (int i = 0; i < kCap; ++i) {
             const bool live = i < hn[l];
             const size_t s = (size_t)vslot(i, l, P.NLP), d = (size_t)l * kCap + i;
-            x[d] = live ? hx[s] : 0.0f; v[d] = live ? hv[s] : 0.0f; sf[d] = live ? hs[s] : 0.0f;
-            w[d] = live ? (int)(hm[s] & 0xFFFFu) : 0; r[d] = live ? (int)(hm[s] >> 16) : 0;
+            uint32_t mb = 0u;
+            if (live) memcpy(&mb, &hs4[s].w, 4);
+            x[d] = live ? hs4[s].x : 0.0f; v[d] = live ? hs4[s].y : 0.0f; sf[d] = live ? hs4[s].z : 0.0f;
+            w[d] = (int)(mb & 0xFFFFu); r[d] = (int)(mb >> 16);
         }
     }
     if (pending) TSC_HIP(hipMemcpy(pending, P.pending + (size_t)e * P.NS, P.NS * 4, hipMemcpyDeviceToHost));
