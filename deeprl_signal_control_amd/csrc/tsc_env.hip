@@ -443,13 +443,13 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     copy_words((uint32_t *)s.mv, (const uint32_t *)P.mv, P.NU * NR);
     copy_words((uint32_t *)s.zip, (const uint32_t *)P.zip, (P.NU * NR + 3) / 4);      // padded to 4 B
     // level 2 (needs n / act / t), issued before the remaining LDS fills
-    float hx = 0, hv = 0, tx = 0, tv = 0; uint32_t hm = 0;
+    float hx = 0, hv = 0, hsf = 0, tx = 0, tv = 0; uint32_t hm = 0;      // head record (slot 0) / tail of my lane, kept in registers
     {
         const int nl = n > 0 ? n - 1 : 0;
         const int s0 = vslot(0, lc, NLP), sl = vslot(nl, lc, NLP);
         const float4 a0 = S[s0];
         const float2 al = *(const float2 *)(S + sl);
-        if (n > 0) { hx = a0.x; hv = a0.y; hm = __float_as_uint(a0.w); tx = al.x; tv = al.y; }
+        if (n > 0) { hx = a0.x; hv = a0.y; hsf = a0.z; hm = __float_as_uint(a0.w); tx = al.x; tv = al.y; }
     }
     // K1: signal FSM (envs/env.py:128-152) -> link chars for the yellow and the green interval
     if (ag) {
@@ -562,7 +562,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 const unsigned ob = (unsigned)vslot(kept, l, NLP) * 4u;
                 stg(S, 4u * ob, make_float4(xn, vn, sf, __uint_as_float(nmeta)));
                 if constexpr (REC) { stg(R0, ob, r0); stg(R1, ob, r1); tally(xn, vn, nmeta); }
-                if (kept == 0) { hx = xn; hv = vn; hm = nmeta; }
+                if (kept == 0) { hx = xn; hv = vn; hsf = sf; hm = nmeta; }
                 tx = xn; tv = vn;
                 ++kept;
                 if (last && xn >= det) { ++d_wave; if (vn < kHalt) ++d_halt; }
@@ -582,7 +582,11 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 return r;
             };
             int i = 0;
-            Raw cur = load_raw(0);
+            // the head's record is what this thread wrote last (hx / hv / hsf / hm track slot 0): with HELP the walk starts from the
+            // registers instead of waiting for a load of it -- one memory round trip less on the second's critical path
+            Raw cur;
+            if constexpr (HELP && !REC) { cur.x = hx; cur.v = hv; cur.sf = hsf; cur.m = hm; cur.r0 = 0u; cur.r1 = 0u; }
+            else cur = load_raw(0);
             for (; i < n; ++i) {
                 if (HELP && !all_crossed) break;
                 const Raw nxt = load_raw(i + 1);
@@ -943,7 +947,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                 if (has_first) {
                     const unsigned ob0 = (unsigned)vslot(0, l, NLP) * 4u;
                     stg(S, 4u * ob0, make_float4(fxn, fvn, fsf, __uint_as_float(fmeta)));
-                    hx = fxn; hv = fvn; hm = fmeta;
+                    hx = fxn; hv = fvn; hsf = fsf; hm = fmeta;
                     if (kept >= 2) { tx = s.tx[l]; tv = s.tv[l]; } else { tx = fxn; tv = fvn; }
                 }
             }
@@ -969,7 +973,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                         }
                         S[d] = make_float4(ax, av, s.osf[o], __uint_as_float(am));
                         if constexpr (REC) { R0[d] = s.or0[o]; R1[d] = s.or1[o]; tally(ax, av, am); }
-                        if (n == 0) { hx = ax; hv = av; hm = am; }
+                        if (n == 0) { hx = ax; hv = av; hsf = s.osf[o]; hm = am; }
                         tx = ax; tv = av;
                         ++n;
                         if (last && ax >= det) { ++d_wave; if (av < kHalt) ++d_halt; }
@@ -1019,7 +1023,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
                         const int d = vslot(n, l, NLP);
                         S[d] = make_float4(ax, 0.0f, asf, __uint_as_float(am));
                         if constexpr (REC) { R0[d] = (uint32_t)t | ((uint32_t)ser << 16); R1[d] = 0u; tally(ax, 0.0f, am); ++rq_dep; }
-                        if (n == 0) { hx = ax; hv = 0.0f; hm = am; }
+                        if (n == 0) { hx = ax; hv = 0.0f; hsf = asf; hm = am; }
                         tx = ax; tv = 0.0f;
                         ++n;
                         if (last && ax >= det) { ++d_wave; ++d_halt; }
