@@ -48,3 +48,19 @@ def test_presets_name_the_baseline_configurations():
     assert b.preset_name('large_grid', 'ma2c', 'lstm', 1024) == 'c3' and b.preset_name('large_grid', 'ia2c', 'fc', 256) == 'c2'
     assert b.preset_name('real_net', 'ma2c', 'lstm', 512) == 'c5' and b.preset_name('large_grid', 'iqld', 'dqn', 1024) == 'q1'
     assert b.preset_name('large_grid', 'ma2c', 'lstm', 64) is None
+
+
+def test_default_window_is_two_whole_episodes_after_whole_warm_up_episodes():
+    """>= 2 full episodes timed after >= 1 warm-up episode.  An episode is 720 control steps; an iteration is the
+    agent's n_step control steps (config/*.ini batch_size: 120 large_grid A2C, 40 Monaco, 20 IQL); the warm-up is whole
+    episodes and at least 10 iterations (a cold device needs that long to reach its clocks)."""
+    b = _bench()
+    for (scenario, agent), (ipe, warm) in {('large_grid', 'ma2c'): (6, 12), ('large_grid', 'ia2c'): (6, 12), ('real_net', 'ma2c'): (18, 18),
+                                           ('large_grid', 'iqld'): (36, 36), ('large_grid', 'iqll'): (36, 36)}.items():
+        assert b.iterations_per_episode(scenario, agent) == ipe
+        assert b.warmup_iterations(ipe) == warm and warm % ipe == 0 and warm >= 10
+    # the package's defaults carry the reference's large_grid values (config_ma2c_large.ini / config_iqld_large.ini [MODEL_CONFIG])
+    from deeprl_signal_control_amd.agents import A2C_DEFAULTS
+    from deeprl_signal_control_amd.iql import IQL_DEFAULTS
+    assert 720 // A2C_DEFAULTS['batch_size'] == b.iterations_per_episode('large_grid', 'ma2c')
+    assert 720 // IQL_DEFAULTS['batch_size'] == b.iterations_per_episode('large_grid', 'iqld')
