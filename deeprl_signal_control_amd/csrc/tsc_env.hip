@@ -11,11 +11,13 @@
 //
 // Mapping: one workgroup per env instance: one thread per lane that a route can ever put a vehicle on (a
 // prefix after load sorting, padded to a multiple of 64 = NLA) plus helper threads up to 256.  Vehicles live
-// in HBM as lane-major SoA  X/V/SF/M[E][NLP][CAP] (vslot): a lane's queue is contiguous, front first, so the flat phase --
-// consecutive threads own consecutive queued vehicles of a lane, and it is most of the kernel -- reads and writes runs of
-// up to 27 x 4 bytes (until round 5 the arrays were slot-major [CAP][NLP], coalesced for the lane threads' head walk instead:
-// every flat-phase access instruction touched 64 cache lines; 92.7 -> 86.3 us per control step at E = 1024 over whole
-// episodes).  Everything lanes need from *other* lanes
+// in HBM as one 16-byte record per slot {x, v, desired-speed factor, bits of (wait | route << 16)}, lane-major: S[E][NLP][CAP]
+// (vslot) -- a lane's queue is contiguous, front first, so the flat phase (consecutive threads own consecutive queued vehicles
+// of a lane; it is most of the kernel) reads and writes runs of up to 27 x 16 bytes with one load / one store per vehicle.
+// Until round 5 the state was four slot-major arrays X / V / SF / M [CAP][NLP], coalesced for the lane threads' head walk
+// instead: every flat-phase access instruction touched 64 cache lines (92.7 -> 86.3 us per control step at E = 1024 over
+// whole episodes with lane-major arrays, -> 81.1 us with the records; PMC traffic per launch 159 -> 57 MB).
+// Everything lanes need from *other* lanes
 // (tail/head summaries, signal states, the per-step hand-off outbox, the route tables) is staged in LDS; one
 // control step (2 yellow + 3 green simulated seconds, detectors, obs, reward) is a single launch.  Per
 // simulated second: phase H (lane threads: the platoon that crosses and the first vehicle that stays), phase F (all
