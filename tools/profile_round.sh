@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiles of one round, on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh r05 [c3 c2 c5 q1]
+#   tools/profile_round.sh r05 [c2 c5 q1 c3]
 # per configuration (c3 = the default workload; suffix "" / _c2 / _c5 / _q1):
 # 1. (run last, see below) the bench line (c3: the driver line `python bench.py` with extra.configs and cpu_baseline)
 # 2. rocprofv3 --kernel-trace --stats of the same command (every launch timed by the profiler; bench.py's default window = whole
