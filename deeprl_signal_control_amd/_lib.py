@@ -52,7 +52,7 @@ SYMBOLS = ['tsc_last_error', 'tsc_version', 'tsc_profile_enable', 'tsc_profile_s
            'tsc_gemm_grouped_f32',
            'tsc_iql_create', 'tsc_iql_destroy', 'tsc_iql_set_stream', 'tsc_iql_layout', 'tsc_iql_set_params', 'tsc_iql_get_params',
            'tsc_iql_get_opt_state', 'tsc_iql_set_opt_state', 'tsc_iql_forward', 'tsc_iql_add_transition', 'tsc_iql_replay_size',
-           'tsc_iql_compute_grads', 'tsc_iql_compute_grads_at', 'tsc_iql_grad_buffer', 'tsc_iql_apply_grads', 'tsc_iql_debug_batch']
+           'tsc_iql_compute_grads', 'tsc_iql_compute_grads_at', 'tsc_iql_grad_buffer', 'tsc_iql_apply_grads', 'tsc_iql_debug_batch', 'tsc_iql_path']
 
 
 def lib():

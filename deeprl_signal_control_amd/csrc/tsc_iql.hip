@@ -23,6 +23,7 @@
 #include "../../include/tsc.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -235,6 +236,8 @@ __global__ void iql_adam_kernel(float *w, float *m1, float *m2, const float *gra
 
 }  // namespace
 
+#include "tsc_iql_fused.h"
+
 struct tsc_iql {
     QLayout lay;
     int E, B, device;
@@ -255,6 +258,10 @@ struct tsc_iql {
     double *norm2, *stats;
     float *ws, *wsc; size_t ws_floats, wsc_floats;
     long long nparam;
+    // fused DeepQPolicy learner (tsc_iql_fused.h): 0 = grouped-GEMM path, 8 / 10 = first-layer column tiles of the instantiation
+    int fused, fS, fcps;
+    int *n_wave, *n_wait;
+    float *fws, *fwsl;
 };
 
 namespace {
@@ -284,6 +291,17 @@ int q_forward(tsc_iql *h, const float *S, long long sS, int ldS, long long rows,
               L.H2, P + L.ob2, L.stride, nullptr, 0, 0, nullptr, 0, nullptr, 0)) return 1;
     return qgemm(h, false, tsc::EPI_BIAS, (int)rows, kQ, L.H2, X2, rows * L.H2, L.H2, P + L.oWq, L.stride, kQ, Q, rows * kQ, kQ,
                  P + L.obq, L.stride, nullptr, 0, 0, nullptr, 0, nullptr, 0);
+}
+
+QFusedArgs fused_args(const tsc_iql *h, long long size) {
+    const QLayout &L = h->lay;
+    QFusedArgs fa;
+    fa.params = h->params; fa.n_act = h->n_act; fa.n_wave = h->n_wave; fa.n_wait = h->n_wait; fa.idx = h->idx;
+    fa.r_obs = h->r_obs; fa.r_next = h->r_next; fa.r_rew = h->r_rew; fa.r_act = h->r_act; fa.r_done = h->r_done;
+    fa.E = h->E; fa.A = L.A; fa.B = h->B; fa.SMAX = L.SMAX; fa.size = (int)size; fa.cap = h->cap; fa.R = (long long)h->E * h->B;
+    fa.gamma = (float)h->gamma; fa.S = h->fS; fa.cps = h->fcps; fa.ws = h->fws; fa.wsl = h->fwsl;
+    fa.stride = L.stride; fa.oW1 = L.oW1; fa.ob1 = L.ob1; fa.oW2 = L.oW2; fa.ob2 = L.ob2; fa.oWq = L.oWq; fa.obq = L.obq;
+    return fa;
 }
 
 }  // namespace
@@ -344,19 +362,54 @@ int tsc_iql_create(const tsc_iql_cfg *cfg, int32_t n_env, int32_t device, tsc_iq
     QMALLOC(h->r_obs, float, E * h->cap * per); QMALLOC(h->r_next, float, E * h->cap * per);
     QMALLOC(h->r_rew, float, E * h->cap * A); QMALLOC(h->r_act, int, E * h->cap * A); QMALLOC(h->r_done, uint8_t, E * h->cap);
     QMALLOC(h->idx, int, E * A * h->B);
-    QMALLOC(h->S, float, A * R * L.SMAX); QMALLOC(h->S1, float, A * R * L.SMAX);
-    QMALLOC(h->rew, float, A * R); QMALLOC(h->q1, float, A * R); QMALLOC(h->act, int, A * R); QMALLOC(h->done, uint8_t, A * R);
-    QMALLOC(h->Q, float, A * R * kQ); QMALLOC(h->dQ, float, A * R * kQ); QMALLOC(h->Qe, float, A * E * kQ);
-    if (L.dqn) {
-        QMALLOC(h->X1, float, A * R * L.H1); QMALLOC(h->X2, float, A * R * L.H2); QMALLOC(h->dX2, float, A * R * L.H2);
-        QMALLOC(h->X1e, float, A * E * L.H1); QMALLOC(h->X2e, float, A * E * L.H2);
-        QMALLOC(h->W2T, float, A * L.H1 * L.H2); QMALLOC(h->WqT, float, A * L.H2 * kQ);
-    } else {
-        h->X1 = h->X2 = h->dX2 = h->X1e = h->X2e = h->W2T = h->WqT = nullptr;
-    }
+    QMALLOC(h->Qe, float, A * E * kQ);
     QMALLOC(h->norm2, double, A); QMALLOC(h->stats, double, A * 2);
-    h->ws_floats = (size_t)16 << 20; h->wsc_floats = (size_t)1 << 18;
-    QMALLOC(h->ws, float, h->ws_floats); QMALLOC(h->wsc, float, h->wsc_floats);
+    // The fused DeepQPolicy learner (tsc_iql_fused.h) is built for the reference's widths (config/config_iqld_*.ini: num_fc 128,
+    // num_h 64 -> H1 = 160 with wait inputs, 128 without) and observations of at most 48 features; anything else, IQL-LR, and
+    // TSC_IQL_FUSED=0 (the A/B switch of tests/test_iql_gpu.py) take the grouped-GEMM path.
+    h->fused = 0; h->fS = h->fcps = 0; h->fws = h->fwsl = nullptr;
+    TSC_HIP(tsc::upload<int>(&h->n_wave, cfg->n_wave, L.A)); h->allocs.push_back(h->n_wave);
+    TSC_HIP(tsc::upload<int>(&h->n_wait, cfg->n_wait, L.A)); h->allocs.push_back(h->n_wait);
+    {
+        const char *sw = getenv("TSC_IQL_FUSED");
+        const bool want = !(sw && sw[0] == '0');
+        if (want && L.dqn && cfg->n_fc0 == 128 && L.H2 == kFH2 && L.SMAX <= kFSF && (L.H1 == 128 || L.H1 == 160)) h->fused = L.H1 / 16;
+    }
+    if (h->fused) {
+        // row splits per agent: one workgroup per CU (the kernel holds its gradient tiles in registers over its whole slice)
+        const long long nchunks = (R + 63) / 64;
+        long long S = 256 / A;
+        if (S < 1) S = 1;
+        if (S > nchunks) S = nchunks;
+        h->fcps = (int)((nchunks + S - 1) / S);
+        h->fS = (int)((nchunks + h->fcps - 1) / h->fcps);
+        QMALLOC(h->fws, float, (long long)h->fS * A * L.stride); QMALLOC(h->fwsl, float, (long long)h->fS * A);
+        const int lds_g = (h->fused == 10 ? QFusedLds<10>::grad_floats : QFusedLds<8>::grad_floats) * 4;
+        const int lds_f = (h->fused == 10 ? QFusedLds<10>::fwd_floats : QFusedLds<8>::fwd_floats) * 4;
+        if (h->fused == 10) {
+            TSC_HIP(hipFuncSetAttribute((const void *)iql_fused_grad_kernel<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_g));
+            TSC_HIP(hipFuncSetAttribute((const void *)iql_fused_act_kernel<10, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_f));
+        } else {
+            TSC_HIP(hipFuncSetAttribute((const void *)iql_fused_grad_kernel<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_g));
+            TSC_HIP(hipFuncSetAttribute((const void *)iql_fused_act_kernel<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_f));
+        }
+        h->S = h->S1 = h->rew = h->q1 = h->Q = h->dQ = nullptr; h->act = nullptr; h->done = nullptr;
+        h->X1 = h->X2 = h->dX2 = h->X1e = h->X2e = h->W2T = h->WqT = nullptr;
+        h->ws = h->wsc = nullptr; h->ws_floats = h->wsc_floats = 0;
+    } else {
+        QMALLOC(h->S, float, A * R * L.SMAX); QMALLOC(h->S1, float, A * R * L.SMAX);
+        QMALLOC(h->rew, float, A * R); QMALLOC(h->q1, float, A * R); QMALLOC(h->act, int, A * R); QMALLOC(h->done, uint8_t, A * R);
+        QMALLOC(h->Q, float, A * R * kQ); QMALLOC(h->dQ, float, A * R * kQ);
+        if (L.dqn) {
+            QMALLOC(h->X1, float, A * R * L.H1); QMALLOC(h->X2, float, A * R * L.H2); QMALLOC(h->dX2, float, A * R * L.H2);
+            QMALLOC(h->X1e, float, A * E * L.H1); QMALLOC(h->X2e, float, A * E * L.H2);
+            QMALLOC(h->W2T, float, A * L.H1 * L.H2); QMALLOC(h->WqT, float, A * L.H2 * kQ);
+        } else {
+            h->X1 = h->X2 = h->dX2 = h->X1e = h->X2e = h->W2T = h->WqT = nullptr;
+        }
+        h->ws_floats = (size_t)16 << 20; h->wsc_floats = (size_t)1 << 18;
+        QMALLOC(h->ws, float, h->ws_floats); QMALLOC(h->wsc, float, h->wsc_floats);
+    }
     *out = guard.release();
     return 0;
 }
@@ -416,6 +469,18 @@ int tsc_iql_forward(tsc_iql *h, const float *obs, float *q_out, int32_t *action,
                     uint64_t step) {
     if (!h || !obs || !q_out || !action || mode < 0 || mode > 2) return tsc::fail("tsc_iql_forward: bad arguments");
     const QLayout &L = h->lay;
+    if (h->fused) {
+        QFusedArgs fa = fused_args(h, 0);
+        const unsigned grid = (unsigned)(L.A * ((h->E + 63) / 64));
+        if (h->fused == 10)
+            hipLaunchKernelGGL((iql_fused_act_kernel<10, 8>), dim3(grid), dim3(256), QFusedLds<10>::fwd_floats * 4, h->stream, fa, obs, (int)mode,
+                               eps, (unsigned long long)seed, (unsigned long long)step, L.AMAX, h->Qe, q_out, action);
+        else
+            hipLaunchKernelGGL((iql_fused_act_kernel<8, 8>), dim3(grid), dim3(256), QFusedLds<8>::fwd_floats * 4, h->stream, fa, obs, (int)mode,
+                               eps, (unsigned long long)seed, (unsigned long long)step, L.AMAX, h->Qe, q_out, action);
+        TSC_HIP(hipGetLastError());
+        return 0;
+    }
     // obs [E][A][SMAX]: agent a's rows start at a * SMAX with row stride A * SMAX
     if (q_forward(h, obs, L.SMAX, L.A * L.SMAX, h->E, h->X1e, h->X2e, h->Qe)) return tsc::fail("tsc_iql_forward: gemm launch failed");
     const int tot = h->E * L.A;
@@ -468,6 +533,19 @@ static int iql_compute_grads(tsc_iql *h, uint64_t seed, uint64_t update_index, c
     } else {
         hipLaunchKernelGGL(iql_sample_kernel, dim3((unsigned)((E * A + 127) / 128)), dim3(128), 0, st, (int)E, (int)A, h->B, size,
                            (unsigned long long)seed, (unsigned long long)update_index, h->idx);
+    }
+    if (h->fused) {
+        QFusedArgs fa = fused_args(h, size);
+        const unsigned grid = (unsigned)(A * h->fS);
+        if (h->fused == 10)
+            hipLaunchKernelGGL((iql_fused_grad_kernel<10, 8>), dim3(grid), dim3(256), QFusedLds<10>::grad_floats * 4, st, fa);
+        else
+            hipLaunchKernelGGL((iql_fused_grad_kernel<8, 8>), dim3(grid), dim3(256), QFusedLds<8>::grad_floats * 4, st, fa);
+        TSC_HIP(hipGetLastError());
+        hipLaunchKernelGGL(iql_fused_reduce_kernel, dim3((unsigned)((L.stride + 255) / 256), (unsigned)A), dim3(256), 0, st, h->fws, h->fwsl,
+                           (int)A, h->fS, L.stride, L.ob1, L.H1, h->rowrange, L.SMAX, h->grads, h->stats);
+        TSC_HIP(hipGetLastError());
+        return 0;
     }
     const long long tot = A * R * (L.SMAX / 4);
     hipLaunchKernelGGL(iql_gather_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (int)E, (int)A, L.SMAX, h->B, h->cap,
@@ -530,6 +608,12 @@ int tsc_iql_apply_grads(tsc_iql *h, double lr, double grad_scale, double *stats_
         TSC_HIP(hipMemcpy(n2.data(), h->norm2, sizeof(double) * L.A, hipMemcpyDeviceToHost));
         for (int a = 0; a < L.A; ++a) { stats_host[a * 2] = s[a * 2]; stats_host[a * 2 + 1] = sqrt(n2[a]); }
     }
+    return 0;
+}
+
+int tsc_iql_path(tsc_iql *h, int32_t *fused) {
+    if (!h || !fused) return tsc::fail("tsc_iql_path: bad arguments");
+    *fused = h->fused ? 1 : 0;
     return 0;
 }
 

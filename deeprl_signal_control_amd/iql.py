@@ -54,6 +54,7 @@ def _setup_lib(L):
     L.tsc_iql_grad_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
     L.tsc_iql_apply_grads.argtypes = [vp, C.c_double, C.c_double, vp]
     L.tsc_iql_debug_batch.argtypes = [vp, vp]
+    L.tsc_iql_path.argtypes = [vp, C.POINTER(C.c_int32)]
     L._iql_ready = True
 
 
@@ -177,6 +178,9 @@ class VecIQL:
         self.layout = QParamLayout(self.n_wave_ls, self.n_w_ls, self.n_a_ls, self.s_max, model_type, cfg['num_fc'], cfg['num_h'])
         assert self.layout.as_tuple() == tuple(int(x) for x in lay), 'host / device parameter layouts disagree'
         self.n_param = self.layout.n_param
+        f = C.c_int32()
+        _lib.check(L.tsc_iql_path(h, C.byref(f)))
+        self.fused = bool(f.value)          # the one-kernel DeepQPolicy learner (csrc/tsc_iql_fused.h) or the grouped-GEMM path
         with torch.cuda.device(self.device):
             self.stream = torch.cuda.current_stream(self.device)
             _lib.check(L.tsc_iql_set_stream(h, C.c_void_p(self.stream.cuda_stream)))

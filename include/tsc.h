@@ -363,6 +363,10 @@ int tsc_iql_grad_buffer(tsc_iql *h, float **grad_dev, int64_t *count);
 int tsc_iql_apply_grads(tsc_iql *h, double lr, double grad_scale, double *stats_host);
 /* Debug / parity access: the replay indices [E, A, batch_size] of the last tsc_iql_compute_grads. Synchronises. */
 int tsc_iql_debug_batch(tsc_iql *h, int32_t *idx_host);
+/* Which learner the handle runs: *fused = 1 when tsc_iql_forward / tsc_iql_compute_grads are the one-kernel DeepQPolicy path
+ * (csrc/tsc_iql_fused.h: num_fc 128, num_h 64, s_max <= 48 -- the reference's configurations), 0 for the grouped-GEMM path
+ * (IQL-LR, other widths, or TSC_IQL_FUSED=0 in the environment when the handle was created). */
+int tsc_iql_path(tsc_iql *h, int32_t *fused);
 
 /* Test hook: the grouped fp32 MFMA GEMM used by every layer.  form: 0 = NN, 1 = TN; epi as
  * csrc/tsc_gemm.h.  All pointers device; strides in elements.  A non-null split-K workspace lets

@@ -141,7 +141,7 @@ def test_hip_replays_reference_learner(name, E, path):
 
 
 # ---- IQL-LR / IQL-DNN -------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('name,E', [('refnet_iqll_large', 1), ('refnet_iqld_large', 1), ('refnet_iqld_large', 8)])
+@pytest.mark.parametrize('name,E', [('refnet_iqll_large', 1), ('refnet_iqld_large', 1), ('refnet_iqld_large', 8), ('refnet_iqld_large', 1024)])
 def test_hip_replays_reference_iql(name, E):
     """csrc/tsc_iql.hip (VecIQL) against the reference IQL executed over oracle/fake_tf.py (agents/models.py:264-376,
     agents/policies.py:285-389, agents/utils.py:231-263 unmodified): weights under the seed, Q values of every forward,
