@@ -40,13 +40,28 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec
 
 
-PROFILE_TAGS = ('r05',)           # committed rocprofv3 summaries this file may quote, newest first
+PROFILE_TAGS = ('r06', 'r05')           # committed rocprofv3 summaries this file may quote, newest first
+
+
+def fetch_calibration():
+    """(fetch factor, write factor, source) for 16-byte-per-lane streams from the committed calibration of the counters on a
+    known byte count (tools/fetch_calib.hip -> profiles/rNN_fetch_calibration.json), or the guide's x2 on FETCH_SIZE and
+    x1 on WRITE_SIZE when there is none."""
+    for tag in PROFILE_TAGS:
+        try:
+            d = json.load(open(os.path.join(ROOT, 'profiles', '%s_fetch_calibration.json' % tag)))
+            return (float(d['fetch']['read_f4']['factor']), float(d['write']['write_f4']['factor']),
+                    'profiles/%s_fetch_calibration.json (1-GiB streams of 16 B per lane, tools/fetch_calib.hip)' % tag)
+        except Exception:
+            continue
+    return 2.0, 1.0, 'MI355X_MICROARCH.md "HBM": FETCH_SIZE x 2 for 16 B/lane streams, WRITE_SIZE uncalibrated (x 1)'
 
 
 def pmc_traffic(kernel, cfg_name, live):
     """(HBM bytes per launch of `kernel`, source) from the committed rocprofv3 --pmc summary of THIS configuration
-    (profiles/rNN_pmc{,_c2,_c5}.json: separate FETCH_SIZE / WRITE_SIZE passes, KB units; the gfx950 x2 FETCH correction only
-    applies to 16 B/lane streams and is NOT applied to these dword-per-lane kernels) or (None, reason).  It is a COMMITTED
+    (profiles/rNN_pmc{,_c2,_c5}.json: separate FETCH_SIZE / WRITE_SIZE passes, KB units) or (None, reason).  The counters are
+    CORRECTED by the factors the box reports on known 16-byte-per-lane streams (fetch_calibration: the simulator moves its
+    vehicle state as 16-byte records since round 5, the update's kernels read 16 bytes per lane).  It is a COMMITTED
     measurement of an earlier run of this very command, not a counter read in this run; the counters average over whole
     episodes (tools/profile_round.sh) and the summary records the window-mean vehicles per instance of that run: a summary
     whose figure is more than 15 % away from this run's is REFUSED (the simulator's traffic scales with the vehicles)."""
@@ -54,6 +69,7 @@ def pmc_traffic(kernel, cfg_name, live):
     if suffix is None:
         return None, 'no committed PMC summary for this configuration'
     why = 'no committed PMC summary (profiles/%s_pmc%s.json)' % (PROFILE_TAGS[0], suffix)
+    ff, fw, fsrc = fetch_calibration()
     for tag in PROFILE_TAGS:
         try:
             d = json.load(open(os.path.join(ROOT, 'profiles', '%s_pmc%s.json' % (tag, suffix))))
@@ -65,10 +81,10 @@ def pmc_traffic(kernel, cfg_name, live):
             why = ('profiles/%s_pmc%s.json refused: collected at %.0f vehicles per instance, this run\'s window mean is %.0f '
                    '(more than 15 %% apart)' % (tag, suffix, v, live))
             continue
-        return (k['fetch_kb'] + k['write_kb']) * 1024.0, (
+        return (ff * k['fetch_kb'] + fw * k['write_kb']) * 1024.0, (
             'profiles/%s_pmc%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over whole episodes of this '
             'configuration, window mean %.0f vehicles per instance against %.0f in this run): committed measurement, not '
-            'collected in this run' % (tag, suffix, v, live or 0.0))
+            'collected in this run; FETCH_SIZE x %.3f, WRITE_SIZE x %.3f by %s' % (tag, suffix, v, live or 0.0, ff, fw, fsrc))
     return None, why
 
 
@@ -76,7 +92,7 @@ def rocprof_avg_us(kernel_key, cfg_name):
     """Average launch duration (us) of the kernel whose name contains `kernel_key` in the committed rocprofv3 --kernel-trace
     --stats summary of this configuration (profiles/rNN_kernel_stats{,_c2,_c5}.csv), or (None, None)."""
     import csv
-    suffix = {'c3': '', 'c2': '_c2', 'c5': '_c5'}.get(cfg_name)
+    suffix = {'c3': '', 'c2': '_c2', 'c5': '_c5', 'q1': '_q1'}.get(cfg_name)
     if suffix is None:
         return None, None
     for tag in PROFILE_TAGS:
@@ -126,7 +142,37 @@ def algorithmic_flops(model, rows):
             'dwo_gemm': 0.0}          # dWo = h^T dL is accumulated inside head_bwd (VALU); 'dwo_gemm' now times its slice reduction
 
 
-def cpu_baseline(n_env=48, n_step=120, threads=8):
+def iql_algorithmic_flops(model, rows):
+    """Per-launch ALGORITHMIC flops of the DeepQPolicy learner's kernels for `rows` rows per agent (agents/policies.py:343-371):
+    one net evaluation = n_wave x 128 + n_wait x 32 + H1 x 64 + 64 x n_a MACs per row (W1's structural zeros excluded);
+    'iql_grad' (one minibatch step) = Q(s') + Q(s) + the backward pass: dWq (64 x n_a), dX2 (64: dQ has ONE non-zero per row),
+    dW2 and dX1 (H1 x 64 each), dW1 (n_wave x 128 + n_wait x 32); 'iql_act' = one evaluation of the acting rows."""
+    lay = model.layout
+    fwd = sum(nw * lay.n_fc0 + nt * lay.ft + lay.H1 * lay.H2 + lay.H2 * na for nw, nt, na in zip(model.n_wave_ls, model.n_w_ls, model.n_a_ls))
+    bwd = sum(lay.H2 * na + lay.H2 + 2 * lay.H1 * lay.H2 + nw * lay.n_fc0 + nt * lay.ft for nw, nt, na in zip(model.n_wave_ls, model.n_w_ls, model.n_a_ls))
+    return {'iql_grad': 2.0 * (2 * fwd + bwd) * rows, 'iql_act': 2.0 * fwd * rows}
+
+
+def usable_cores():
+    """Cores this process may actually run on: the affinity mask, cut by a cgroup CPU quota when one is visible."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path, parse in (('/sys/fs/cgroup/cpu.max', lambda t: (lambda q, p_: None if q == 'max' else float(q) / float(p_))(*t.split()[:2])),
+                        ('/sys/fs/cgroup/cpu/cpu.cfs_quota_us', lambda t: None if int(t) <= 0 else int(t) / float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read()))):
+        try:
+            q = parse(open(path).read().strip())
+            if q:
+                cores = max(1, min(cores, int(q + 0.5)))
+            break
+        except Exception:
+            continue
+    return cores
+
+
+def cpu_baseline(n_env=48, n_step=120, threads=None):
     """Same iteration on the host: oracle/ (test infrastructure) = C microsim + NumPy restatement of
     envs/env.py + torch-CPU restatement of agents/policies.py.  Bounded sample: n_env env instances,
     one iteration (n_step control steps + update), run twice: with float32 nets (the reference's TensorFlow arithmetic:
@@ -138,7 +184,9 @@ def cpu_baseline(n_env=48, n_step=120, threads=8):
     import oracle.nets_oracle as nets
     from oracle.nets_oracle import OracleA2C, choice_from_uniform
     from deeprl_signal_control_amd.agents import ortho_init
-    torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))   # 128 threads on 64-wide matmuls is slower than 8
+    # every core the process may use (the figure used 8 of the 16 the box offered), at most 32: the nets are
+    # 64- to 224-wide matmuls on 48 x 25 rows, which stop scaling long before that
+    torch.set_num_threads(max(1, min(threads or usable_cores(), 32)))
     scn = build_large_grid('ma2c')
     nw = [s - w - f for s, w, f in zip(scn.n_s_ls, scn.n_w_ls, scn.n_f_ls)]
     S = scn.s_max
@@ -233,22 +281,8 @@ def sim_only_all_cores(scn, target_s=3.0):
     (oracle/microsim_worker.py), every process a share of the instances, one full episode each under a fixed signal cycle,
     released together; value = agents x instances x simulated seconds / wall time from the release to the last answer."""
     import subprocess
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
     # a container usually sees every core of the host but may only run on a quota of them: one process per core it can USE
-    for path, parse in (('/sys/fs/cgroup/cpu.max', lambda t: (lambda q, p_: None if q == 'max' else float(q) / float(p_))(*t.split()[:2])),
-                        ('/sys/fs/cgroup/cpu/cpu.cfs_quota_us', lambda t: None if int(t) <= 0 else int(t) / float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read()))):
-        try:
-            q = parse(open(path).read().strip())
-            if q:
-                cores = max(1, min(cores, int(q + 0.5)))
-            break
-        except Exception:
-            continue
-    cores = min(cores, 32)           # (a 256-thread GPU host ran 256 workers at the speed of ~9 cores: the quota is not always visible)
+    cores = min(usable_cores(), 32)           # (a 256-thread GPU host ran 256 workers at the speed of ~9 cores: the quota is not always visible)
     per = max(1, int(target_s / 0.06))                     # one episode is ~0.04-0.07 s of one core
     procs = []
     try:
@@ -457,7 +491,7 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
         # 160 MB of dirty lines, add ~17 us to the simulator step's figure; 98 against 80 us by rocprofv3), so the kernels
         # that alternate once per control step are bracketed in passes of their own: the simulator step alone, the other
         # per-control-step kernels (the rollout forward) alone, then the update's kernels together (tsc_profile_select).
-        per_step = ('env_step', 'policy_fwd_fused', 'add_transition', 'fingerprint', 'sample')
+        per_step = ('env_step', 'policy_fwd_fused', 'add_transition', 'fingerprint', 'sample', 'iql_act', 'iql_add')
         names = _lib.profile_names()
         passes = [['env_step'], [n for n in per_step if n != 'env_step'], [n for n in names if n not in per_step]]
         dt_prof, live_prof = 0.0, None
@@ -480,6 +514,9 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
     if rank == 0 and world == 1 and B == 1 and want_extra and not is_q:
         extra = extra_lines(env, model, scn)
     ranks = rank_table(rank, world, local, args.backend)          # collective: every rank
+    if world > 1 and args.backend == 'nccl' and ranks['distinct_devices'] < world:
+        # an RCCL line is a claim about N GPUs: ranks that share a device (a wrong LOCAL_RANK / visibility mask) void it
+        raise SystemExit('bench.py: --backend nccl with %d ranks on %d distinct devices: %r' % (world, ranks['distinct_devices'], ranks['ranks']))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda')
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -497,19 +534,48 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
                                        '(x%d sim-steps) of every instance into the replay rings + 10 minibatch steps (%d transitions per '
                                        'instance and agent each: TD loss, clip, Adam%s)'
                                        % ('large_grid 5x5', scn.n_agent, agent.upper(), policy.upper(), E, n_step, ctrl, n_step,
-                                          ', RCCL grad all-reduce' if world > 1 else '')) if is_q else
+                                          (', RCCL grad all-reduce' if args.backend == 'nccl' else ', gloo grad all-reduce') if world > 1 else '')) if is_q else
                                       '%s (%d agents), %s %s policy%s, %d env instances per GPU; step = %d control steps '
                                       '(x%d sim-steps) of every instance + 1 A2C update (%sclip, RMSProp%s)'
                                       % ('large_grid 5x5' if scenario == 'large_grid' else 'real_net Monaco', scn.n_agent,
                                          agent.upper(), policy.upper(),
                                          ' (neighbour fingerprint gather)' if agent == 'ma2c' else '', E, n_step, ctrl,
-                                         'BPTT, ' if policy == 'lstm' else '', ', RCCL grad all-reduce' if world > 1 else ''),
+                                         'BPTT, ' if policy == 'lstm' else '', (', RCCL grad all-reduce' if args.backend == 'nccl' else ', gloo grad all-reduce') if world > 1 else ''),
                           'envs_per_gpu': E, 'n_step': n_step, 'agents': scn.n_agent,
                           'parallelism': 'env-sharded x%d%s' % (world, ', %d half-batches on separate streams' % B if B > 1 else ''),
                           'mean_live_vehicles_per_env': live, 'live_vehicles': 'window mean over the timed region',
                           'mean_step_reward': msr}}
-        if prof and is_q:                   # the Q learner's kernels are the grouped GEMM + small elementwise kernels: table only
-            out['kernels'] = {k: {'ms_total': round(v[0], 3), 'launches': v[1]} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+        if prof and is_q:
+            # the Q learner: one fused kernel per minibatch step (csrc/tsc_iql_fused.h) dominates; its roofline is the f32 MFMA peak
+            total = sum(ms for ms, _ in prof.values())
+            kern = {k: {'ms_total': round(v[0], 3), 'launches': v[1]} for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+            out['kernels'] = kern
+            if getattr(model, 'fused', False) and 'iql_grad' in prof:
+                fl = iql_algorithmic_flops(model, E * n_step)['iql_grad']
+                for k, rows_ in (('iql_grad', E * n_step), ('iql_act', E)):
+                    if k in kern:
+                        avg = kern[k]['ms_total'] / kern[k]['launches'] * 1e-3
+                        kern[k]['frac_mfma'] = round(iql_algorithmic_flops(model, rows_)[k] / avg / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+                ms, cnt = prof['iql_grad']
+                ach = fl / (ms / cnt * 1e-3) / 1e12
+                roof = {'bound': 'mfma', 'kernel': 'iql_grad', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                        'traffic_source': 'not collected: the kernel reads two 144-B observation rows per transition and writes its partial gradient once',
+                        'algorithmic': '%.1f kFLOP per row and agent on average (two evaluations of the Q net + its backward pass, structural zeros '
+                                       'of the block-diagonal first layer excluded; bench.py:iql_algorithmic_flops) x %d rows x %d agents'
+                                       % (fl / (E * n_step) / scn.n_agent / 1e3, E * n_step, scn.n_agent),
+                        'avg_launch_ms': ms / cnt, 'share_of_kernel_time': ms / total, 'kernel_time_ms_total': total,
+                        'timed': 'HIP events on the launch stream around every launch of one group of kernels at a time, in passes of %d '
+                                 'iterations right after the timed region (which carries no events)' % psteps}
+                us, src = rocprof_avg_us('iql_fused_grad_kernel', cfg_name)
+                if us:
+                    roof['rocprofv3_avg_launch_ms'] = us * 1e-3
+                    roof['rocprofv3_source'] = src + ' (committed rocprofv3 --kernel-trace --stats run of this command, not this run)'
+                if 'env_step' in kern:
+                    avg = kern['env_step']['ms_total'] / kern['env_step']['launches'] * 1e-3
+                    alg = (32.0 * live_prof + 16.0 * scn.n_lane + scn.n_agent * 52.0 / 5.0) * ctrl * E
+                    kern['env_step']['frac_hbm'] = round(alg / avg / 1e9 / PEAK_HBM_GBS, 4)
+                out['roofline'] = roof
         elif prof:
             total = sum(ms for ms, _ in prof.values())
             # which kernel dominates: by event totals -- except that the simulator step's event figure carries the launch boundary
@@ -518,8 +584,18 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
             # rocprofv3 average of this configuration's step kernel, when there is one; every reported figure stays the event's.
             rank = {k: v[0] for k, v in prof.items()}
             us_rp, _ = rocprof_avg_us('step_kernel', cfg_name)
+            cap = {'applied': False}
             if us_rp and 'env_step' in rank:
-                rank['env_step'] = min(rank['env_step'], 1.1 * us_rp * 1e-3 * prof['env_step'][1])
+                live_us = 1e3 * prof['env_step'][0] / prof['env_step'][1]
+                if live_us > 1.35 * us_rp:
+                    # the boundary explains ~3 - 17 us, not this: a live figure far above the committed one is a regression (or a stale
+                    # profile) and must be able to make the simulator step the dominant kernel
+                    cap['refused'] = 'live %.1f us per launch is more than 1.35 x the committed %.1f us' % (live_us, us_rp)
+                elif 1.1 * us_rp < live_us:
+                    uncapped_dom = max(rank, key=lambda k: rank[k])
+                    rank['env_step'] = 1.1 * us_rp * 1e-3 * prof['env_step'][1]
+                    cap = {'applied': True, 'env_step_us_live': live_us, 'env_step_us_ranked': 1.1 * us_rp,
+                           'dominant_uncapped': uncapped_dom, 'changed_ranking': uncapped_dom != max(rank, key=lambda k: rank[k])}
             dom = max(rank, key=lambda k: rank[k])
             ms, cnt = prof[dom]
             avg_s = ms / cnt * 1e-3
@@ -578,6 +654,7 @@ def run_config(args, rank, world, local, scenario, agent, policy, E, steps, warm
             roof['mean_live_vehicles_per_env'] = live_prof
             roof['dominant_by'] = ('largest total of the HIP-event passes; the simulator step enters the ranking with at most 1.1 x its committed '
                                    'rocprofv3 average per launch (its event figure includes the launch boundary behind the forward)')
+            roof['dominant_cap'] = cap
             roof['avg_launch_ms'] = ms / cnt
             roof['share_of_kernel_time'] = ms / total
             roof['kernel_time_ms_total'] = total
@@ -668,9 +745,14 @@ def main():
         out.setdefault('extra', {})['configs'] = cfgs
         # the next row of SURVEY 8(f): the IQL-DNN learner on the same env path (config/config_iqld_large.ini), same method
         o = run_config(args, rank, world, local, *PRESETS['q1'], 2 * iterations_per_episode('large_grid', 'iqld'),
-                       warmup_iterations(iterations_per_episode('large_grid', 'iqld')), want_extra=False, want_cpu=False, want_profile=False)
+                       warmup_iterations(iterations_per_episode('large_grid', 'iqld')), want_extra=False, want_cpu=False,
+                       want_profile=not args.no_profile)
         out['extra']['iql'] = {'workload': o['config']['workload'], 'value': o['value'], 'unit': o['unit'], 'ms_per_step': o['ms_per_step'],
                                'steps': o['steps'], 'warmup': o['warmup'], 'mean_live_vehicles_per_env': o['config']['mean_live_vehicles_per_env']}
+        if 'roofline' in o:
+            out['extra']['iql']['roofline'] = {k: o['roofline'][k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms',
+                                                                              'share_of_kernel_time', 'algorithmic')}
+            out['extra']['iql']['kernels'] = o['kernels']
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

@@ -34,8 +34,19 @@ def build(force=False, verbose=False):
     if not force and not stale():
         return LIB
     extra = os.environ.get('TSC_BUILD_DEFS', '').split()          # measurement builds, e.g. TSC_BUILD_DEFS=-DTSC_STREAM_SC1=1
-    objdir = os.path.join(HERE, '_obj')
-    os.makedirs(objdir, exist_ok=True)
+    # object files of THIS build only (two concurrent force builds -- ranks, pytest workers -- wrote the same
+    # _obj/<name>.o and could link a torn object): a per-process directory, removed after linking
+    import shutil
+    import tempfile
+    os.makedirs(os.path.join(HERE, '_obj'), exist_ok=True)
+    objdir = tempfile.mkdtemp(prefix='build%d_' % os.getpid(), dir=os.path.join(HERE, '_obj'))
+    try:
+        return _build_in(objdir, extra, verbose)
+    finally:
+        shutil.rmtree(objdir, ignore_errors=True)
+
+
+def _build_in(objdir, extra, verbose):
     cflags = [f for f in FLAGS if f != '-shared'] + extra + ['-I', os.path.join(HERE, '..', 'include')]
     jobs = []
     for src in sources():

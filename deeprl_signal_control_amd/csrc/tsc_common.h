@@ -58,7 +58,8 @@ inline hipError_t upload(T **dst, const T *src, size_t count) {
 enum KernelId : int {
     KID_ENV_STEP = 0, KID_FC_GEMM, KID_ZX_GEMM, KID_LSTM_FWD, KID_HEAD_FWD, KID_SAMPLE, KID_ADD_TRANS,
     KID_RETURNS, KID_HEAD_BWD, KID_LSTM_BWD, KID_DWO_GEMM, KID_DWH_GEMM, KID_DWX_GEMM, KID_DX1_GEMM,
-    KID_DW1_GEMM, KID_GRADNORM, KID_RMSPROP, KID_TRANSPOSE, KID_FINGERPRINT, KID_FUSED_FWD, KID_COUNT
+    KID_DW1_GEMM, KID_GRADNORM, KID_RMSPROP, KID_TRANSPOSE, KID_FINGERPRINT, KID_FUSED_FWD,
+    KID_IQL_ACT, KID_IQL_GRAD, KID_IQL_REDUCE, KID_IQL_SAMPLE, KID_IQL_ADD, KID_IQL_ADAM, KID_COUNT
 };
 
 struct ProfState {
@@ -80,7 +81,7 @@ struct ProfScope {
         ProfState &p = prof();
         if (!p.on) return;
         const bool per_step = id == KID_ENV_STEP || id == KID_FUSED_FWD || id == KID_ADD_TRANS || id == KID_FINGERPRINT ||
-                              id == KID_SAMPLE;
+                              id == KID_SAMPLE || id == KID_IQL_ACT || id == KID_IQL_ADD;
         if (p.seq[id]++ % (per_step ? p.stride : 1) != 0) return;
         if (!((p.only >> id) & 1ull)) return;
         auto get = [&]() { hipEvent_t e; if (!p.pool.empty()) { e = p.pool.back(); p.pool.pop_back(); } else { (void)hipEventCreate(&e); } return e; };

@@ -1262,7 +1262,9 @@ int tsc_profile_read(int32_t kernel_id, double *total_ms, int64_t *count) {
 const char *tsc_profile_name(int32_t id) {
     static const char *names[] = {"env_step", "fc_gemm", "zx_gemm", "lstm_fwd", "head_fwd", "sample", "add_transition",
                                   "returns", "head_bwd", "lstm_bwd", "dwo_gemm", "dwh_gemm", "dwx_gemm", "dx1_gemm",
-                                  "dw1_gemm", "grad_norm", "rmsprop", "transpose_wx", "fingerprint", "policy_fwd_fused"};
+                                  "dw1_gemm", "grad_norm", "rmsprop", "transpose_wx", "fingerprint", "policy_fwd_fused",
+                                  "iql_act", "iql_grad", "iql_reduce", "iql_sample", "iql_add", "iql_adam"};
+    static_assert(sizeof(names) / sizeof(names[0]) == tsc::KID_COUNT, "one name per kernel id");
     return (id >= 0 && id < tsc::KID_COUNT) ? names[id] : "";
 }
 

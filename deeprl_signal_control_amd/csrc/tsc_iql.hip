@@ -472,6 +472,7 @@ int tsc_iql_forward(tsc_iql *h, const float *obs, float *q_out, int32_t *action,
     if (h->fused) {
         QFusedArgs fa = fused_args(h, 0);
         const unsigned grid = (unsigned)(L.A * ((h->E + 63) / 64));
+        tsc::ProfScope ps(tsc::KID_IQL_ACT, h->stream);
         if (h->fused == 10)
             hipLaunchKernelGGL((iql_fused_act_kernel<10, 8>), dim3(grid), dim3(256), QFusedLds<10>::fwd_floats * 4, h->stream, fa, obs, (int)mode,
                                eps, (unsigned long long)seed, (unsigned long long)step, L.AMAX, h->Qe, q_out, action);
@@ -495,6 +496,7 @@ int tsc_iql_add_transition(tsc_iql *h, const float *obs, const int32_t *action, 
     if (!h || !obs || !action || !reward || !next_obs || !done) return tsc::fail("tsc_iql_add_transition: bad arguments");
     const QLayout &L = h->lay;
     const long long n = (long long)h->E * L.A * L.SMAX;
+    tsc::ProfScope ps(tsc::KID_IQL_ADD, h->stream);
     hipLaunchKernelGGL(iql_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->E, L.A, L.SMAX, h->cap,
                        h->cum % h->cap, obs, action, reward, next_obs, done, h->rnorm, h->rclip, h->r_obs, h->r_next, h->r_act,
                        h->r_rew, h->r_done);
@@ -531,17 +533,22 @@ static int iql_compute_grads(tsc_iql *h, uint64_t seed, uint64_t update_index, c
     if (idx_dev) {      // the caller's draw (e.g. the reference's random.sample); the gather clamps every index into [0, size)
         TSC_HIP(hipMemcpyAsync(h->idx, idx_dev, sizeof(int) * E * A * h->B, hipMemcpyDeviceToDevice, st));
     } else {
+        tsc::ProfScope ps(tsc::KID_IQL_SAMPLE, st);
         hipLaunchKernelGGL(iql_sample_kernel, dim3((unsigned)((E * A + 127) / 128)), dim3(128), 0, st, (int)E, (int)A, h->B, size,
                            (unsigned long long)seed, (unsigned long long)update_index, h->idx);
     }
     if (h->fused) {
         QFusedArgs fa = fused_args(h, size);
         const unsigned grid = (unsigned)(A * h->fS);
-        if (h->fused == 10)
-            hipLaunchKernelGGL((iql_fused_grad_kernel<10, 8>), dim3(grid), dim3(256), QFusedLds<10>::grad_floats * 4, st, fa);
-        else
-            hipLaunchKernelGGL((iql_fused_grad_kernel<8, 8>), dim3(grid), dim3(256), QFusedLds<8>::grad_floats * 4, st, fa);
+        {
+            tsc::ProfScope ps(tsc::KID_IQL_GRAD, st);
+            if (h->fused == 10)
+                hipLaunchKernelGGL((iql_fused_grad_kernel<10, 8>), dim3(grid), dim3(256), QFusedLds<10>::grad_floats * 4, st, fa);
+            else
+                hipLaunchKernelGGL((iql_fused_grad_kernel<8, 8>), dim3(grid), dim3(256), QFusedLds<8>::grad_floats * 4, st, fa);
+        }
         TSC_HIP(hipGetLastError());
+        tsc::ProfScope ps(tsc::KID_IQL_REDUCE, st);
         hipLaunchKernelGGL(iql_fused_reduce_kernel, dim3((unsigned)((L.stride + 255) / 256), (unsigned)A), dim3(256), 0, st, h->fws, h->fwsl,
                            (int)A, h->fS, L.stride, L.ob1, L.H1, h->rowrange, L.SMAX, h->grads, h->stats);
         TSC_HIP(hipGetLastError());
@@ -595,12 +602,14 @@ int tsc_iql_apply_grads(tsc_iql *h, double lr, double grad_scale, double *stats_
     if (!h) return tsc::fail("null handle");
     const QLayout &L = h->lay;
     hipStream_t st = h->stream;
+    tsc::ProfScope ps(tsc::KID_IQL_ADAM, st);          // norm + Adam
     hipLaunchKernelGGL(iql_norm_kernel, dim3(L.A), dim3(256), 0, st, h->grads, L.stride, grad_scale, h->norm2);
     h->adam_t += 1;
     const double lr_t = lr * sqrt(1.0 - pow(0.999, (double)h->adam_t)) / (1.0 - pow(0.9, (double)h->adam_t));
     hipLaunchKernelGGL(iql_adam_kernel, dim3((unsigned)((h->nparam + 255) / 256)), dim3(256), 0, st, h->params, h->m1, h->m2, h->grads,
                        L.stride, h->nparam, h->norm2, (float)grad_scale, (float)h->max_norm, (float)lr_t);
     TSC_HIP(hipGetLastError());
+    ps.stop();
     if (stats_host) {
         std::vector<double> s(L.A * 2), n2(L.A);
         TSC_HIP(hipStreamSynchronize(st));

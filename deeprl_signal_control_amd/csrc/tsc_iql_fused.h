@@ -525,7 +525,6 @@ template <int NM1, int NMW>
 __global__ void __launch_bounds__(256, 1) iql_fused_act_kernel(QFusedArgs p, const float *__restrict__ obs, int mode, double eps,
                                                                unsigned long long seed, unsigned long long step, int AMAX,
                                                                float *__restrict__ Qe, float *__restrict__ q_out, int *__restrict__ action) {
-    using LD = QFusedLds<NM1>;
     extern __shared__ __attribute__((aligned(16))) float q_smem[];
     float *sm = q_smem;
     const int a = blockIdx.x % p.A, blk = blockIdx.x / p.A;

@@ -115,3 +115,31 @@ def test_monaco_greedy_eval_tables_vs_published():
     assert 0.65 * pub['avg_speed_mps'] < ours['avg_speed_mps'] < pub['avg_speed_mps']     # still slower than SUMO's 6.06 m/s
     assert 0.6 * pub['avg_wait_sec'] < ours['avg_wait_sec'] < 1.2 * pub['avg_wait_sec']
     assert pub['trips'] < ours['trips'] < 1.25 * pub['trips']        # today's flow table demands 2383 vehicles, the published run inserted ~2150
+
+
+def test_junction_box_experiment_blocks_foe_links():
+    """the junction-interior experiment of round 4 (oracle/microsim.c ms_set_box, OFF in the spec; DESIGN.md 3
+    "junction interiors", tools/sweep_junction_box.py -> profiles/r04_junction_box_sweep.json) has a producer (a head that enters a
+    full junction sets its link's bit in blocked[]) AND a consumer (a head whose link has a foe among the blocked ones holds):
+    with p = 1 vehicles stand in junctions (n_box > 0) and the run differs from p = 0; p = 0 is the spec, bit for bit."""
+    from oracle.env_oracle import OracleEnv, greedy_large_grid
+    scn = build_large_grid('greedy', norm_wave=1.0, norm_wait=1.0, clip_wave=-1.0, clip_wait=-1.0, episode_length_sec=1500)
+
+    def run(p):
+        env = OracleEnv(scn, seed=10000, train_mode=False, test_seeds=(10000,))
+        ob = env.reset(0)
+        if p is not None:
+            env.ms.set_box(p)
+        rs = []
+        while True:
+            ob, r, done, g = env.step([greedy_large_grid(o[:6]) for o in ob])
+            rs.append(g)
+            if done:
+                break
+        return np.array(rs), int(env.ms.L.ms_box_count(env.ms.h))
+    r_spec, n_spec = run(None)
+    r0, n0 = run(0.0)
+    r1, n1 = run(1.0)
+    assert n_spec == 0 and n0 == 0 and np.array_equal(r_spec, r0)
+    assert n1 > 0 and not np.array_equal(r1, r0)
+    assert r1.sum() < r0.sum()          # blocked approaches cost reward

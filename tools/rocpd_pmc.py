@@ -13,7 +13,7 @@ import json
 import sqlite3
 import sys
 
-NAMES = [('step_kernel', 'env_step'), ('fc_bwd_reduce', 'dw1_gemm'), ('fc_bwd_kernel', 'dx1_gemm'), ('policy_fwd_fc_mfma', 'policy_fwd_fused'), ('head_bwd2_reduce', 'dwo_gemm'), ('head_bwd2', 'head_bwd'), ('register_order', 'register_order'),
+NAMES = [('step_kernel', 'env_step'), ('iql_fused_grad', 'iql_grad'), ('iql_fused_act', 'iql_act'), ('iql_fused_reduce', 'iql_reduce'), ('fc_bwd_reduce', 'dw1_gemm'), ('fc_bwd_kernel', 'dx1_gemm'), ('policy_fwd_fc_mfma', 'policy_fwd_fused'), ('head_bwd2_reduce', 'dwo_gemm'), ('head_bwd2', 'head_bwd'), ('register_order', 'register_order'),
          ('grad_norm_fold', 'grad_norm'), ('policy_fwd_fused', 'policy_fwd_fused'), ('policy_fwd_ws', 'policy_fwd_fused'), ('dwxh_kernel', 'dwx_gemm'),
          ('dx1w1_kernel', 'dx1_gemm'), ('lstm_bwd', 'lstm_bwd'), ('lstm_fwd', 'lstm_fwd'), ('head_bwd', 'head_bwd'),
          ('head_fwd', 'head_fwd'), ('add_transition', 'add_transition'), ('dwxh_reduce', 'dwh_gemm'),
