@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libtsc.so')
+# TSC_LIB: a measurement build of the same sources (tools/build_variant.sh: libtsc_<name>.so next to the library), A/B runs only
+LIB_PATH = os.environ.get('TSC_LIB') or os.path.join(HERE, 'libtsc.so')
 
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int32)
@@ -52,7 +53,7 @@ SYMBOLS = ['tsc_last_error', 'tsc_version', 'tsc_profile_enable', 'tsc_profile_s
            'tsc_gemm_grouped_f32',
            'tsc_iql_create', 'tsc_iql_destroy', 'tsc_iql_set_stream', 'tsc_iql_layout', 'tsc_iql_set_params', 'tsc_iql_get_params',
            'tsc_iql_get_opt_state', 'tsc_iql_set_opt_state', 'tsc_iql_forward', 'tsc_iql_add_transition', 'tsc_iql_replay_size',
-           'tsc_iql_compute_grads', 'tsc_iql_compute_grads_at', 'tsc_iql_grad_buffer', 'tsc_iql_apply_grads', 'tsc_iql_debug_batch', 'tsc_iql_path']
+           'tsc_iql_compute_grads', 'tsc_iql_compute_grads_at', 'tsc_iql_grad_buffer', 'tsc_iql_apply_grads', 'tsc_iql_debug_batch', 'tsc_iql_path', 'tsc_iql_debug_clock']
 
 
 def lib():

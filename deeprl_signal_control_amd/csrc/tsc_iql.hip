@@ -262,6 +262,7 @@ struct tsc_iql {
     int fused, fS, fcps;
     int *n_wave, *n_wait;
     float *fws, *fwsl;
+    long long *dbg;
 };
 
 namespace {
@@ -300,6 +301,7 @@ QFusedArgs fused_args(const tsc_iql *h, long long size) {
     fa.r_obs = h->r_obs; fa.r_next = h->r_next; fa.r_rew = h->r_rew; fa.r_act = h->r_act; fa.r_done = h->r_done;
     fa.E = h->E; fa.A = L.A; fa.B = h->B; fa.SMAX = L.SMAX; fa.size = (int)size; fa.cap = h->cap; fa.R = (long long)h->E * h->B;
     fa.gamma = (float)h->gamma; fa.S = h->fS; fa.cps = h->fcps; fa.ws = h->fws; fa.wsl = h->fwsl;
+    fa.dbg = h->dbg;
     fa.stride = L.stride; fa.oW1 = L.oW1; fa.ob1 = L.ob1; fa.oW2 = L.oW2; fa.ob2 = L.ob2; fa.oWq = L.oWq; fa.obq = L.obq;
     return fa;
 }
@@ -367,14 +369,22 @@ int tsc_iql_create(const tsc_iql_cfg *cfg, int32_t n_env, int32_t device, tsc_iq
     // The fused DeepQPolicy learner (tsc_iql_fused.h) is built for the reference's widths (config/config_iqld_*.ini: num_fc 128,
     // num_h 64 -> H1 = 160 with wait inputs, 128 without) and observations of at most 48 features; anything else, IQL-LR, and
     // TSC_IQL_FUSED=0 (the A/B switch of tests/test_iql_gpu.py) take the grouped-GEMM path.
-    h->fused = 0; h->fS = h->fcps = 0; h->fws = h->fwsl = nullptr;
+    h->fused = 0; h->fS = h->fcps = 0; h->fws = h->fwsl = nullptr; h->dbg = nullptr;
     TSC_HIP(tsc::upload<int>(&h->n_wave, cfg->n_wave, L.A)); h->allocs.push_back(h->n_wave);
     TSC_HIP(tsc::upload<int>(&h->n_wait, cfg->n_wait, L.A)); h->allocs.push_back(h->n_wait);
     {
         const char *sw = getenv("TSC_IQL_FUSED");
         const bool want = !(sw && sw[0] == '0');
-        if (want && L.dqn && cfg->n_fc0 == 128 && L.H2 == kFH2 && L.SMAX <= kFSF && (L.H1 == 128 || L.H1 == 160)) h->fused = L.H1 / 16;
+        int max_wave = 0, max_wait = 0;
+        for (int a = 0; a < L.A; ++a) {
+            max_wave = cfg->n_wave[a] > max_wave ? cfg->n_wave[a] : max_wave;
+            max_wait = cfg->n_wait[a] > max_wait ? cfg->n_wait[a] : max_wait;
+        }
+        // with a wait part the kernel keeps two 16-feature groups of W1 per column tile in registers (tsc_iql_fused.h QW1)
+        const bool fits = L.H1 == 128 || (L.H1 == 160 && max_wave <= 32 && max_wait <= 16);
+        if (want && L.dqn && cfg->n_fc0 == 128 && L.H2 == kFH2 && L.SMAX <= kFSF && fits) h->fused = L.H1 / 16;
     }
+    if (h->fused && R >= ((long long)1 << 31) / 64) h->fused = 0;       // the fused kernel indexes rows and chunks in 32 bits
     if (h->fused) {
         // row splits per agent: one workgroup per CU (the kernel holds its gradient tiles in registers over its whole slice)
         const long long nchunks = (R + 63) / 64;
@@ -617,6 +627,21 @@ int tsc_iql_apply_grads(tsc_iql *h, double lr, double grad_scale, double *stats_
         TSC_HIP(hipMemcpy(n2.data(), h->norm2, sizeof(double) * L.A, hipMemcpyDeviceToHost));
         for (int a = 0; a < L.A; ++a) { stats_host[a * 2] = s[a * 2]; stats_host[a * 2 + 1] = sqrt(n2[a]); }
     }
+    return 0;
+}
+
+int tsc_iql_debug_clock(tsc_iql *h, int32_t enable, int64_t *stamps_host, int32_t count) {
+    if (!h) return tsc::fail("null handle");
+    if (!h->fused) return tsc::fail("tsc_iql_debug_clock: only the fused learner carries clock stamps");
+    TSC_HIP(hipStreamSynchronize(h->stream));
+    const size_t n = 64 + 2 * (size_t)h->lay.A * h->fS;
+    if (enable && !h->dbg) {
+        TSC_HIP(hipMalloc((void **)&h->dbg, n * sizeof(long long)));
+        TSC_HIP(hipMemset(h->dbg, 0, n * sizeof(long long)));
+        h->allocs.push_back(h->dbg);
+    }
+    if (stamps_host && h->dbg)
+        TSC_HIP(hipMemcpy(stamps_host, h->dbg, sizeof(long long) * ((size_t)count < n ? (size_t)count : n), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -22,6 +22,11 @@
 //     (deterministic), applies W1's block-diagonal mask and sums the loss.
 // Arithmetic: fp32 MFMA (exact f32 products, f32 accumulate) -- the same numbers as the grouped-GEMM path up to summation order.
 #pragma once
+#include <type_traits>
+
+#ifndef TSC_IQL_SCHED
+#define TSC_IQL_SCHED 1        // bit 0: pin the operand fetches of the second layer ahead of its MFMAs; 1: phase B; 2: phase D
+#endif
 
 namespace {
 
@@ -44,6 +49,7 @@ struct QFusedArgs {
     int S, cps;                   // row splits per agent; 64-row chunks per split
     float *ws, *wsl;              // partial gradients [S][A][stride]; partial losses [S][A]
     long long stride, oW1, ob1, oW2, ob2, oWq, obq;
+    long long *dbg;               // tsc_iql_debug_clock: [64] phase stamps of workgroup 0 (16 per wavefront, chunk 2) | [2 x workgroups] start / end (100 MHz)
 };
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -99,92 +105,179 @@ __device__ __forceinline__ QRanges q_ranges(int nw, int nt) {
 // one agent's nets on 16 rows of this wavefront: lane = (row n = lane & 15, kq = lane >> 4)
 //   s[q] = obs[row][16 q + 4 kq .. + 3];  w1[t][q][c] = W1[16 q + 4 kq + c][16 t + m]  (m = lane & 15 as the A operand's row)
 //   X1[t][i] = relu(.)[feature 16 t + 4 kq + i][row n], X2 likewise, q[i] = Q[action 4 kq + i][row n] (kq < 2)
+// stationary first-layer operands of one lane: the wave part's columns x the 16-feature groups they can read (three without a wait
+// part: up to 48 wave features; two with one: the host admits n_wave <= 32 there), the wait part's columns x the (at most two)
+// groups [qt0, qt0 + 2) its features [n_wave, n_wave + n_wait <= 16) fall into
 template <int NM1, int NMW>
-__device__ __forceinline__ void q_nets(const float (&w1)[NM1][3][4], const float4 (&s)[3], const float *sm, const QRanges &rg, int m, int kq,
-                                       f32x4 (&X1)[NM1], f32x4 (&X2)[4], f32x4 &q) {
+struct QW1 {
+    static constexpr int QW = NM1 > NMW ? 2 : 3, NT = NM1 > NMW ? NM1 - NMW : 1;
+    float w[NMW][QW][4];
+    float t[NT][2][4];
+};
+
+template <int NB, int NM1, int NMW>
+__device__ __forceinline__ void q_nets(const QW1<NM1, NMW> &w1, const float4 (&s)[NB][3], const float *sm, const QRanges &rg, int m, int kq,
+                                       f32x4 (&X1)[NB][NM1], f32x4 (&X2)[NB][4], f32x4 (&q)[NB], long long *fst = nullptr) {
+    // NB independent row sets (the gradient kernel's s' and s) go through every layer side by side: one weight operand feeds NB
+    // MFMAs, and the relu / bias work of one set sits under the MFMAs of the other instead of at a serialising layer boundary
     using LD = QFusedLds<NM1>;
+    using W = QW1<NM1, NMW>;
     constexpr int H1 = LD::H1;
     const float *Bs = sm + LD::oB;
 #pragma unroll
     for (int t = 0; t < NM1; ++t) {
         const float4 b = *reinterpret_cast<const float4 *>(Bs + 16 * t + 4 * kq);
-        X1[t] = f32x4{b.x, b.y, b.z, b.w};
-    }
 #pragma unroll
-    for (int qp = 0; qp < 3; ++qp) {
-        const float sv[4] = {s[qp].x, s[qp].y, s[qp].z, s[qp].w};
-        if (qp < rg.qw1) {
+        for (int b_ = 0; b_ < NB; ++b_) X1[b_][t] = f32x4{b.x, b.y, b.z, b.w};
+    }
+    // the observation groups as plain values: with the loads visible the compiler folds the wait part's wavefront-uniform choice of a
+    // group (below) into an indexed load, which sends the caller's row buffers to scratch
+    float so[NB][3][4];
+#pragma unroll
+    for (int b_ = 0; b_ < NB; ++b_)
+#pragma unroll
+        for (int qp = 0; qp < 3; ++qp) {
+            so[b_][qp][0] = s[b_][qp].x; so[b_][qp][1] = s[b_][qp].y; so[b_][qp][2] = s[b_][qp].z; so[b_][qp][3] = s[b_][qp].w;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) asm("" : "+v"(so[b_][qp][c]));
+        }
+    // No branch on the agent's group counts: W1 holds structural zeros outside an agent's wave / wait rows and the observation is
+    // zero-padded, so the groups an agent does not use contribute exact zeros -- and a wavefront-uniform branch around a block of MFMAs
+    // makes the compiler shuttle every accumulator between the AGPR and VGPR files at the block's edges (measured: 49 instead of 32
+    // cycles per MFMA over this layer).
+#pragma unroll
+    for (int qp = 0; qp < W::QW; ++qp)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < NMW; ++t)
+#pragma unroll
+                for (int b_ = 0; b_ < NB; ++b_) X1[b_][t] = mfma16(w1.w[t][qp][c], so[b_][qp][c], X1[b_][t]);
+    if (NM1 > NMW) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const int qp = rg.qt0 + qq;                            // wavefront-uniform; qt0 + 1 <= 2 (n_wave <= 32)
+            float sv[NB][4];
+#pragma unroll
+            for (int b_ = 0; b_ < NB; ++b_)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sv[b_][c] = qp == 0 ? so[b_][0][c] : qp == 1 ? so[b_][1][c] : so[b_][2][c];
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int t = 0; t < NMW; ++t) X1[t] = mfma16(w1[t][qp][c], sv[c], X1[t]);
-        }
-        if (NM1 > NMW && qp >= rg.qt0 && qp < rg.qt1) {
+                for (int t = NMW; t < NM1; ++t)
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int t = NMW; t < NM1; ++t) X1[t] = mfma16(w1[t][qp][c], sv[c], X1[t]);
+                    for (int b_ = 0; b_ < NB; ++b_) X1[b_][t] = mfma16(w1.t[t - NMW][qq][c], sv[b_][c], X1[b_][t]);
         }
     }
+#ifdef TSC_IQL_FINE
+    if (fst) fst[11] = clock64();
+#endif
 #pragma unroll
-    for (int t = 0; t < NM1; ++t)
+    for (int b_ = 0; b_ < NB; ++b_)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) X1[t][i] = X1[t][i] > 0.f ? X1[t][i] : 0.f;
+        for (int t = 0; t < NM1; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) X1[b_][t][i] = X1[b_][t][i] > 0.f ? X1[b_][t][i] : 0.f;
+#ifdef TSC_IQL_FINE
+    if (fst) fst[12] = clock64();
+#endif
     // second layer: A = W2[k = 16 kt + 4 kq + i][out 16 t2 + m] from LDS (consecutive lanes, consecutive banks), B = X1[kt][i]
 #pragma unroll
     for (int t2 = 0; t2 < 4; ++t2) {
         const float4 b = *reinterpret_cast<const float4 *>(Bs + H1 + 16 * t2 + 4 * kq);
-        X2[t2] = f32x4{b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int b_ = 0; b_ < NB; ++b_) X2[b_][t2] = f32x4{b.x, b.y, b.z, b.w};
     }
     const float *W2s = sm + LD::oW2 + 4 * kq * kFLd + m;
+    // the 16 weight operands of k-tile kt + 1 are requested before the MFMAs of k-tile kt are issued (the compiler, left alone,
+    // put every ds_read right in front of its two MFMAs with lgkmcnt(0))
+    float wa[2][16];
+    auto fetch = [&](int kt, float (&w)[16]) {
 #pragma unroll
-    for (int kt = 0; kt < NM1; ++kt)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float *wr = W2s + (16 * kt + i) * kFLd;
+            for (int t2 = 0; t2 < 4; ++t2) w[4 * i + t2] = W2s[(16 * kt + i) * kFLd + 16 * t2];
+    };
+    fetch(0, wa[0]);
 #pragma unroll
-            for (int t2 = 0; t2 < 4; ++t2) X2[t2] = mfma16(wr[16 * t2], X1[kt][i], X2[t2]);
-        }
+    for (int kt = 0; kt < NM1; ++kt) {
+        if (kt + 1 < NM1) fetch(kt + 1, wa[(kt + 1) & 1]);
+#if TSC_IQL_SCHED & 1
+        __builtin_amdgcn_sched_barrier(0);                         // the requests stay in front of this k-tile's MFMAs
+#endif
 #pragma unroll
-    for (int t2 = 0; t2 < 4; ++t2)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) X2[t2][i] = X2[t2][i] > 0.f ? X2[t2][i] : 0.f;
-    // Q^T [16 (8 used) actions][16 rows]: two accumulators (the 16x16x4 form's dependent latency is 40 cycles)
+            for (int t2 = 0; t2 < 4; ++t2)
+#pragma unroll
+                for (int b_ = 0; b_ < NB; ++b_) X2[b_][t2] = mfma16(wa[kt & 1][4 * i + t2], X1[b_][kt][i], X2[b_][t2]);
+#if TSC_IQL_SCHED & 1
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+#ifdef TSC_IQL_FINE
+    if (fst) fst[13] = clock64();
+#endif
+#pragma unroll
+    for (int b_ = 0; b_ < NB; ++b_)
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) X2[b_][t2][i] = X2[b_][t2][i] > 0.f ? X2[b_][t2][i] : 0.f;
+#ifdef TSC_IQL_FINE
+    if (fst) fst[14] = clock64();
+#endif
+    // Q^T [16 (8 used) actions][16 rows]: two accumulators per set (the 16x16x4 form's dependent latency is 40 cycles)
     const float4 bq = *reinterpret_cast<const float4 *>(Bs + H1 + kFH2 + 4 * kq);
-    f32x4 qa = f32x4{bq.x, bq.y, bq.z, bq.w}, qb = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 qa[NB], qb[NB];
+#pragma unroll
+    for (int b_ = 0; b_ < NB; ++b_) { qa[b_] = f32x4{bq.x, bq.y, bq.z, bq.w}; qb[b_] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const float *Wqs = sm + LD::oWq + 4 * kq * kFLq + m;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        qa = mfma16(Wqs[(0 + i) * kFLq], X2[0][i], qa);
-        qb = mfma16(Wqs[(16 + i) * kFLq], X2[1][i], qb);
-    }
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        qa = mfma16(Wqs[(32 + i) * kFLq], X2[2][i], qa);
-        qb = mfma16(Wqs[(48 + i) * kFLq], X2[3][i], qb);
-    }
-    q = qa + qb;
+        for (int i = 0; i < 4; ++i) {
+            const float wA = Wqs[(32 * h + i) * kFLq], wB = Wqs[(32 * h + 16 + i) * kFLq];
+#pragma unroll
+            for (int b_ = 0; b_ < NB; ++b_) {
+                qa[b_] = mfma16(wA, X2[b_][2 * h][i], qa[b_]);
+                qb[b_] = mfma16(wB, X2[b_][2 * h + 1][i], qb[b_]);
+            }
+        }
+#pragma unroll
+    for (int b_ = 0; b_ < NB; ++b_) q[b_] = qa[b_] + qb[b_];
 }
 
-template <int NM1>
-__device__ __forceinline__ void q_load_w1(const float *__restrict__ P, const QFusedArgs &p, int m, int kq, float (&w1)[NM1][3][4]) {
+template <int NM1, int NMW>
+__device__ __forceinline__ void q_load_w1(const float *__restrict__ P, const QFusedArgs &p, const QRanges &rg, int m, int kq, QW1<NM1, NMW> &w1) {
     constexpr int H1 = 16 * NM1;
+    using W = QW1<NM1, NMW>;
+    auto ld = [&](int f, int col) {                      // W1[f][col], zero past the observation's width (the row index is clamped, the value selected)
+        const float v = P[p.oW1 + (long long)(f < p.SMAX ? f : p.SMAX - 1) * H1 + col];
+        return f < p.SMAX ? v : 0.f;
+    };
 #pragma unroll
-    for (int t = 0; t < NM1; ++t)
+    for (int t = 0; t < NMW; ++t)
 #pragma unroll
-        for (int qp = 0; qp < 3; ++qp)
+        for (int qp = 0; qp < W::QW; ++qp)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int f = 16 * qp + 4 * kq + c;
-                w1[t][qp][c] = f < p.SMAX ? P[p.oW1 + (long long)f * H1 + 16 * t + m] : 0.f;
-            }
+            for (int c = 0; c < 4; ++c) w1.w[t][qp][c] = ld(16 * qp + 4 * kq + c, 16 * t + m);
+    if (NM1 > NMW) {
+#pragma unroll
+        for (int t = NMW; t < NM1; ++t)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) w1.t[t - NMW][qq][c] = ld(16 * (rg.qt0 + qq) + 4 * kq + c, 16 * t + m);
+    }
 }
 
 // 16 bytes of an observation row (features 16 q + 4 kq ..): zero past the row's end
 __device__ __forceinline__ float4 q_obs4(const float *row, int f0, int SMAX, bool ok) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok && f0 < SMAX) v = *reinterpret_cast<const float4 *>(row + f0);
-    return v;
+    const bool in = ok && f0 < SMAX;                     // the load itself is unconditional (a valid address either way): no branch per group
+    const float4 v = *reinterpret_cast<const float4 *>(row + (f0 < SMAX ? f0 : 0));
+    return in ? v : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // ---- the minibatch gradient ---------------------------------------------------------------------------------------------------
@@ -201,22 +294,26 @@ __global__ void __launch_bounds__(256, 1) iql_fused_grad_kernel(QFusedArgs p) {
     const int na = p.n_act[a];
     const QRanges rg = q_ranges(p.n_wave[a], p.n_wait[a]);
     q_stage_weights<NM1>(P, p, sm, tid, 256);
-    float w1[NM1][3][4];
-    q_load_w1<NM1>(P, p, n, kq, w1);
+    QW1<NM1, NMW> w1;
+    q_load_w1<NM1, NMW>(P, p, rg, n, kq, w1);
 
-    // ---- this wavefront's tiles of the weight gradients (all of them live in registers over the whole slice)
-    // dW2 [H1][64]: row tiles mi = wave + 4 j (j < 3), all four column tiles; dWq [64][8]: row tiles 2 (wave - 2) .. + 1 on wavefronts 2, 3
-    // dW1 [48][H1]: column tiles ni = wave + 4 j, the three feature tiles
-    f32x4 aW2[3][4], aWq[2], aW1[3][3];
+    // ---- this wavefront's tiles of the weight gradients (all of them live in registers over the whole slice; equal work per wavefront)
+    // dW2 [H1][64]: column tile `wave`, all NM1 row tiles;  dWq [64][8]: row tile `wave`
+    // dW1 [48][H1]: wave part (columns < 16 NMW): column tiles wave, wave + 4 x the feature tiles [0, qw1);
+    //               wait part (columns >= 16 NMW): tile `wave` of the list (feature tile qt0 + wave / 2, column tile NMW + wave % 2)
+    static_assert(NMW == 8, "two wave-part column tiles per wavefront");
+    f32x4 aW2[NM1], aWq, aW1w[2][3], aW1t;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int t = 0; t < NM1; ++t) aW2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) aW2[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) aW1[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    aWq[0] = aWq[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float sb2[4] = {0.f, 0.f, 0.f, 0.f}, sbq = 0.f, sb1[3] = {0.f, 0.f, 0.f}, loss = 0.f;
+        for (int t = 0; t < 3; ++t) aW1w[j][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    aWq = aW1t = f32x4{0.f, 0.f, 0.f, 0.f};
+    float sb2 = 0.f, sbq = 0.f, sb1[2] = {0.f, 0.f}, sb1t = 0.f, loss = 0.f;
+    // the wait-part tile of this wavefront: list index = wave (at most 2 feature groups x 2 column tiles, see QW1)
+    const bool wt_on = NM1 > NMW && rg.qt0 + (wave >> 1) < rg.qt1;
+    const int wt_mf = wt_on ? rg.qt0 + (wave >> 1) : 0, wt_ni = NM1 > NMW ? NMW + (wave & 1) : 0;
     const long long nchunks = (p.R + 63) >> 6;
     const long long c0 = (long long)sp * p.cps;
     long long c1 = c0 + p.cps;
@@ -224,19 +321,22 @@ __global__ void __launch_bounds__(256, 1) iql_fused_grad_kernel(QFusedArgs p) {
     const float fR = (float)p.R;
 
     struct Rows { float4 s0[3], s1[3]; float rew; int act, done; bool ok; };
-    auto slot_of = [&](long long c) -> int {             // ring slot of this lane's row in chunk c (clamped like the gather kernel's)
-        long long row = (c << 6) + 16 * wave + n;
-        if (row >= p.R) row = p.R - 1;
-        const long long e = row / p.B;
-        int s = p.idx[(e * p.A + a) * p.B + row % p.B];
-        return s < 0 ? 0 : s >= p.size ? p.size - 1 : s;
+    // rows are 32-bit here (the host refuses E * B >= 2^31): a 64-bit division per lane and chunk costs more than the chunk's VALU work
+    const unsigned uR = (unsigned)p.R, uB = (unsigned)p.B;
+    struct Slot { int slot; unsigned e; };
+    auto slot_of = [&](long long c) -> Slot {            // ring slot of this lane's row in chunk c (clamped like the gather kernel's)
+        unsigned row = ((unsigned)c << 6) + 16 * wave + n;
+        if (row >= uR) row = uR - 1;
+        Slot o;
+        o.e = row / uB;
+        const int s_ = p.idx[((long long)o.e * p.A + a) * p.B + (row - o.e * uB)];
+        o.slot = s_ < 0 ? 0 : s_ >= p.size ? p.size - 1 : s_;
+        return o;
     };
-    auto load_rows = [&](long long c, int slot, Rows &r) {
-        long long row = (c << 6) + 16 * wave + n;
-        r.ok = row < p.R && c < c1;
-        if (row >= p.R) row = p.R - 1;
-        const long long e = row / p.B;
-        const long long tr = (e * p.cap + slot) * p.A + a;
+    auto load_rows = [&](long long c, const Slot &sl, Rows &r) {
+        const unsigned row = ((unsigned)c << 6) + 16 * wave + n;
+        r.ok = row < uR && c < c1;
+        const long long tr = ((long long)sl.e * p.cap + sl.slot) * p.A + a;
         const float *o = p.r_obs + tr * p.SMAX, *o1 = p.r_next + tr * p.SMAX;
 #pragma unroll
         for (int qp = 0; qp < 3; ++qp) {
@@ -245,11 +345,18 @@ __global__ void __launch_bounds__(256, 1) iql_fused_grad_kernel(QFusedArgs p) {
         }
         r.rew = p.r_rew[tr];
         r.act = p.r_act[tr];
-        r.done = p.r_done[e * p.cap + slot];
+        r.done = p.r_done[(long long)sl.e * p.cap + sl.slot];
     };
 
+    const bool stamp_wg = p.dbg && blockIdx.x == 0 && lane == 0;
+    if (p.dbg && tid == 0) p.dbg[64 + 2 * blockIdx.x] = wall_clock64();
+#ifdef TSC_IQL_STAMPS
+#define QSTAMP(k) do { if (stamp_wg && c == c0 + 2) p.dbg[16 * wave + (k)] = clock64(); } while (0)
+#else
+#define QSTAMP(k) do { } while (0)
+#endif
     Rows cur, nxt;
-    int slot_n = 0;
+    Slot slot_n = {0, 0};
     if (c0 < c1) {
         load_rows(c0, slot_of(c0), cur);
         slot_n = slot_of(c0 + 1 < c1 ? c0 + 1 : c0);
@@ -261,14 +368,24 @@ __global__ void __launch_bounds__(256, 1) iql_fused_grad_kernel(QFusedArgs p) {
         load_rows(c + 1 < c1 ? c + 1 : c, slot_n, nxt);
         slot_n = slot_of(c + 2 < c1 ? c + 2 : c);
         // ================= phase A: 16 rows per wavefront =================
-        f32x4 X1[NM1], X2[4], q;
-        q_nets<NM1, NMW>(w1, cur.s1, sm, rg, n, kq, X1, X2, q);       // Q(s'): only its maximum survives
+        QSTAMP(0);
+        // Q(s') (set 0: only its maximum survives) and Q(s) (set 1: its activations feed the backward pass) side by side
+        f32x4 XX1[2][NM1], XX2[2][4], qq[2];
+        {
+            float4 ss[2][3];
+#pragma unroll
+            for (int qp = 0; qp < 3; ++qp) { ss[0][qp] = cur.s1[qp]; ss[1][qp] = cur.s0[qp]; }
+            q_nets<2, NM1, NMW>(w1, ss, sm, rg, n, kq, XX1, XX2, qq, (stamp_wg && c == c0 + 2) ? p.dbg + 16 * wave : nullptr);
+        }
+        QSTAMP(1);
+        f32x4 (&X1)[NM1] = XX1[1];
+        f32x4 (&X2)[4] = XX2[1];
+        const f32x4 q = qq[1];
         float q1 = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (kq < 2 && 4 * kq + i < na) q1 = fmaxf(q1, q[i]);
+        for (int i = 0; i < 4; ++i) if (kq < 2 && 4 * kq + i < na) q1 = fmaxf(q1, qq[0][i]);
         q1 = fmaxf(q1, __shfl_xor(q1, 16, 64));
         q1 = fmaxf(q1, __shfl_xor(q1, 32, 64));
-        q_nets<NM1, NMW>(w1, cur.s0, sm, rg, n, kq, X1, X2, q);       // Q(s) with the activations the backward pass needs
         const int act = cur.act;
         float q0 = 0.f;
 #pragma unroll
@@ -316,6 +433,7 @@ __global__ void __launch_bounds__(256, 1) iql_fused_grad_kernel(QFusedArgs p) {
                     d2s[(16 * t + i) * kFLd] = D2[t][i];
                 }
         }
+        QSTAMP(2);
         // dX1 = (W2 dX2) relu'(X1): A = W2[16 t + m][16 t2 + 4 kq .. + 3] (16-byte LDS reads), B = dX2[t2][i]
         f32x4 D1[NM1];
         {
@@ -340,54 +458,56 @@ __global__ void __launch_bounds__(256, 1) iql_fused_grad_kernel(QFusedArgs p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) D1[t][i] = X1[t][i] > 0.f ? D1[t][i] : 0.f;
         }
+        QSTAMP(3);
         __syncthreads();
+        QSTAMP(4);
         // ================= phase B: dW2 += X1^T dX2, db2, dWq += X2^T dQ, dbq over the chunk's 64 rows =================
         // contraction step (t', c): lane group kq supplies row 16 t' + 4 kq + c -- the same permutation on both operands
         {
-            const float *xa = sm + LD::oX1 + n * kFLd + 4 * kq, *db = sm + LD::oD2 + n * kFLd + 4 * kq;
-            const float *x2a = sm + LD::oX2 + n * kFLd + 4 * kq;
+            const float *xa = sm + LD::oX1 + n * kFLd + 4 * kq, *db = sm + LD::oD2 + (16 * wave + n) * kFLd + 4 * kq;
+            const float *x2a = sm + LD::oX2 + (16 * wave + n) * kFLd + 4 * kq;
+            // the operands of contraction step t' + 1 are requested before the 44 MFMAs of step t' (pinned: see q_nets)
+            struct BOps { float bv[4], qv[4], xv[4], av[NM1][4]; };
+            auto fetch_b = [&](int tp, BOps &o) {
+                const float4 bv4 = *reinterpret_cast<const float4 *>(db + 16 * tp);
+                o.bv[0] = bv4.x; o.bv[1] = bv4.y; o.bv[2] = bv4.z; o.bv[3] = bv4.w;
+                const float4 gv = *reinterpret_cast<const float4 *>(sm + LD::oG + 16 * tp + 4 * kq);
+                const int4 tv = *reinterpret_cast<const int4 *>(sm + LD::oG + 64 + 16 * tp + 4 * kq);
+                o.qv[0] = tv.x == n ? gv.x : 0.f; o.qv[1] = tv.y == n ? gv.y : 0.f;
+                o.qv[2] = tv.z == n ? gv.z : 0.f; o.qv[3] = tv.w == n ? gv.w : 0.f;
+                const float4 xv4 = *reinterpret_cast<const float4 *>(x2a + 16 * tp);
+                o.xv[0] = xv4.x; o.xv[1] = xv4.y; o.xv[2] = xv4.z; o.xv[3] = xv4.w;
+#pragma unroll
+                for (int mi = 0; mi < NM1; ++mi) {
+                    const float4 v = *reinterpret_cast<const float4 *>(xa + 16 * mi * kFLd + 16 * tp);
+                    o.av[mi][0] = v.x; o.av[mi][1] = v.y; o.av[mi][2] = v.z; o.av[mi][3] = v.w;
+                }
+            };
+            BOps ob[2];
+            fetch_b(0, ob[0]);
 #pragma unroll
             for (int tp = 0; tp < 4; ++tp) {
-                float4 bv[4];
+                if (tp + 1 < 4) fetch_b(tp + 1, ob[(tp + 1) & 1]);
+#if TSC_IQL_SCHED & 2
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                const BOps &o = ob[tp & 1];
+                sb2 += (o.bv[0] + o.bv[1]) + (o.bv[2] + o.bv[3]);
+                if (wave == 0) sbq += (o.qv[0] + o.qv[1]) + (o.qv[2] + o.qv[3]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) bv[t] = *reinterpret_cast<const float4 *>(db + 16 * t * kFLd + 16 * tp);
-                if (wave == 0) {
+                for (int c = 0; c < 4; ++c) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) sb2[t] += (bv[t].x + bv[t].y) + (bv[t].z + bv[t].w);
+                    for (int mi = 0; mi < NM1; ++mi) aW2[mi] = mfma16(o.av[mi][c], o.bv[c], aW2[mi]);
+                    aWq = mfma16(o.xv[c], o.qv[c], aWq);
                 }
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int mi = wave + 4 * j;
-                    if (mi < NM1) {
-                        const float4 av4 = *reinterpret_cast<const float4 *>(xa + 16 * mi * kFLd + 16 * tp);
-                        const float av[4] = {av4.x, av4.y, av4.z, av4.w};
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            aW2[j][0] = mfma16(av[c], c == 0 ? bv[0].x : c == 1 ? bv[0].y : c == 2 ? bv[0].z : bv[0].w, aW2[j][0]);
-                            aW2[j][1] = mfma16(av[c], c == 0 ? bv[1].x : c == 1 ? bv[1].y : c == 2 ? bv[1].z : bv[1].w, aW2[j][1]);
-                            aW2[j][2] = mfma16(av[c], c == 0 ? bv[2].x : c == 1 ? bv[2].y : c == 2 ? bv[2].z : bv[2].w, aW2[j][2]);
-                            aW2[j][3] = mfma16(av[c], c == 0 ? bv[3].x : c == 1 ? bv[3].y : c == 2 ? bv[3].z : bv[3].w, aW2[j][3]);
-                        }
-                    }
-                }
-                if (wave >= 2) {
-                    const float4 gv = *reinterpret_cast<const float4 *>(sm + LD::oG + 16 * tp + 4 * kq);
-                    const int4 av = *reinterpret_cast<const int4 *>(sm + LD::oG + 64 + 16 * tp + 4 * kq);
-                    const float b0 = av.x == n ? gv.x : 0.f, b1 = av.y == n ? gv.y : 0.f, b2 = av.z == n ? gv.z : 0.f,
-                                b3 = av.w == n ? gv.w : 0.f;
-                    if (wave == 2) sbq += (b0 + b1) + (b2 + b3);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const float4 xv = *reinterpret_cast<const float4 *>(x2a + 16 * (2 * (wave - 2) + j) * kFLd + 16 * tp);
-                        aWq[j] = mfma16(xv.x, b0, aWq[j]);
-                        aWq[j] = mfma16(xv.y, b1, aWq[j]);
-                        aWq[j] = mfma16(xv.z, b2, aWq[j]);
-                        aWq[j] = mfma16(xv.w, b3, aWq[j]);
-                    }
-                }
+#if TSC_IQL_SCHED & 2
+                __builtin_amdgcn_sched_barrier(0);
+#endif
             }
         }
+        QSTAMP(5);
         __syncthreads();
+        QSTAMP(6);
         // ================= phase C: dX1 over X1's image =================
         {
             float *x1s = sm + LD::oX1 + 4 * kq * kFLd + rcol;
@@ -396,82 +516,108 @@ __global__ void __launch_bounds__(256, 1) iql_fused_grad_kernel(QFusedArgs p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) x1s[(16 * t + i) * kFLd] = D1[t][i];
         }
+        QSTAMP(7);
         __syncthreads();
+        QSTAMP(8);
         // ================= phase D: dW1 += S^T dX1, db1 =================
         {
             const float *sa = sm + LD::oS + n * kFLd + 4 * kq, *db = sm + LD::oX1 + n * kFLd + 4 * kq;
+            auto wave_part = [&](auto nmf_c) {
+                constexpr int NMF = decltype(nmf_c)::value;
+                struct DOps { float bw[2][4], bt[4], at[4], aw[NMF][4]; };
+                auto fetch_d = [&](int tp, DOps &o) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int ni = wave + 4 * j;
-                if (ni < NM1) {
-#pragma unroll
-                    for (int tp = 0; tp < 4; ++tp) {
-                        const float4 bv = *reinterpret_cast<const float4 *>(db + 16 * ni * kFLd + 16 * tp);
-                        sb1[j] += (bv.x + bv.y) + (bv.z + bv.w);
-                        float av[3][4];
-#pragma unroll
-                        for (int mf = 0; mf < 3; ++mf) {
-                            const float4 v = *reinterpret_cast<const float4 *>(sa + 16 * mf * kFLd + 16 * tp);
-                            av[mf][0] = v.x; av[mf][1] = v.y; av[mf][2] = v.z; av[mf][3] = v.w;
-                        }
-                        const float bc[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-#pragma unroll
-                            for (int mf = 0; mf < 3; ++mf) aW1[j][mf] = mfma16(av[mf][c], bc[c], aW1[j][mf]);
+                    for (int j = 0; j < 2; ++j) {
+                        const float4 v = *reinterpret_cast<const float4 *>(db + 16 * (wave + 4 * j) * kFLd + 16 * tp);
+                        o.bw[j][0] = v.x; o.bw[j][1] = v.y; o.bw[j][2] = v.z; o.bw[j][3] = v.w;
                     }
+                    const float4 bt4 = *reinterpret_cast<const float4 *>(db + 16 * wt_ni * kFLd + 16 * tp);
+                    const float4 at4 = *reinterpret_cast<const float4 *>(sa + 16 * wt_mf * kFLd + 16 * tp);
+                    o.bt[0] = bt4.x; o.bt[1] = bt4.y; o.bt[2] = bt4.z; o.bt[3] = bt4.w;
+                    o.at[0] = wt_on ? at4.x : 0.f; o.at[1] = wt_on ? at4.y : 0.f; o.at[2] = wt_on ? at4.z : 0.f; o.at[3] = wt_on ? at4.w : 0.f;
+#pragma unroll
+                    for (int mf = 0; mf < NMF; ++mf) {
+                        const float4 v = *reinterpret_cast<const float4 *>(sa + 16 * mf * kFLd + 16 * tp);
+                        o.aw[mf][0] = v.x; o.aw[mf][1] = v.y; o.aw[mf][2] = v.z; o.aw[mf][3] = v.w;
+                    }
+                };
+                DOps od[2];
+                fetch_d(0, od[0]);
+#pragma unroll
+                for (int tp = 0; tp < 4; ++tp) {
+                    if (tp + 1 < 4) fetch_d(tp + 1, od[(tp + 1) & 1]);
+#if TSC_IQL_SCHED & 4
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                    const DOps &o = od[tp & 1];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) sb1[j] += (o.bw[j][0] + o.bw[j][1]) + (o.bw[j][2] + o.bw[j][3]);
+                    if (NM1 > NMW && wave < 2) sb1t += (o.bt[0] + o.bt[1]) + (o.bt[2] + o.bt[3]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int mf = 0; mf < NMF; ++mf) aW1w[j][mf] = mfma16(o.aw[mf][c], o.bw[j][c], aW1w[j][mf]);
+                        if (NM1 > NMW) aW1t = mfma16(o.at[c], o.bt[c], aW1t);
+                    }
+#if TSC_IQL_SCHED & 4
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
                 }
-            }
+            };
+            wave_part(std::integral_constant<int, QW1<NM1, NMW>::QW>{});       // every feature group the instantiation admits: no branch (see q_nets)
         }
+        QSTAMP(9);
         __syncthreads();
+        QSTAMP(10);
         cur = nxt;
     }
 
     // ---- this split's partial gradient, parameter layout; the reduce kernel never reads what is not written here
     float *w = p.ws + ((long long)sp * p.A + a) * p.stride;
+    auto fold_kq = [&](float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; };
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int mi = wave + 4 * j;
-        if (mi < NM1) {
+    for (int mi = 0; mi < NM1; ++mi)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+        for (int i = 0; i < 4; ++i) w[p.oW2 + (long long)(16 * mi + 4 * kq + i) * kFH2 + 16 * wave + n] = aW2[mi][i];
+    {
+        const float s2 = fold_kq(sb2);
+        if (kq == 0) w[p.ob2 + 16 * wave + n] = s2;
+    }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) w[p.oW2 + (long long)(16 * mi + 4 * kq + i) * kFH2 + 16 * t + n] = aW2[j][t][i];
+    for (int i = 0; i < 4; ++i)
+        if (n < 8) w[p.oWq + (long long)(16 * wave + 4 * kq + i) * 8 + n] = aWq[i];
+    {
+        const float sq = fold_kq(sbq);
+        if (wave == 0 && kq == 0 && n < 8) w[p.obq + n] = sq;
+    }
 #pragma unroll
-            for (int mf = 0; mf < 3; ++mf)
+    for (int j = 0; j < 2; ++j) {
+        const int ni = wave + 4 * j;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int f = 16 * mf + 4 * kq + i;
-                    if (f < p.SMAX) w[p.oW1 + (long long)f * H1 + 16 * mi + n] = aW1[j][mf][i];
-                }
-            float s = sb1[j];
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            if (kq == 0) w[p.ob1 + 16 * mi + n] = s;
+        for (int mf = 0; mf < 3; ++mf)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int f = 16 * mf + 4 * kq + i;
+                if (f < p.SMAX) w[p.oW1 + (long long)f * H1 + 16 * ni + n] = aW1w[j][mf][i];
+            }
+        const float s1 = fold_kq(sb1[j]);
+        if (kq == 0) w[p.ob1 + 16 * ni + n] = s1;
+    }
+    if (wt_on) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = 16 * wt_mf + 4 * kq + i;
+            if (f < p.SMAX) w[p.oW1 + (long long)f * H1 + 16 * wt_ni + n] = aW1t[i];
         }
     }
-    if (wave == 0) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float s = sb2[t];
-            s += __shfl_xor(s, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            if (kq == 0) w[p.ob2 + 16 * t + n] = s;
-        }
+    if (NM1 > NMW) {
+        const float st = fold_kq(sb1t);
+        if (wave < 2 && kq == 0) w[p.ob1 + 16 * (NMW + wave) + n] = st;
     }
-    if (wave >= 2) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (n < 8) w[p.oWq + (long long)(16 * (2 * (wave - 2) + j) + 4 * kq + i) * 8 + n] = aWq[j][i];
-    }
-    if (wave == 2) {
-        float s = sbq;
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        if (kq == 0 && n < 8) w[p.obq + n] = s;
-    }
+    if (p.dbg && tid == 0) p.dbg[64 + 2 * blockIdx.x + 1] = wall_clock64();
+#undef QSTAMP
     // loss of the split: lanes kq == 0 hold one row each
     __syncthreads();
     {
@@ -541,11 +687,15 @@ __global__ void __launch_bounds__(256, 1) iql_fused_act_kernel(QFusedArgs p, con
 #pragma unroll
     for (int qp = 0; qp < 3; ++qp) s[qp] = q_obs4(row, 16 * qp + 4 * kq, p.SMAX, ok);
     q_stage_weights<NM1>(P, p, sm, tid, 256);
-    float w1[NM1][3][4];
-    q_load_w1<NM1>(P, p, n, kq, w1);
+    QW1<NM1, NMW> w1;
+    q_load_w1<NM1, NMW>(P, p, rg, n, kq, w1);
     __syncthreads();
-    f32x4 X1[NM1], X2[4], q;
-    q_nets<NM1, NMW>(w1, s, sm, rg, n, kq, X1, X2, q);
+    f32x4 X1[1][NM1], X2[1][4], qo[1];
+    {
+        float4 ss[1][3] = {{s[0], s[1], s[2]}};
+        q_nets<1, NM1, NMW>(w1, ss, sm, rg, n, kq, X1, X2, qo);
+    }
+    const f32x4 q = qo[0];
     // the row's eight Q values into its kq == 0 lane
     float qv[8];
 #pragma unroll

@@ -55,6 +55,7 @@ def _setup_lib(L):
     L.tsc_iql_apply_grads.argtypes = [vp, C.c_double, C.c_double, vp]
     L.tsc_iql_debug_batch.argtypes = [vp, vp]
     L.tsc_iql_path.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.tsc_iql_debug_clock.argtypes = [vp, C.c_int32, vp, C.c_int32]
     L._iql_ready = True
 
 

@@ -367,6 +367,13 @@ int tsc_iql_debug_batch(tsc_iql *h, int32_t *idx_host);
  * (csrc/tsc_iql_fused.h: num_fc 128, num_h 64, s_max <= 48 -- the reference's configurations), 0 for the grouped-GEMM path
  * (IQL-LR, other widths, or TSC_IQL_FUSED=0 in the environment when the handle was created). */
 int tsc_iql_path(tsc_iql *h, int32_t *fused);
+/* Measurement hook of the fused learner (tools/bench_iql.py --stamps): enable != 0 allocates the stamp buffer; the next
+ * tsc_iql_compute_grads then records, for every workgroup, its start / end on the 100-MHz wall clock ([64 + 2 b],
+ * [64 + 2 b + 1]) and -- in a measurement build with -DTSC_IQL_STAMPS (tools/build_variant.sh; the stamps' branches are kept
+ * out of the product kernel) -- for workgroup 0 eleven shader-clock stamps per wavefront around the phases of its third 64-row
+ * chunk ([16 w + k], csrc/tsc_iql_fused.h QSTAMP).  stamps_host (nullable) receives min(count, 64 + 2 x workgroups) values.
+ * Synchronises. */
+int tsc_iql_debug_clock(tsc_iql *h, int32_t enable, int64_t *stamps_host, int32_t count);
 
 /* Test hook: the grouped fp32 MFMA GEMM used by every layer.  form: 0 = NN, 1 = TN; epi as
  * csrc/tsc_gemm.h.  All pointers device; strides in elements.  A non-null split-K workspace lets
