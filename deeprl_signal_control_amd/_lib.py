@@ -45,7 +45,7 @@ _LIB = None
 SYMBOLS = ['tsc_last_error', 'tsc_version', 'tsc_profile_enable', 'tsc_profile_select', 'tsc_profile_reset', 'tsc_profile_read',
            'tsc_profile_name', 'tsc_env_create', 'tsc_env_destroy', 'tsc_env_set_stream', 'tsc_env_set_resident_instances',
            'tsc_env_reset', 'tsc_env_set_stream_routes', 'tsc_env_set_greedy', 'tsc_env_greedy_actions', 'tsc_env_set_fingerprint', 'tsc_env_bind_fingerprint', 'tsc_env_reward_sum', 'tsc_env_step', 'tsc_env_get_state',
-           'tsc_env_live_vehicles', 'tsc_env_counters', 'tsc_env_debug_clock', 'tsc_env_live_sum', 'tsc_env_record', 'tsc_env_read_record', 'tsc_env_read_trips',
+           'tsc_env_live_vehicles', 'tsc_env_vehicle_counts', 'tsc_env_set_block_order', 'tsc_env_counters', 'tsc_env_debug_clock', 'tsc_env_live_sum', 'tsc_env_record', 'tsc_env_read_record', 'tsc_env_read_trips',
            'tsc_model_create', 'tsc_model_destroy', 'tsc_model_set_stream', 'tsc_model_layout',
            'tsc_model_set_params', 'tsc_model_reset_opt_state', 'tsc_model_debug_read', 'tsc_model_get_params', 'tsc_model_get_opt_state', 'tsc_model_set_opt_state',
            'tsc_model_reset', 'tsc_model_forward', 'tsc_model_forward_sample', 'tsc_model_sample', 'tsc_model_add_transition',
@@ -88,6 +88,8 @@ def lib():
     L.tsc_env_step.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int32]
     L.tsc_env_get_state.argtypes = [vp, C.c_int32, _ip, _fp, _fp, _fp, _ip, _ip, _ip, _ip, _ip]
     L.tsc_env_live_vehicles.argtypes = [vp, C.POINTER(C.c_double)]
+    L.tsc_env_vehicle_counts.argtypes = [vp, vp]
+    L.tsc_env_set_block_order.argtypes = [vp, vp]
     L.tsc_env_counters.argtypes = [vp, vp, vp]
     L.tsc_env_debug_clock.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64)]
     L.tsc_env_live_sum.argtypes = [vp, C.POINTER(C.c_double), C.c_int32]

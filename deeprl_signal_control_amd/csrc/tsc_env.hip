@@ -97,6 +97,7 @@ struct EnvDev {
     double *reward_acc;            // [E] running sum of the global reward (training-curve logging, utils.py:161,296-305)
     const float *fp_bound;         // zero-copy fingerprint source (tsc_env_bind_fingerprint) or null
     long long *dbg;                // optional: shader-clock stamps of workgroup 0 / thread 0 (tsc_env_debug_clock)
+    const int *order;              // [E] instance of workgroup b (tsc_env_set_block_order / the load balancer); null = b
     // ---- evaluation recording (envs/env.py:409-437,498-515; tsc_env_record): off on the training path
     int rec;                       // per-second network statistics + trip log are being kept
     int trip_cap;                  // trip records per instance
@@ -396,7 +397,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         P.NS = D.NR;                            // the reference's configurations: every route is its own stream
     }
     Smem s = carve(smem_raw, P);
-    const int e = blockIdx.x, l = threadIdx.x, NLP = P.NLP, NLA = P.NLA, NR = P.NR, NS = P.NS;
+    const int e = P.order ? P.order[blockIdx.x] : (int)blockIdx.x, l = threadIdx.x, NLP = P.NLP, NLA = P.NLA, NR = P.NR, NS = P.NS;
     const bool lane = l < P.NU;             // lanes >= NU are never entered by any route: always empty
     const bool lthr = l < NLA;              // threads >= NLA only help in phase A1 and in the strided loops
     const bool stamp = P.dbg && blockIdx.x == 0 && threadIdx.x == 0;
@@ -1196,6 +1197,7 @@ struct tsc_env {
     int spec;                       // 1: the scenario has the large_grid table dimensions -> specialised step_kernel (TSC_ENV_SPEC=0: off)
     uint32_t *d_seeds;
     std::vector<int> h_mode, h_sroute;      // host copies of the stream tables (tsc_env_set_stream_routes)
+    int *order_buf = nullptr;       // tsc_env_set_block_order
     bool auto_threads;              // the workgroup size follows the number of instances resident on the device (pick_workgroup)
     int kf_default;
 };
@@ -1498,6 +1500,7 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     P.trips = nullptr;
     P.fp_bound = nullptr;
     P.dbg = nullptr;
+    P.order = nullptr;
     TSC_HIP(hipMalloc((void **)&h->d_seeds, sizeof(uint32_t) * n_env));
     h->allocs.push_back(h->d_seeds);
     {   // phase A1 (helper threads) unless switched off for A/B measurements
@@ -1824,6 +1827,39 @@ int tsc_env_debug_clock(tsc_env *h, int32_t enable, int64_t *stamps64_host) {
     }
     if (stamps64_host && h->P.dbg)
         TSC_HIP(hipMemcpy(stamps64_host, h->P.dbg, (enable == 2 ? 64 + 2 * (size_t)h->P.E : 64) * sizeof(long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tsc_env_vehicle_counts(tsc_env *h, int32_t *counts_host) {
+    if (!h || !counts_host) return tsc::fail("tsc_env_vehicle_counts: bad arguments");
+    const EnvDev &P = h->P;
+    TSC_HIP(hipStreamSynchronize(h->stream));
+    std::vector<int> hn((size_t)P.E * P.NLP);
+    TSC_HIP(hipMemcpy(hn.data(), P.N, hn.size() * 4, hipMemcpyDeviceToHost));
+    for (int e = 0; e < P.E; ++e) {
+        int tot = 0;
+        for (int l = 0; l < P.NL; ++l) tot += hn[(size_t)e * P.NLP + l];
+        counts_host[e] = tot;
+    }
+    return 0;
+}
+
+int tsc_env_set_block_order(tsc_env *h, const int32_t *order_host) {
+    if (!h) return tsc::fail("tsc_env_set_block_order: null handle");
+    TSC_HIP(hipStreamSynchronize(h->stream));
+    if (!order_host) { h->P.order = nullptr; return 0; }
+    std::vector<char> seen(h->P.E, 0);
+    for (int b = 0; b < h->P.E; ++b) {
+        const int e = order_host[b];
+        if (e < 0 || e >= h->P.E || seen[e]) return tsc::fail("tsc_env_set_block_order: not a permutation of the %d instances", h->P.E);
+        seen[e] = 1;
+    }
+    if (!h->order_buf) {
+        TSC_HIP(hipMalloc((void **)&h->order_buf, sizeof(int) * (size_t)h->P.E));
+        h->allocs.push_back(h->order_buf);
+    }
+    TSC_HIP(hipMemcpy(h->order_buf, order_host, sizeof(int) * (size_t)h->P.E, hipMemcpyHostToDevice));
+    h->P.order = h->order_buf;
     return 0;
 }
 

@@ -182,6 +182,12 @@ int tsc_env_get_state(tsc_env *h, int32_t e, int32_t *n, float *x, float *v, flo
  * 64 + 2E entries). */
 int tsc_env_debug_clock(tsc_env *h, int32_t enable, int64_t *stamps64_host);
 
+/* Tuning aids of the simulator's launch geometry.  tsc_env_vehicle_counts: vehicles in the network of every instance (host int32
+ * [E]; synchronises).  tsc_env_set_block_order: workgroup b of tsc_env_step simulates instance order[b] (host int32 [E], a
+ * permutation; null = identity).  The order changes which instances share a CU, never a result. */
+int tsc_env_vehicle_counts(tsc_env *h, int32_t *counts_host);
+int tsc_env_set_block_order(tsc_env *h, const int32_t *order_host);
+
 /* Per-instance counters of the running episode, uint64 [E] each (either pointer may be null): vehicles that reached the
  * end of their route (simulation.getArrivedNumber summed over the episode, envs/env.py:413) and vehicles the teleport
  * surrogate removed (SUMO --time-to-teleport, envs/env.py:283-284; they are NOT arrivals).  Host pointers. Synchronises. */
