@@ -686,7 +686,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra', action='store_true', help='skip the sim-only / sim+forward lines (SURVEY 8d) and the other single-GPU configs')
     ap.add_argument('--no-profile', action='store_true')
-    ap.add_argument('--no-lane-change', action='store_true', help='large_grid without DESIGN.md 3 rule 10 (the rounds 1 - 4 spec): A/B measurement only')
+    ap.add_argument('--no-lane-change', action='store_true', help='large_grid without MICROSIM_SPEC.md rule 10 (the rounds 1 - 4 spec): A/B measurement only')
     ap.add_argument('--profile-stride', type=int, default=1,
                     help='profiled pass: HIP-event timing of every n-th launch of the per-control-step kernels (1 = all)')
     ap.add_argument('--profile-steps', type=int, default=0, help='iterations of every profiled pass (0 = one episode: T / n_step)')

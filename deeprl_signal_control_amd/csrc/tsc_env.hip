@@ -3,8 +3,8 @@
 // Replaces, for E parallel env instances, the reference's TrafficSimulator.step/reset
 // (envs/env.py:544-631) *including* the SUMO process behind its TraCI socket:
 //   K1 signal FSM ............ envs/env.py:128-152,455-459 (tables from scenario.py)
-//   K2 vehicle update ........ DESIGN.md "microsim spec" (IDM + safe-speed clamp, lane queues)
-//   K3 hand-off / insertion .. DESIGN.md "microsim spec" (feeder gather, vehsPerHour flows)
+//   K2 vehicle update ........ MICROSIM_SPEC.md (IDM + safe-speed clamp, lane queues)
+//   K3 hand-off / insertion .. MICROSIM_SPEC.md (feeder gather, vehsPerHour flows)
 //   K4 detectors ............. envs/env.py:325-407 (wave / halting / head-vehicle wait)
 //   K5 observation gather .... envs/env.py:163-205,439-442 (float64 arithmetic, cast to f32)
 //   K6 reward + shaping ...... envs/env.py:356-367,580,590-631 (float64, numpy sum order)
@@ -39,7 +39,7 @@
 
 namespace {
 
-constexpr float kLen = 5.0f, kS0 = 2.0f /* standstill gap (SUMO minGap 2.5 less the storage of its junction interiors) */,
+constexpr float kLen = 5.0f, kS0 = 2.0f /* standstill gap (SUMO minGap 2.5 less the storage of its junction interiors, MICROSIM_SPEC.md) */,
                 kAcc = 5.0f, kDec = 10.0f, kTHead = 1.0f;   // headway = SUMO's default tau
 constexpr float kICab = 0.070710678f /* 1 / (2 sqrt(acc dec)): a multiply instead of an IEEE division */, kHalt = 0.1f, kYieldT = 3.0f, kYieldD = 10.0f;
 constexpr int kCap = TSC_LANE_CAP, kMaxCross = TSC_MAX_CROSS, kMaxUp = TSC_MAX_UP;
@@ -158,7 +158,7 @@ __device__ __forceinline__ void wave_seg_scan_min(float &v, int &f) {
 #undef TSC_SEG_STEP
 }
 
-// one car-following evaluation against one leader (DESIGN.md "follow")
+// one car-following evaluation against one leader (MICROSIM_SPEC.md rule 3)
 __device__ __forceinline__ float follow(float v, float v0, bool has_lead, float g, float vl, float s0gap) {
     float ratio = v / v0;
     float r2 = ratio * ratio;
@@ -559,7 +559,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             int ncross = 0;
             bool all_crossed = true;
             float pnx = INFINITY, pox = 0.0f, pov = 0.0f;
-            float K = INFINITY;                            // plain walk: running min of the chain keys (DESIGN.md rule 4)
+            float K = INFINITY;                            // plain walk: running min of the chain keys (MICROSIM_SPEC.md rule 4)
             // a vehicle that stays on the lane: compact it to slot `kept`, refresh the summary, count detectors
             auto keep = [&](float xn, float vn, float sf, uint32_t nmeta, uint32_t r0 = 0u, uint32_t r1 = 0u) {
                 const unsigned ob = (unsigned)vslot(kept, l, NLP) * 4u;
@@ -792,7 +792,7 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         // ================= phase F (K2, HELP): every vehicle behind the first stayer, one per thread slot =============
         // Nobody behind a vehicle that stays can cross, so such a vehicle's new speed depends only on OLD state (itself, the
         // vehicle ahead, the signal) and its new position on the chain clamp x'_i = min(a_i, x'_{i-1} - 5), a_i = min(x_i +
-        // v'_i, L).  The clamp is an exclusive prefix-min over the keys a_j + 5 j within a lane (DESIGN.md rule 4): all
+        // v'_i, L).  The clamp is an exclusive prefix-min over the keys a_j + 5 j within a lane (MICROSIM_SPEC.md rule 4): all
         // queued vehicles of the instance are laid out flat over the workgroup (prefix sum of the lane counts, lane marks +
         // a prefix maximum to find a flat index's lane), kF consecutive ones per thread, and the chain is a segmented
         // min-scan -- in the thread, then over the wavefront on the DPP path, then across wavefronts through one LDS word
@@ -1431,7 +1431,7 @@ int tsc_env_create(const tsc_scenario *sc, int32_t n_env, int32_t device, tsc_en
     ptr[NS] = (int)fl.size() / 4;
     UP(flows, int, fl.data(), fl.size());
     UP(flow_ptr, int, ptr.data(), NS + 1);
-    {   // per-lane entry routes (<= 2) and per-route emission table (DESIGN.md microsim spec, rule 6)
+    {   // per-lane entry routes (<= 2) and per-route emission table (MICROSIM_SPEC.md, rule 6)
         std::vector<int> lr((size_t)NL * kMaxEntry, -1);
         for (int r = 0; r < NS; ++r) {
             const int l = stream_entry(r);

@@ -1605,6 +1605,10 @@ policy_fwd_ws_kernel(const float *__restrict__ params, Layout lay, const int *__
     };
     const int nt_full = last_half ? nt - 1 : nt;
     for (int it = 0; it < nt_full; ++it) tile(std::false_type{}, it);
+    // The half tile MUST stay the last use of the stationary weights: it re-pairs bwg[] in place for the 16x16x4 form (72
+    // v_permlane16_swap) and nothing restores the 32x32x2 order afterwards.  It also accumulates its gate pre-activations in K = 4
+    // steps instead of K = 2, so an instance's logits depend, at fp32 rounding, on E and on where the instance falls in its
+    // workgroup's share (tests/test_model_gpu.py keeps an E where every split ends in a half tile).
     if (last_half) tile(std::true_type{}, nt - 1);
     // ---- drain: a full group still waiting for its softmax, then the head of the last tile and its group
     {

@@ -205,7 +205,7 @@ def write_eval_tables(env, output_dir):
         if kind == 'trip_truncated':
             if not rows:
                 continue
-            # trips the teleport surrogate cut short (DESIGN.md 3 rule 1): not in the trip table (SUMO's tripinfo would list them
+            # trips the teleport surrogate cut short (MICROSIM_SPEC.md rule 1): not in the trip table (SUMO's tripinfo would list them
             # later, with long durations), so averages over the trip table alone are biased low -- say so where it is read
             logging.info('Evaluation: %d trips truncated by the teleport surrogate (mean %.1f s in the network, %.1f s waiting) are in '
                          '%s_%s_trip_truncated.csv, not in the trip table' % (

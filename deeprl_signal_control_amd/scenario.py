@@ -17,7 +17,7 @@ restatement of the reference's own network generator and env class:
 * yellow-phase rule .............................. envs/env.py:128-152
 
 The SUMO-internal parts the reference does not contain (route choice, lane
-choice, junction right-of-way) are *defined* here and in DESIGN.md ("microsim
+choice, junction right-of-way) are *defined* here and in MICROSIM_SPEC.md ("microsim
 spec"); they are this repo's spec, not SUMO's.
 """
 from __future__ import annotations
@@ -28,12 +28,12 @@ from typing import Dict, List, Tuple
 
 import numpy as np
 
-# --- microsim spec constants (DESIGN.md "microsim spec") -------------------
+# --- microsim spec constants (MICROSIM_SPEC.md) -------------------
 VEH_LEN = 5.0        # vType length=5            (build_file.py:279)
 VEH_ACCEL = 5.0      # vType accel=5
 VEH_DECEL = 10.0     # vType decel=10
 MIN_GAP = 2.5        # SUMO default minGap (not in the reference tree): sizes lane pieces and contracted chains
-STAND_GAP = 2.0      # standstill gap of the microsim spec (csrc/tsc_env.hip kS0)
+STAND_GAP = 2.0      # standstill gap of the microsim spec (csrc/tsc_env.hip kS0; MICROSIM_SPEC.md)
 LANE_CAP = 28        # vehicle slots per lane: 200 m / 7.5 m = 26.7 -> 27 (+1); hand-offs stop at LANE_CAP - MAX_CROSS
 LANE_CHANGE_DEFAULT = True    # large_grid: lane choice by the junction's connections + lane changes on the two-lane streets (rule 10)
 MAX_CROSS = 4        # vehicles that may leave one lane in one sim-step
@@ -101,9 +101,9 @@ class Scenario:
     teleport_sec: int = 600          # --time-to-teleport (env.py:281-284)
     extra: Dict = field(default_factory=dict)
     link_foes: np.ndarray = None     # u32 [A, KMAX] bit k2 of row (a, k): the path of signal link k2 crosses or joins the path of link k
-                                     # inside the junction (junction interiors, DESIGN.md 3 rule 10); None = no junction has foes
+                                     # inside the junction (junction interiors, MICROSIM_SPEC.md rule 10); None = no junction has foes
     lane_sib: np.ndarray = None      # i32 [NL] the other lane of a two-lane street, -1 = none (None: the scenario has no lane changing,
-                                     # DESIGN.md 3 rule 10): a vehicle on a lane that does not serve its movement moves over to it
+                                     # MICROSIM_SPEC.md rule 10): a vehicle on a lane that does not serve its movement moves over to it
     lane_origin: np.ndarray = None   # f32 [NL] where the SUMO lane of that name begins inside the compiled lane (0 unless
                                      # contract_chains merged upstream pieces into it): `lane.*` TraCI getters count from here
 
@@ -399,7 +399,7 @@ def four_leg_foes():
 
 def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: int = 925,
                      sort_lanes: bool = True, init_density: float = 0.0, lane_change: bool = LANE_CHANGE_DEFAULT, **env_kw) -> Scenario:
-    # lane_change (DESIGN.md 3 rule 10): a hand-off enters the lane the junction's CONNECTION leads to (build_file.py:107-124:
+    # lane_change (MICROSIM_SPEC.md rule 10): a hand-off enters the lane the junction's CONNECTION leads to (build_file.py:107-124:
     # through and right turns lane 0 -> lane 0, a left turn from an avenue -> street lane 1); a vehicle that then stands on the
     # street lane its next movement does not use has to move over to the sibling lane inside the edge.  False: the vehicle is put
     # on the lane its next movement needs right at edge entry (rounds 1 - 4)
@@ -550,7 +550,7 @@ def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: in
     lane_det = np.where(lane_node >= 0, lane_len - DET_LEN, 0).astype(np.float32)
 
     def lane_choice(edge, r, via_mv, from_street):
-        """Lane a vehicle of route r takes when it enters `edge` (DESIGN.md
+        """Lane a vehicle of route r takes when it enters `edge` (MICROSIM_SPEC.md
         'lane choice at edge entry').  On the arrival edge the lane follows the
         reference's connection table (build_file.py:107-124)."""
         if edges[edge][2] == 1:
@@ -604,7 +604,7 @@ def build_large_grid(agent: str = 'ma2c', peak_flow1: int = 1100, peak_flow2: in
         assert len(ups) <= MAX_UP
         lane_up[l2, :len(ups)] = ups
 
-    # right of way (DESIGN.md microsim spec, rule 2): left turns yield to the opposing approach's lane-0 head
+    # right of way (MICROSIM_SPEC.md, rule 2): left turns yield to the opposing approach's lane-0 head
     # when that head goes right / through -- the only merge conflict the five phases admit
     opp = {'N': 'S', 'S': 'N', 'E': 'W', 'W': 'E'}
     mv_yield = np.full((NL, NR), -1, np.int32)
@@ -724,7 +724,7 @@ def build_real_net(agent: str = 'ma2c', flow_rate: int = 325, sort_lanes: bool =
     the whole lane (env.py:376-377, real_net_env.py:18); reward = -sum(min(10, halting))
     (env.py:332-333, objective queue); rewards / ((1+deg)*20) (env.py:599-601,625-629);
     --time-to-teleport 300 (env.py:283-284); every active flow at `flow_rate` veh/h.
-    Microsim-side choices: zero-length junctions, unsignalised junctions always open,
+    Microsim-side choices (MICROSIM_SPEC.md): zero-length junctions, unsignalised junctions always open,
     free lane choice at edge entry among the lanes that continue the route, no right-of-way table."""
     import json
     import os
@@ -799,7 +799,7 @@ def build_real_net(agent: str = 'ma2c', flow_rate: int = 325, sort_lanes: bool =
         ups = sorted({l for l in range(NL) if (mv_next[l] == l2).any()})
         assert len(ups) <= MAX_UP, 'lane %s has %d feeders' % (lane_names[l2], len(ups))
         lane_up[l2, :len(ups)] = ups
-    # zipper merge (DESIGN.md microsim spec): a lane with several feeders takes arrivals from feeder `rank`
+    # zipper merge (MICROSIM_SPEC.md): a lane with several feeders takes arrivals from feeder `rank`
     # only in seconds with (t + rank) % count == 0
     mv_zip = np.zeros((NL, NR), np.int32)
     for l in range(NL):
@@ -865,7 +865,7 @@ def build_real_net(agent: str = 'ma2c', flow_rate: int = 325, sort_lanes: bool =
 
 
 def contract_chains(scn: Scenario) -> Scenario:
-    """Merge 1-to-1 lane chains across unsignalised junctions (DESIGN.md microsim spec, "lane chains").
+    """Merge 1-to-1 lane chains across unsignalised junctions (MICROSIM_SPEC.md, "lane chains").
 
     SUMO splits Monaco's roads at every geometry node: half of the lanes a route uses are 2-30 m pieces in series.  With
     zero-length junctions, one lane hop per second and the room rule at lane entry such a chain is a far worse

@@ -87,7 +87,7 @@ typedef struct tsc_scenario {
     const int32_t *stream_choice;  /* [n_stream, n_interval, k_choice, 2]; the choices in force at second t: interval
                                     * min(t / choice_interval_sec, n_interval - 1) (time-variant turn ratios) */
     int32_t n_interval, choice_interval_sec;
-    /* Lane changing on two-lane streets (round 5; DESIGN.md 3 rule 10; SUMO's lane-change model behind simulationStep,
+    /* Lane changing on two-lane streets (round 5; MICROSIM_SPEC.md rule 10; SUMO's lane-change model behind simulationStep,
      * envs/env.py:464, with the reference's connection table large_grid/data/build_file.py:107-124): lane_sib[l] = the other lane
      * of lane l's edge or -1; NULL = none.  mv_next then names the lane a junction's CONNECTION enters; a vehicle standing on a
      * lane whose mv_next entry for its route is "not served" (< -1) while lane_sib[l] serves it moves over as a hand-off that keeps
@@ -209,7 +209,7 @@ int tsc_env_record(tsc_env *h, int32_t enable, int32_t trip_cap);
 int tsc_env_read_record(tsc_env *h, int64_t *ints_host, double *speed_host, int32_t *queue_host);
 /* Finished trips of instance e since reset(): rows {route, serial within the route, depart_sec, arrival_sec, waiting
  * seconds, waiting count}; *count = trips finished (may exceed max_trips / the capacity given to tsc_env_record).
- * A row with a NEGATIVE arrival_sec (= -second) is a trip the teleport surrogate truncated (DESIGN.md 3 rule 1): SUMO
+ * A row with a NEGATIVE arrival_sec (= -second) is a trip the teleport surrogate truncated (MICROSIM_SPEC.md rule 1): SUMO
  * would have moved that vehicle on and written its tripinfo later, so collect_tripinfo (envs/env.py:498-515) must not
  * count it as a finished trip. */
 int tsc_env_read_trips(tsc_env *h, int32_t e, int32_t *trips_host, int32_t max_trips, int32_t *count);

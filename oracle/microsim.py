@@ -104,14 +104,14 @@ class MicroSim:
         self.L.ms_reset(self.h, int(seed) & 0xFFFFFFFF)
 
     def set_box(self, p):
-        """EXPERIMENT (not the spec): a head with an open signal and a full target lane stands in the junction
+        """EXPERIMENT (MICROSIM_SPEC.md, not the spec): a head with an open signal and a full target lane stands in the junction
         (with probability p, drawn per vehicle) and blocks its foe links (Scenario.link_foes); 0 switches it off."""
         foes = np.ascontiguousarray(self.scn.link_foes, np.uint32)
         assert foes.shape == (self.scn.n_agent, self.kmax)
         self.L.ms_set_box(self.h, foes.ctypes.data_as(C.POINTER(C.c_uint32)), float(p))
 
     def set_lanechange(self, gap_front=None, gap_back=2.0):
-        """EXPERIMENT (DESIGN.md 3 "lane changing", not the spec; large_grid only): hand-offs enter the lane the junction's
+        """EXPERIMENT (MICROSIM_SPEC.md "lane changing", not the spec; large_grid only): hand-offs enter the lane the junction's
         connection leads to (large_grid/data/build_file.py:107-124: through and right turns lane 0 -> lane 0, a left turn
         from an avenue -> street lane 1) and a vehicle on the wrong lane of a two-lane street must change to its sibling lane
         inside the edge, gaps permitting (gap_front / gap_back metres + 1 s of the closing speed); None switches it off."""

@@ -23,12 +23,38 @@ def test_pmc_traffic_is_quoted_only_at_a_matching_vehicle_count():
         v = float(d['mean_live_vehicles_per_env'])
         k = d['kernels']['env_step']
         got, src = b.pmc_traffic('env_step', cfg, v * 1.1)
-        assert got == (k['fetch_kb'] + k['write_kb']) * 1024.0 and 'committed measurement' in src and 'whole episodes' in src
+        ff, fw, fsrc = b.fetch_calibration()            # the counters corrected by what the box reports on known 1-GiB streams
+        assert abs(got - (ff * k['fetch_kb'] + fw * k['write_kb']) * 1024.0) < 1.0 and 'committed measurement' in src and 'whole episodes' in src
+        assert 'FETCH_SIZE x' in src and fsrc.split()[0] in src
         got, why = b.pmc_traffic('env_step', cfg, v * 1.3)
         assert got is None and 'refused' in why and '15 %' in why
         got, why = b.pmc_traffic('env_step', cfg, v * 0.7)
         assert got is None and 'refused' in why
     assert b.pmc_traffic('env_step', 'q1', 600.0)[0] is None and b.pmc_traffic('env_step', None, 600.0)[0] is None
+
+
+def test_fetch_calibration_is_the_committed_one_and_sane():
+    """FETCH_SIZE / WRITE_SIZE are calibrated on known byte counts (tools/fetch_calib.hip); gfx950's rocprofv3
+    reports half the bytes of a streaming read (MI355X_MICROARCH.md) and exact writes."""
+    b = _bench()
+    ff, fw, src = b.fetch_calibration()
+    assert 'fetch_calibration.json' in src and 1.8 < ff < 2.2 and 0.9 < fw < 1.1
+    d = json.load(open(os.path.join(ROOT, 'profiles', '%s_fetch_calibration.json' % b.PROFILE_TAGS[0])))
+    assert d['known_bytes'] == 1 << 30 and set(d['fetch']) == {'read_dword', 'read_f4'} and 'write_f4_nt' in d['write']
+
+
+def test_iql_algorithmic_flops_count_the_block_diagonal_first_layer():
+    """bench.py:iql_algorithmic_flops (the q1 roofline): an inner large_grid agent (30 wave + 6 wait inputs, 5 actions) costs
+    2 x 14 592 MACs forward + 24 896 backward per row; structural zeros of W1 are not counted."""
+    b = _bench()
+
+    class Lay: n_fc0, ft, H1, H2 = 128, 32, 160, 64
+
+    class M: layout, n_wave_ls, n_w_ls, n_a_ls = Lay, [30], [6], [5]
+    fl = b.iql_algorithmic_flops(M, 10)
+    fwd = 30 * 128 + 6 * 32 + 160 * 64 + 64 * 5
+    bwd = 64 * 5 + 64 + 2 * 160 * 64 + 30 * 128 + 6 * 32
+    assert fl['iql_act'] == 2.0 * fwd * 10 and fl['iql_grad'] == 2.0 * (2 * fwd + bwd) * 10
 
 
 def test_rocprofv3_averages_come_from_the_configuration_s_own_trace():

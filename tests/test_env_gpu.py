@@ -245,7 +245,7 @@ def test_resident_instances_hint_changes_the_launch_shape_not_the_results():
 
 @pytest.mark.parametrize('threads,spec,help_', [('256', '1', '1'), ('512', '1', '1'), ('1024', '1', '1'), ('256', '0', '1'), ('256', '1', '0')])
 def test_lane_change_rule_vs_oracle(threads, spec, help_, monkeypatch):
-    """DESIGN.md 3 rule 10 (lane choice by the junction's connections + lane changes on the two-lane streets, lane_change=True):
+    """MICROSIM_SPEC.md rule 10 (lane choice by the junction's connections + lane changes on the two-lane streets, lane_change=True):
     the step kernel against the CPU oracle over a whole greedy-driven episode of four instances -- obs, rewards, done, and
     the complete vehicle state at the demand peak and at the end -- with lane changers in the head platoons, wrong-lane heads
     lining up behind the sibling's queue, teleported changers, for every workgroup size, with and without the compile-time

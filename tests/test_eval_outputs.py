@@ -126,7 +126,7 @@ def test_window_mean_live_vehicles():
 
 @pytest.mark.gpu
 def test_teleported_trips_are_counted_apart_from_arrivals():
-    """A full greedy Monaco episode starves a few heads for time-to-teleport seconds: the teleport surrogate
+    """A full greedy Monaco episode starves a few heads for time-to-teleport seconds (MICROSIM_SPEC.md): the teleport surrogate
     takes them out of the network.  They are truncated trips, not arrivals: the device counters, the per-second
     number_arrived_car and the trip table (like SUMO's tripinfo file) leave them out and report them apart; the oracle
     agrees on every figure."""

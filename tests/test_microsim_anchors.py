@@ -1,4 +1,4 @@
-"""Statistical gate of the microsimulator spec against the only published anchors of the
+"""Statistical gate of the microsimulator spec (MICROSIM_SPEC.md) against the only published anchors of the
 reference's SUMO runs: the greedy controllers' mean step reward and, for Monaco, the aggregates of the
 authors' evaluation tables.  SUMO itself is absent, the dynamics are this repo's spec -- the bands below are what the spec
 produces today (regression gate), next to the published numbers:
@@ -7,12 +7,12 @@ produces today (regression gate), next to the published numbers:
                                                                       -66 with every vehicle put on its needed lane, rounds 1 - 4)
   Monaco greedy       published  -41.8  (real_net_experimental_data)  this spec ~ -37   (round 3; -169 in round 2)
 
-Round 3 changed the spec: merge arbitration by readiness, a teleport surrogate that removes a
+Round 3 changed the spec (MICROSIM_SPEC.md): merge arbitration by readiness, a teleport surrogate that removes a
 blocked head after time-to-teleport, headway 1.0 s, and a standstill gap of 2.0 m (SUMO's minGap is 2.5 m, but its junction
 interiors store vehicles that this spec's zero-length junctions put on the edges).  Monaco under the reference's greedy
 controller sits on a regime boundary in that gap: at >= 2.2 m the network spills back into starved shared lanes (1200 - 1600
 trips, 2.7 m/s, -135 ... -160), at <= 2.0 m it flows (2250 trips, 4.5 m/s, 48 s mean wait, -37 on three seeds).  large_grid
-does not move with the gap (-66.5 -> -66.2); what was missing there is lane choice (round 5, DESIGN.md 3 rule 10)."""
+does not move with the gap (-66.5 -> -66.2); what was missing there is lane choice (round 5, MICROSIM_SPEC.md rule 10)."""
 import numpy as np
 
 from deeprl_signal_control_amd.scenario import build_large_grid, build_real_net
@@ -34,7 +34,7 @@ def _episode(scn, seed, act):
 
 
 def test_large_grid_greedy_band():
-    """Round 5: with rule 10 (lane choice by the junction's connections + lane changes on the two-lane streets)
+    """Round 5: with rule 10 (lane choice by the junction's connections + lane changes on the two-lane streets, MICROSIM_SPEC.md)
     the greedy run is a congested, partly gridlocking regime like the authors' -- seeds 10000 / 20000 / 30000 / 40000 give
     -715 / -758 / -396 / -424 (83 - 95 % of the demand arrives, 13 - 45 teleports) against the published -972.28; without
     the rule (rounds 1 - 4: every vehicle is put on the lane its next movement needs at edge entry) it was -66."""
@@ -79,7 +79,7 @@ def test_monaco_greedy_band():
 
 
 # Aggregates of real_net_experimental_data/eva_data/real_net_greedy_{traffic,trip,control}.csv (10 evaluation episodes of
-# the authors' SUMO run): the statistical counterpart of the evaluation tables this repo writes (DESIGN.md 8f-2).
+# the authors' SUMO run): the statistical counterpart of the evaluation tables this repo writes (SURVEY.md 8f-2).
 PUBLISHED_MONACO_GREEDY = dict(avg_queue=0.51, avg_speed_mps=6.06, avg_wait_sec=65.5, peak_cars=322, trips=1945,
                                trip_duration_sec=238.0, reward=-41.8)
 
@@ -118,7 +118,7 @@ def test_monaco_greedy_eval_tables_vs_published():
 
 
 def test_junction_box_experiment_blocks_foe_links():
-    """the junction-interior experiment of round 4 (oracle/microsim.c ms_set_box, OFF in the spec; DESIGN.md 3
+    """the junction-interior experiment of round 4 (oracle/microsim.c ms_set_box, OFF in the spec; MICROSIM_SPEC.md
     "junction interiors", tools/sweep_junction_box.py -> profiles/r04_junction_box_sweep.json) has a producer (a head that enters a
     full junction sets its link's bit in blocked[]) AND a consumer (a head whose link has a foe among the blocked ones holds):
     with p = 1 vehicles stand in junctions (n_box > 0) and the run differs from p = 0; p = 0 is the spec, bit for bit."""

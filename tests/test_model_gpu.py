@@ -447,6 +447,7 @@ def _read_cache(m, what, g, row0, nrows, width):
     ('large_grid', 'ma2c', 200, '1'),       # ragged: 13 half tiles over 5 workgroups (2 / 3 / 2 / 3 / 3), the last one holds 8 instances
     ('large_grid', 'ma2c', 1000, '1'),      # 63 half tiles: 12 / 13 / 12 / 13 / 13, the last one 8 instances
     ('large_grid', 'ma2c', 48, '1'),        # one workgroup per tower: a full tile + a half tile
+    ('large_grid', 'ma2c', 240, '1'),       # 15 half tiles over 5 workgroups, 3 each: EVERY split ends in a half tile
     ('large_grid', 'ma2c', 16, '1'),        # nothing but a half tile
     ('large_grid', 'ia2c', 1024, '1'),      # H = 160 instantiation
     ('large_grid', 'ma2c', 200, '0'),       # TSC_FWD_WS=0: policy_fwd_fused_kernel, ragged 64-instance tile

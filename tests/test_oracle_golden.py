@@ -174,7 +174,7 @@ def test_live_lanes_are_a_prefix_after_load_sorting(name):
 
 
 def test_chain_clamp_closed_form_equals_the_recurrence():
-    """DESIGN.md section 3 rule 4 / ADVICE r02: the queue clamp behind the first vehicle that stays is evaluated as an
+    """MICROSIM_SPEC.md rule 4 / ADVICE r02: the queue clamp behind the first vehicle that stays is evaluated as an
     exclusive prefix-min over keys (x'_i = max(x_i, min(a_i, K_{i-1} - 5 i)), K_i = min(K_{i-1}, a_i + 5 i)) so that the HIP
     kernel can scan it.  On random queues it equals the sequential recurrence x'_i = max(x_i, min(a_i, x'_{i-1} - 5)): with the
     spec's invariant (old spacing >= 5 m, nobody moves backward) the no-backward clamp never binds -- x'_{i-1} - 5 >= x_{i-1} - 5

@@ -68,7 +68,7 @@ def test_capacity_limits_are_refused_not_truncated():
 
 
 def test_foe_tables_of_the_junction_experiment():
-    """Scenario.link_foes (DESIGN.md 3 "Junction interiors": data of a round-4 experiment on the CPU oracle, not consumed by the
+    """Scenario.link_foes (MICROSIM_SPEC.md "Junction interiors": data of a round-4 experiment on the CPU oracle, not consumed by the
     device library).  Four-leg grid junctions: chord crossing over netconvert's link order -- symmetric, no link is its own
     foe, links of one approach are never foes, a right turn only meets the two streams that join its target, the opposing
     through streams do not conflict, a permissive left crosses the opposing through.  Monaco: the junctions' own

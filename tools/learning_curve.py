@@ -8,7 +8,7 @@ global reward, averaged over the env instances -- the quantity of figs/large_gri
     python tools/learning_curve.py --episodes 50 --envs 1024 --out profiles/r03_learning_curve.json
 
 Every instance sees its own demand seed per episode (seed0 + e, stride E per episode), every instance explores with its
-own action stream, all share one set of weights.  The simulator underneath is this repo's microsim spec:
+own action stream, all share one set of weights.  The simulator underneath is this repo's microsim spec (MICROSIM_SPEC.md):
 absolute reward levels are not SUMO's, the trend is what this shows."""
 import argparse
 import json
@@ -91,7 +91,7 @@ def main():
     ap.add_argument('--agent', default='ma2c')
     ap.add_argument('--lr', type=float, default=None)
     ap.add_argument('--policy', default='lstm', choices=['lstm', 'fc'], help='fc = FcACPolicy (ia2c only; BASELINE configs[1])')
-    ap.add_argument('--lane-change', type=int, default=None, help='large_grid: 1 / 0 = with / without DESIGN.md 3 rule 10 (default: the scenario default)')
+    ap.add_argument('--lane-change', type=int, default=None, help='large_grid: 1 / 0 = with / without MICROSIM_SPEC.md rule 10 (default: the scenario default)')
     ap.add_argument('--test-seeds', default=None, help='comma-separated evaluation seeds (default: the config\'s test_seeds)')
     ap.add_argument('--out', default=None)
     args = ap.parse_args()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Round-4 experiment behind DESIGN.md section 3 ("junction interiors"): does a junction-blocking mechanism move the greedy
+"""Round-4 experiment behind MICROSIM_SPEC.md ("junction interiors"): does a junction-blocking mechanism move the greedy
 large_grid run towards the authors' SUMO figure (-972.28, result_plot.ipynb:188) while Monaco stays in its band (-41.8)?
 
 The mechanism lives in the CPU oracle only (oracle/microsim.c ms_set_box, OFF by default and not part of the spec): a lane head

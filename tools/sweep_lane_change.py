@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Round-5 experiment behind DESIGN.md section 3 ("lane changing"): does lane choice on large_grid's two-lane streets -- hand-offs
+"""Round-5 experiment behind MICROSIM_SPEC.md ("lane changing"): does lane choice on large_grid's two-lane streets -- hand-offs
 that enter the lane the junction's connection leads to, and a gap-acceptance lane change inside the 200-m edge -- move the greedy
 large_grid run from this spec's -66 towards the authors' -972 (result_plot.ipynb:188)?  CPU oracle only (oracle/microsim.c,
 ms_set_lanechange: off by default, the spec is unchanged).  One greedy episode per (gaps, seed).
