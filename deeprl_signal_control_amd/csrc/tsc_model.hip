@@ -216,6 +216,10 @@ __global__ void __launch_bounds__(256, PF ? 1 : 2) lstm_fwd_kernel(const float *
 // Measured (tools/bench_update.py, E = 1024, T = 120): 4.13 ms (round 2) -> 4.02 (16-column waves, dword accesses)
 // -> 3.60 (c_t from registers) -> 3.39 ms: 2.56 KB per sample and tower (gates in, dz out, c_prev, dH) = 15.7 GB per update
 // at 4.6 TB/s.  Three workgroups per CU (168 VGPRs, 4 spilled) measured the same (3.35 ms); 64-instance tiles spill.
+// Round 6 (under rule 10's batches the kernel had drifted to 3.8 ms): the inputs are requested TWO steps ahead (two register sets):
+// 3.82 -> 3.57 - 3.70 ms.  An eight-wavefront variant (512 threads, a thread owns four units, a wavefront half of the contraction: 64
+// MFMAs per step, 16 wavefronts per CU) measured the same 3.62 ms and was removed: at 15.5 GB of mixed read / write traffic per
+// launch the kernel sits at 4.3 TB/s whatever the per-step latency chain looks like.
 // ------------------------------------------------------------------------------------------------
 constexpr int kDz2Ld = kG4 + 4;   // dz tile [32 env][256 k + 4]
 constexpr int kDh3Ld = kL + 4;    // recurrent dh tile [32 env][64 units + 4]
@@ -247,10 +251,13 @@ __global__ void __launch_bounds__(256, 2) lstm_bwd2_kernel(const float *__restri
     const float *sg = state_bw + (long long)g * E * 2 * kL;
     const int e = e0 + er < E ? e0 + er : E - 1;
     const bool live = e0 + er < E;
-    float4 gi[2], gf[2], go[2], gu[2], cc[2], cpv[2], dhi[2];
-    float keep = 0.f, keep_next = 0.f;              // keep of the step being processed / of the step processed before it (t + 1)
-    // c_t of step t is the c_{t-1} the step after it (t + 1, processed before) asked for (`first`: step T - 1 loads both)
-    auto request = [&](int t, bool first) {
+    // The inputs of a step are requested TWO steps ahead (round 6; one step ahead before: the request went out behind the step's
+    // first barrier and had the 64 MFMAs of one step -- ~ 2 us with the co-resident workgroup's -- to land, less than a loaded HBM
+    // round trip): two register sets, alternating by step parity.
+    struct In { float4 gi[2], gf[2], go[2], gu[2], dhi[2], cpv[2]; float keep; };
+    In in0, in1;
+    float4 cc[2];                                   // c_t of the step about to be processed = the c_{t-1} the step after it asked for
+    auto request = [&](int t, In &o) {
         const long long nt = (long long)t * E;
         const float *zt = zg + nt * kG4, *ct = cg + nt * kL, *ht = hg + nt * kL;
         const float *cp_base = t > 0 ? ct - (long long)E * kL : sg;         // c_{t-1}: Cc[t-1] ([e][64]) or the state ([e][128])
@@ -260,20 +267,24 @@ __global__ void __launch_bounds__(256, 2) lstm_bwd2_kernel(const float *__restri
         const unsigned oz = (unsigned)((e + zq) * kG4 + u0) * 4u, oc = (unsigned)((e + zq) * kL + u0) * 4u;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            gi[a] = ldg((const float4 *)zt, oz + 16u * a); gf[a] = ldg((const float4 *)zt, oz + 256u + 16u * a);
-            go[a] = ldg((const float4 *)zt, oz + 512u + 16u * a); gu[a] = ldg((const float4 *)zt, oz + 768u + 16u * a);
-            if (first) cc[a] = ldg((const float4 *)ct, oc + 16u * a);
-            else cc[a] = cpv[a];
-            dhi[a] = ldg((const float4 *)ht, oc + 16u * a);
-            cpv[a] = ldg((const float4 *)cp_base, (unsigned)((e + zq) * cp_ld + u0) * 4u + 16u * a);
+            o.gi[a] = ldg((const float4 *)zt, oz + 16u * a); o.gf[a] = ldg((const float4 *)zt, oz + 256u + 16u * a);
+            o.go[a] = ldg((const float4 *)zt, oz + 512u + 16u * a); o.gu[a] = ldg((const float4 *)zt, oz + 768u + 16u * a);
+            o.dhi[a] = ldg((const float4 *)ht, oc + 16u * a);
+            o.cpv[a] = ldg((const float4 *)cp_base, (unsigned)((e + zq) * cp_ld + u0) * 4u + 16u * a);
         }
-        keep_next = keep;
-        keep = done[nt + e] == 0 ? 1.0f : 0.0f;
+        o.keep = done[nt + e] == 0 ? 1.0f : 0.0f;
     };
-    request(T - 1, true);
-    for (int t = T - 1; t >= 0; --t) {
+    {   // c_{T-1} itself: nobody asked for it as a c_{t-1}
+        const float *ct = cg + (long long)(T - 1) * E * kL;
+        cc[0] = ldg((const float4 *)ct, (unsigned)(e * kL + u0) * 4u); cc[1] = ldg((const float4 *)ct, (unsigned)(e * kL + u0) * 4u + 16u);
+    }
+    request(T - 1, in0);
+    if (T > 1) request(T - 2, in1);
+    float keep_next = 0.f;                          // keep of the step processed before (t + 1)
+    auto step = [&](int t, In &cur) {
         const long long nt = (long long)t * E;
         float *zw = Z + ((long long)g * N + nt) * kG4;
+        const float keep = cur.keep;
         // recurrent dh of this thread's pairs: what the MFMA phase of step t + 1 left in LDS, cut where step t + 1 began an episode
         float4 dhr[2];
         if (t == T - 1) { dhr[0] = dhr[1] = make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -283,10 +294,10 @@ __global__ void __launch_bounds__(256, 2) lstm_bwd2_kernel(const float *__restri
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            const float igv[4] = {gi[a].x, gi[a].y, gi[a].z, gi[a].w}, fgv[4] = {gf[a].x, gf[a].y, gf[a].z, gf[a].w};
-            const float ogv[4] = {go[a].x, go[a].y, go[a].z, go[a].w}, ugv[4] = {gu[a].x, gu[a].y, gu[a].z, gu[a].w};
-            const float ccv[4] = {cc[a].x, cc[a].y, cc[a].z, cc[a].w}, cpw[4] = {cpv[a].x, cpv[a].y, cpv[a].z, cpv[a].w};
-            const float dhv[4] = {dhi[a].x, dhi[a].y, dhi[a].z, dhi[a].w}, drv[4] = {dhr[a].x, dhr[a].y, dhr[a].z, dhr[a].w};
+            const float igv[4] = {cur.gi[a].x, cur.gi[a].y, cur.gi[a].z, cur.gi[a].w}, fgv[4] = {cur.gf[a].x, cur.gf[a].y, cur.gf[a].z, cur.gf[a].w};
+            const float ogv[4] = {cur.go[a].x, cur.go[a].y, cur.go[a].z, cur.go[a].w}, ugv[4] = {cur.gu[a].x, cur.gu[a].y, cur.gu[a].z, cur.gu[a].w};
+            const float ccv[4] = {cc[a].x, cc[a].y, cc[a].z, cc[a].w}, cpw[4] = {cur.cpv[a].x, cur.cpv[a].y, cur.cpv[a].z, cur.cpv[a].w};
+            const float dhv[4] = {cur.dhi[a].x, cur.dhi[a].y, cur.dhi[a].z, cur.dhi[a].w}, drv[4] = {dhr[a].x, dhr[a].y, dhr[a].z, dhr[a].w};
             float di[4], df[4], dg[4], du[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -314,8 +325,10 @@ __global__ void __launch_bounds__(256, 2) lstm_bwd2_kernel(const float *__restri
             *reinterpret_cast<float4 *>(row + 128) = o_do; *reinterpret_cast<float4 *>(row + 192) = o_du;
             __builtin_amdgcn_sched_barrier(0);       // the two halves one after the other (registers)
         }
+        cc[0] = cur.cpv[0]; cc[1] = cur.cpv[1];     // this step's c_{t-1} is the next step's c_t
+        keep_next = keep;
         __syncthreads();
-        if (t > 0) request(t - 1, false);           // in flight under the MFMAs below
+        if (t > 1) request(t - 2, cur);             // two steps ahead, into the set this step just freed
         f32x4 acc[2];
         acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float4 *Aa = reinterpret_cast<const float4 *>(dzs + n * kDz2Ld + 4 * kq), *Ab = Aa + (16 * kDz2Ld) / 4;
@@ -341,6 +354,10 @@ __global__ void __launch_bounds__(256, 2) lstm_bwd2_kernel(const float *__restri
 #pragma unroll
             for (int i = 0; i < 4; ++i) dhs[(16 * rt + 4 * kq + i) * kDh3Ld + j] = acc[rt][i];
         __syncthreads();
+    };
+    for (int t = T - 1; t >= 0; t -= 2) {
+        step(t, in0);
+        if (t >= 1) step(t - 1, in1);
     }
 }
 
