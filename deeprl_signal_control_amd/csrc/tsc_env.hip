@@ -402,7 +402,22 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
     const bool lthr = l < NLA;              // threads >= NLA only help in phase A1 and in the strided loops
     const bool stamp = P.dbg && blockIdx.x == 0 && threadIdx.x == 0;
     int nstamp = 0;
+    // A measurement build (-DTSC_ENV_PHASE_SUMS, tools/build_variant.sh) also lets every workgroup's thread 0 sum its shader-clock
+    // cycles per kind of phase (tsc_env_debug_clock enable == 3): bucket 0 prologue + epilogue, 1 head walk, 2 flat phase, 3 gather +
+    // demand, 4 the barriers between them.  Not in the product build: the sums live in registers over the whole kernel (25 spilled
+    // dwords in the benchmarked instantiation).
+#ifdef TSC_ENV_PHASE_SUMS
+    const bool wsum = P.dbg && threadIdx.x == 0;
+    long long pacc_[5] = {0, 0, 0, 0, 0}, wprev = 0;
+    int wk = 0;
+#define TSC_STAMP() do { if (stamp && nstamp < 62) P.dbg[nstamp++] = clock64();                                        \
+        if (wsum) { const long long now_ = clock64();                                                                    \
+            if (wk > 0) { const int d_ = wk - 1, r_ = (d_ - 1) % 6;                                                       \
+                const int b_ = (d_ == 0 || d_ > 30) ? 0 : (r_ == 0 ? 1 : r_ == 2 ? 2 : r_ == 4 ? 3 : 4); pacc_[b_] += now_ - wprev; } \
+            wprev = now_; ++wk; } } while (0)
+#else
 #define TSC_STAMP() do { if (stamp && nstamp < 62) P.dbg[nstamp++] = clock64(); } while (0)
+#endif
     TSC_STAMP();
     if (P.dbg && threadIdx.x == 0) P.dbg[64 + 2 * blockIdx.x] = wall_clock64();
     float4 *S = P.S + (size_t)e * kCap * NLP;
@@ -443,8 +458,17 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
             for (int u = 0; u < 4; ++u) { const int i = base + u * (int)blockDim.x; if (i < count) dst[i] = w[u]; }
         }
     };
-    copy_words((uint32_t *)s.mv, (const uint32_t *)P.mv, P.NU * NR);
-    copy_words((uint32_t *)s.zip, (const uint32_t *)P.zip, (P.NU * NR + 3) / 4);      // padded to 4 B
+    // Round 6: the first 8 / 4 words per thread of the two tables are REQUESTED here, next to the level-1 loads, and stored behind the
+    // level-2 requests (one memory round trip for both tables instead of one per 4-word round: three on large_grid -- the workgroup is a
+    // latency chain, 64 us alone on a CU against 80 us with three neighbours, so a round trip is ~ 1 % of the step); what does not fit
+    // (no reference scenario) takes the loop.
+    constexpr int kTW = 8, kTZ = 4;
+    const int n_mv = P.NU * NR, n_zip = (P.NU * NR + 3) / 4;                            // zip padded to 4 B
+    uint32_t tw[kTW], tz[kTZ];
+#pragma unroll
+    for (int u = 0; u < kTW; ++u) { const int i = l + u * (int)blockDim.x; tw[u] = ((const uint32_t *)P.mv)[i < n_mv ? i : n_mv - 1]; }
+#pragma unroll
+    for (int u = 0; u < kTZ; ++u) { const int i = l + u * (int)blockDim.x; tz[u] = ((const uint32_t *)P.zip)[i < n_zip ? i : n_zip - 1]; }
     // level 2 (needs n / act / t), issued before the remaining LDS fills
     float hx = 0, hv = 0, hsf = 0, tx = 0, tv = 0; uint32_t hm = 0;      // head record (slot 0) / tail of my lane, kept in registers
     {
@@ -454,6 +478,12 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         const float2 al = *(const float2 *)(S + sl);
         if (n > 0) { hx = a0.x; hv = a0.y; hsf = a0.z; hm = __float_as_uint(a0.w); tx = al.x; tv = al.y; }
     }
+#pragma unroll
+    for (int u = 0; u < kTW; ++u) { const int i = l + u * (int)blockDim.x; if (i < n_mv) ((uint32_t *)s.mv)[i] = tw[u]; }
+#pragma unroll
+    for (int u = 0; u < kTZ; ++u) { const int i = l + u * (int)blockDim.x; if (i < n_zip) ((uint32_t *)s.zip)[i] = tz[u]; }
+    if (n_mv > kTW * (int)blockDim.x) copy_words((uint32_t *)s.mv + kTW * blockDim.x, (const uint32_t *)P.mv + kTW * blockDim.x, n_mv - kTW * (int)blockDim.x);
+    if (n_zip > kTZ * (int)blockDim.x) copy_words((uint32_t *)s.zip + kTZ * blockDim.x, (const uint32_t *)P.zip + kTZ * blockDim.x, n_zip - kTZ * (int)blockDim.x);
     // K1: signal FSM (envs/env.py:128-152) -> link chars for the yellow and the green interval
     if (ag) {
         P.prev_action[(size_t)e * P.A + l] = act;
@@ -1172,6 +1202,12 @@ step_kernel(EnvDev P, const int *__restrict__ action, float *__restrict__ obs, d
         reward[(size_t)e * P.A + a] = out;
     }
     TSC_STAMP();
+#ifdef TSC_ENV_PHASE_SUMS
+    if (wsum) {
+#pragma unroll
+        for (int b_ = 0; b_ < 5; ++b_) P.dbg[64 + 2 * (size_t)P.E + 5 * (size_t)blockIdx.x + b_] = pacc_[b_];
+    }
+#endif
     if (stamp) P.dbg[63] = nstamp;
     if (P.dbg && threadIdx.x == 0) {
         unsigned hwid, xcc;
@@ -1820,13 +1856,13 @@ int tsc_env_debug_clock(tsc_env *h, int32_t enable, int64_t *stamps64_host) {
     TSC_HIP(hipStreamSynchronize(h->stream));
     if (enable && !h->P.dbg) {
         long long *d = nullptr;
-        TSC_HIP(hipMalloc((void **)&d, (64 + 2 * (size_t)h->P.E) * sizeof(long long)));
-        TSC_HIP(hipMemset(d, 0, (64 + 2 * (size_t)h->P.E) * sizeof(long long)));
+        TSC_HIP(hipMalloc((void **)&d, (64 + 7 * (size_t)h->P.E) * sizeof(long long)));
+        TSC_HIP(hipMemset(d, 0, (64 + 7 * (size_t)h->P.E) * sizeof(long long)));
         h->allocs.push_back(d);
         h->P.dbg = d;
     }
     if (stamps64_host && h->P.dbg)
-        TSC_HIP(hipMemcpy(stamps64_host, h->P.dbg, (enable == 2 ? 64 + 2 * (size_t)h->P.E : 64) * sizeof(long long), hipMemcpyDeviceToHost));
+        TSC_HIP(hipMemcpy(stamps64_host, h->P.dbg, (enable == 3 ? 64 + 7 * (size_t)h->P.E : enable == 2 ? 64 + 2 * (size_t)h->P.E : 64) * sizeof(long long), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -179,7 +179,9 @@ int tsc_env_get_state(tsc_env *h, int32_t e, int32_t *n, float *x, float *v, flo
 /* Tuning aid: shader-clock stamps (s_memtime) taken by workgroup 0 / thread 0 of the last step at
  * every phase boundary; stamps[63] = number of stamps. enable != 0 allocates the buffer; enable == 2 also
  * returns [64 + 2e], [64 + 2e + 1] = constant-rate (100 MHz) start / end time of workgroup e (host buffer of
- * 64 + 2E entries). */
+ * 64 + 2E entries); enable == 3 also [64 + 2E + 5e + b] = shader-clock cycles workgroup e spent in phase kind b (0 prologue +
+ * epilogue, 1 head walk, 2 flat phase, 3 gather + demand, 4 the barriers between them; host buffer of 64 + 7E entries; zeros unless
+ * the library was built with -DTSC_ENV_PHASE_SUMS, tools/build_variant.sh). */
 int tsc_env_debug_clock(tsc_env *h, int32_t enable, int64_t *stamps64_host);
 
 /* Tuning aids of the simulator's launch geometry.  tsc_env_vehicle_counts: vehicles in the network of every instance (host int32

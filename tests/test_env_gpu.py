@@ -290,3 +290,35 @@ def test_lane_change_rule_vs_oracle(threads, spec, help_, monkeypatch):
     assert [int(x) for x in arrived] == [x['arrived'] for x in tot] and [int(x) for x in teleported] == [x['teleported'] for x in tot]
     assert sum(o.ms.lanechange_counts()['changes'] for o in orc) > 2000 and sum(x['teleported'] for x in tot) > 0
     env.close()
+
+
+def test_block_order_never_changes_a_result():
+    """tsc_env_set_block_order (round 6 tuning hook): which workgroup simulates which instance is a launch-geometry choice; obs,
+    rewards, dones and the per-instance vehicle counts of a run under a random permutation equal the identity run's bit for bit,
+    and a non-permutation is refused."""
+    import ctypes as C
+    from deeprl_signal_control_amd import _lib
+    from deeprl_signal_control_amd.env import VecTrafficEnv
+    scn = build_large_grid('ma2c', episode_length_sec=600)
+    E = 48
+    envs = [VecTrafficEnv(scn, E, seed=5) for _ in range(2)]
+    perm = np.random.RandomState(3).permutation(E).astype(np.int32)
+    _lib.check(envs[1]._L.tsc_env_set_block_order(envs[1]._h, perm.ctypes.data_as(C.c_void_p)))
+    bad = perm.copy(); bad[0] = bad[1]
+    assert envs[1]._L.tsc_env_set_block_order(envs[1]._h, bad.ctypes.data_as(C.c_void_p)) != 0
+    obs = [e.reset().clone() for e in envs]
+    assert torch.equal(obs[0], obs[1])
+    g = torch.Generator(device='cuda'); g.manual_seed(0)
+    for t in range(120):
+        act = torch.randint(0, 5, (E, 25), generator=g, device='cuda', dtype=torch.int32)
+        outs = [e.step(act) for e in envs]
+        for a, b in zip(outs[0][:3], outs[1][:3]):
+            assert torch.equal(a, b), t
+    cnt = [np.zeros(E, np.int32) for _ in envs]
+    for e, c in zip(envs, cnt):
+        _lib.check(e._L.tsc_env_vehicle_counts(e._h, c.ctypes.data_as(C.c_void_p)))
+    np.testing.assert_array_equal(cnt[0], cnt[1])
+    assert cnt[0].min() > 0 and abs(cnt[0].mean() - envs[0].mean_live_vehicles()) < 1e-9
+    _lib.check(envs[1]._L.tsc_env_set_block_order(envs[1]._h, None))
+    for e in envs:
+        e.close()

@@ -83,6 +83,22 @@ out['placement_groups'] = len(groups)
 out['placement_examples'] = [v for _, v in sorted(groups.items())[:6]]
 out['b_mod8_is_xcc'] = bool(all(int(xcc[b]) == int(xcc[b % 8]) for b in range(E)))
 
+# per-workgroup cycles by phase kind: what makes the slow workgroups slow?
+buf = (C.c_int64 * (64 + 7 * E))()
+_lib.check(env._L.tsc_env_debug_clock(env._h, 3, None))
+for i in range(3):
+    env.step(acts[i])
+torch.cuda.synchronize()
+_lib.check(env._L.tsc_env_debug_clock(env._h, 3, buf))
+ph = np.array(buf[64 + 2 * E:], dtype=np.int64).reshape(E, 5)
+tot = ph.sum(1)
+order_ = np.argsort(tot)
+names = ['pro+epilogue', 'head walk', 'flat phase', 'gather', 'barriers']
+sl = {'fastest 10 %': order_[:E // 10], 'median 10 %': order_[E // 2 - E // 20:E // 2 + E // 20], 'slowest 10 %': order_[-E // 10:]}
+out['phase_cycles'] = {k: {n_: float(ph[idx, j].mean()) for j, n_ in enumerate(names)} | {'total': float(tot[idx].mean()), 'vehicles': float(counts()[idx].mean())}
+                       for k, idx in sl.items()}
+out['phase_corr_with_total'] = {n_: float(np.corrcoef(ph[:, j], tot)[0, 1]) for j, n_ in enumerate(names)}
+
 rank = np.argsort(-c, kind='stable')            # heaviest first
 res = {}
 res['identity'] = timed(steps)
@@ -108,4 +124,5 @@ set_order(rng.permutation(E)); res['random'] = timed(steps)
 set_order(None); res['identity_again'] = timed(steps)
 out['us_per_step'] = res
 print(json.dumps(out))
+print(json.dumps(out['phase_cycles'], indent=1), file=sys.stderr)
 env.close()
