@@ -46,6 +46,7 @@ def lib():
         L.ms_set_box.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_double]
         L.ms_box_count.argtypes = [C.c_void_p]
         L.ms_box_count.restype = C.c_int64
+        L.ms_set_krauss.argtypes = [C.c_int, C.c_double]
         L.ms_set_lanechange.argtypes = [C.c_void_p, ip, ip, ip, C.c_double, C.c_double]
         L.ms_lanechange_counts.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.ms_set_sibling.argtypes = [C.c_void_p, ip]
