@@ -36,8 +36,18 @@ def run(episodes, n_env, scenario='large_grid', agent='ma2c', seed=0, lr=None, l
     if lr is not None:
         mcfg['lr_init'] = lr
     env = VecTrafficEnv(scn, n_env, device=0, seed=seed0, **({'test_seeds': tuple(test_seeds)} if test_seeds else {}))
-    model = VecA2C(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, scn.n_f_ls, n_env, scn.s_max, int(scn.green_tab.shape[1]), mcfg,
-                   device=0, seed=seed, name=agent, policy=policy)
+    is_q = agent in ('iqld', 'iqll')
+    if is_q:
+        # config/config_iql{d,l}_large.ini; total_step = the run's control steps (epsilon decays linearly to its floor over the first half)
+        from deeprl_signal_control_amd.iql import VecIQL
+        qcfg = dict(batch_size=20, buffer_size=1000, reward_norm=3000.0 if scenario == 'large_grid' else 1.0)
+        if lr is not None:
+            qcfg['lr_init'] = lr
+        model = VecIQL(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, n_env, scn.s_max, int(scn.green_tab.shape[1]), qcfg,
+                       total_step=episodes * int(env.T), device=0, seed=seed, model_type='dqn' if agent == 'iqld' else 'lr')
+    else:
+        model = VecA2C(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, scn.n_f_ls, n_env, scn.s_max, int(scn.green_tab.shape[1]), mcfg,
+                       device=0, seed=seed, name=agent, policy=policy)
     tr = VecTrainer(env, model, log_rewards=True)
     rows = []
     T = int(env.T)
@@ -47,7 +57,7 @@ def run(episodes, n_env, scenario='large_grid', agent='ma2c', seed=0, lr=None, l
         tr._ep_rewards = []
         while True:
             finished, R = tr.explore()
-            model.backward(R)
+            model.backward() if is_q else model.backward(R)
             if finished:
                 env.terminate()
                 break
@@ -88,7 +98,7 @@ def main():
     ap.add_argument('--episodes', type=int, default=50)
     ap.add_argument('--envs', type=int, default=1024)
     ap.add_argument('--scenario', default='large_grid')
-    ap.add_argument('--agent', default='ma2c')
+    ap.add_argument('--agent', default='ma2c', help='ma2c | ia2c | iqld | iqll (the IQL agents: epsilon-greedy exploration, replay rings, Adam)')
     ap.add_argument('--lr', type=float, default=None)
     ap.add_argument('--policy', default='lstm', choices=['lstm', 'fc'], help='fc = FcACPolicy (ia2c only; BASELINE configs[1])')
     ap.add_argument('--lane-change', type=int, default=None, help='large_grid: 1 / 0 = with / without MICROSIM_SPEC.md rule 10 (default: the scenario default)')
