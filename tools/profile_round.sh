@@ -23,6 +23,7 @@ cd /tmp && export TMPDIR=/tmp
 for C in $CFGS; do
   if [ $C = cal ]; then
     # 0. the counters on known byte counts (tools/fetch_calib.hip: 1-GiB streams, dword and 16 B per lane), one counter per pass
+    [ -x $ROOT/tools/fetch_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $ROOT/tools/fetch_calib $ROOT/tools/fetch_calib.hip
     rocprofv3 --pmc FETCH_SIZE -d $OUT/${TAG}_cal_f -o f -- $ROOT/tools/fetch_calib > /dev/null 2> $OUT/${TAG}_cal_f.err
     rocprofv3 --pmc WRITE_SIZE -d $OUT/${TAG}_cal_w -o w -- $ROOT/tools/fetch_calib > /dev/null 2> $OUT/${TAG}_cal_w.err
     python $ROOT/tools/fetch_calib.py $(find $OUT/${TAG}_cal_f -name "*.db" | head -1) $(find $OUT/${TAG}_cal_w -name "*.db" | head -1) $RES/${TAG}_fetch_calibration.json
