@@ -20,7 +20,7 @@ def _make(scenario, agent, model_type, E, seed=0, **cfg):
     from deeprl_signal_control_amd.scenario import build_scenario
     from oracle.iql_oracle import OracleIQL
     scn = build_scenario(scenario, agent)
-    mc = dict(batch_size=20, buffer_size=1000, reward_norm=3000.0 if scenario == 'large_grid' else 1.0)
+    mc = dict(batch_size=20, buffer_size=1000, reward_norm=3000.0 if scenario == 'large_grid' else 1.0 if scenario == 'real_net' else 100.0)
     mc.update(cfg)
     m = VecIQL(scn.n_s_ls, scn.n_a_ls, scn.n_w_ls, E, scn.s_max, int(scn.green_tab.shape[1]), mc, total_step=10000,
                seed=seed, model_type=model_type)
@@ -116,7 +116,8 @@ def _rand_obs_off_the_kinks(scn, E, rng, o, thr=5e-6):
     ('large_grid', 'iqld', 'dqn', 6, 30, '1'), ('large_grid', 'iqld', 'dqn', 6, 30, '0'), ('large_grid', 'iqll', 'lr', 9, 1000, '0'),
     ('real_net', 'iqld', 'dqn', 4, 64, '1'), ('real_net', 'iqld', 'dqn', 4, 64, '0'), ('large_grid', 'iqld', 'dqn', 3, 25, '1'),
     ('large_grid', 'iqld', 'dqn', 70, 22, '1'), ('large_grid', 'iqld', 'dqn', 1024, 22, '1'), ('large_grid', 'iqld', 'dqn', 1024, 22, '0'),
-    ('real_net', 'iqld', 'dqn', 512, 22, '1'), ('large_grid', 'iqll', 'lr', 1024, 22, '0')])        # IQL-LR at the benchmarked batch too
+    ('real_net', 'iqld', 'dqn', 512, 22, '1'), ('large_grid', 'iqll', 'lr', 1024, 22, '0'),         # IQL-LR at the benchmarked batch too
+    ('small_grid', 'iqld', 'dqn', 7, 40, '1')])              # s_max 12, 2 - 3 actions, wait inputs in the first 16-feature group
 def test_replay_minibatch_gradient_and_adam(scenario, agent, model_type, E, cap, fused, monkeypatch):
     """Fill the rings past their capacity, then three minibatch steps: replay indices (Floyd on the documented
     uniform) exact, TD loss / gradient / clip norm / Adam-updated parameters against the oracle."""
