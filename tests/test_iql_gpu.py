@@ -281,3 +281,36 @@ def test_every_instance_draws_its_own_minibatch():
     gf = full.grad_tensor().cpu().numpy()
     assert np.isfinite(gf).all() and np.abs(gf).max() > 0
     full.close()
+
+
+def test_other_batch_sizes_take_the_generic_draw_and_the_same_kernels():
+    """batch_size != 20 (the reference's value, which has its own register-resident Floyd draw): the generic sampler and the fused
+    learner at 8 rows per instance -- indices exact, gradients against the oracle."""
+    from deeprl_signal_control_amd import _lib
+    scn, m, o = _make('large_grid', 'iqld', 'dqn', 9, seed=4, buffer_size=16, batch_size=8)
+    assert m.fused and m.n_step == 8
+    A, B, E = scn.n_agent, 8, 9
+    rng = np.random.RandomState(1)
+    obs = _rand_obs(scn, E, rng)
+    for t in range(19):
+        nobs = _rand_obs(scn, E, rng)
+        act = np.stack([rng.randint(0, n, E) for n in scn.n_a_ls], 1).astype(np.int32)
+        rew = -rng.rand(E, A) * 3.0 * m.cfg['reward_norm']
+        done = (rng.rand(E) < 0.1).astype(np.uint8)
+        m.add_transition(torch.from_numpy(obs).cuda(), torch.from_numpy(act).cuda(), torch.from_numpy(rew).cuda(),
+                         torch.from_numpy(nobs).cuda(), torch.from_numpy(done).cuda())
+        o.add_transition(obs, act, rew, nobs, done)
+        obs = nobs
+    _lib.check(m._L.tsc_iql_compute_grads(m._h, m.replay_seed, m.update_step))
+    idx = np.zeros((E, A, B), np.int32)
+    _lib.check(m._L.tsc_iql_debug_batch(m._h, idx.ctypes.data_as(C.c_void_p)))
+    g = m.layout.unpack(m.grad_tensor().cpu().numpy())
+    losses, norms, og = o.minibatch_step(1e-3)
+    np.testing.assert_array_equal(idx, o.last_idx)
+    assert all(len(set(idx[e, a])) == B and idx[e, a].max() < 16 for e in range(E) for a in range(A))
+    for a in range(A):
+        for k, ref in og[a].items():
+            scale = max(np.abs(ref).max(), 1e-9)
+            # 72 rows: a unit within 1e-6 of its ReLU kink is a ~ 1e-4 event per tensor; such a tensor would fail loudly, not silently
+            assert np.abs(g[a][k] - ref).max() <= 5e-5 * scale, (a, k)
+    m.close()
